@@ -1,0 +1,240 @@
+"""Generate tests/golden/*.npz by running the REAL reference (ad12/DOSMA @ /root/reference).
+
+Build-side tool, this container only (see oracle/ref_harness.py).  The reference's own tests hold no
+stored vectors for the fit path (all its data is unseeded random), so the
+golden vectors are produced here from seeded inputs by calling the reference's public API:
+``dosma.curve_fit``, ``dosma.CurveFitter``, ``dosma.MonoExponentialFit`` (dosma/core/fitting.py).
+A fixture is data only: inputs + the reference's outputs (+ scipy's ier/nfev for the same call).
+
+    python oracle/make_golden.py            # writes tests/golden/g*.npz  (~1-2 min, 8 workers)
+"""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle.ref_harness import load_reference  # noqa: E402
+
+dosma = load_reference()
+MV = dosma.MedicalVolume
+NW = min(8, os.cpu_count() or 1)
+
+
+def vols(y3d):
+    """list of MedicalVolumes from (E, X, Y, Z)."""
+    return [MV(np.array(v), affine=np.eye(4)) for v in y3d]
+
+
+def scipy_info(x, y, p0):
+    """ier / nfev of the very call the reference makes (fitting.py:1030), per voxel."""
+    from scipy import optimize as sop
+
+    ier = np.zeros(y.shape[1], np.int32)
+    nfev = np.zeros(y.shape[1], np.int32)
+    for i in range(y.shape[1]):
+        yi = y[:, i]
+        if (yi == 0).all():
+            continue
+        p0i = tuple(float(v[i]) if isinstance(v, np.ndarray) else float(v) for v in p0)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = sop.curve_fit(dosma.monoexponential, x, yi, p0=p0i, ftol=1e-5, maxfev=100,
+                                    full_output=True)
+            ier[i], nfev[i] = out[4], out[2]["nfev"]
+        except RuntimeError:
+            ier[i], nfev[i] = 5, -1
+    return ier, nfev
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def g1():
+    """The reference tests' own generator, seeded (tests/core/test_fitting.py:18-31, 199-277, 283-291)."""
+    rng = np.random.default_rng(1)
+    shape = (10, 10, 20)
+    x = np.asarray([0.5, 1.0, 2.0, 4.0])
+    b = rng.random(shape) + 0.1
+    y = np.stack([dosma.monoexponential(t, 1.0, b) for t in x])  # float64
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tc_def, r2_def = dosma.MonoExponentialFit(decimal_precision=8).fit(x, vols(y))
+        tc_pf, r2_pf = dosma.MonoExponentialFit(tc0="polyfit", decimal_precision=8).fit(x, vols(y))
+        popt, r2 = dosma.CurveFitter(dosma.monoexponential).fit(x, vols(y))
+        mask = rng.random(shape) > 0.5
+        popt_m, r2_m = dosma.CurveFitter(dosma.monoexponential).fit(x, vols(y), mask=mask)
+        tc_m, r2_tm = dosma.MonoExponentialFit(decimal_precision=8).fit(x, vols(y), mask)
+        # zeros in echo 0 (test_fitting.py:267-277)
+        y0 = y.copy()
+        y0[0, :5, :5] = 0
+        tc_z, r2_z = dosma.MonoExponentialFit(tc0="polyfit", decimal_precision=8).fit(x, vols(y0))
+    save("g1_tests_generator.npz", x=x, b=b, y=y, tc_default=tc_def.A, r2_default=r2_def.A,
+         tc_polyfit=tc_pf.A, r2_polyfit=r2_pf.A, popt=popt.A, r2=r2.A, mask=mask,
+         popt_masked=popt_m.A, r2_masked=r2_m.A, tc_masked=tc_m.A, r2_tc_masked=r2_tm.A,
+         y_zero_echo0=y0, tc_zero_echo0=tc_z.A, r2_zero_echo0=r2_z.A)
+
+
+def cfg2_like(rng, n_tissue, n_bg, snr, E=8):
+    """SURVEY.md 8(d) cfg2 distribution: S0~U(300,1500), T2~U(15,80) ms, TE=10..80, sigma=mean(S0)/SNR."""
+    x = np.arange(1, E + 1) * 10.0
+    s0 = rng.uniform(300, 1500, n_tissue)
+    t2 = rng.uniform(15, 80, n_tissue)
+    y = s0 * np.exp(-x[:, None] / t2) + (900.0 / snr) * rng.standard_normal((E, n_tissue))
+    y = np.concatenate([y, np.zeros((E, n_bg))], axis=1).astype(np.float32)
+    return x, y
+
+
+def g2():
+    """8-echo noisy set (headline config), fixed p0 and polyfit init, three SNRs."""
+    rng = np.random.default_rng(20260928)
+    out = {}
+    for snr in (100, 50, 20):
+        x, y = cfg2_like(rng, 4000, 200, snr)
+        N = y.shape[1]
+        # raw curve_fit, p0 = MonoExponentialFit's default (1, -1/30)   (fitting.py:720)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            popt, r2 = dosma.curve_fit(dosma.monoexponential, x, y, p0=(1.0, -1 / 30.0),
+                                       num_workers=NW, chunksize=500)
+            ier, nfev = scipy_info(x, y, (1.0, -1 / 30.0))
+            # full recipes on a (N,1,1) volume
+            y3 = y.reshape(y.shape[0], N, 1, 1)
+            tc_a, r2_a = dosma.MonoExponentialFit(num_workers=NW).fit(x, vols(y3))
+            tc_b, r2_b = dosma.MonoExponentialFit(tc0="polyfit", decimal_precision=3,
+                                                  num_workers=NW).fit(x, vols(y3))
+        out.update({f"y_snr{snr}": y, f"popt_snr{snr}": popt, f"r2_snr{snr}": r2,
+                    f"ier_snr{snr}": ier, f"nfev_snr{snr}": nfev,
+                    f"tcA_snr{snr}": tc_a.A.reshape(-1), f"r2A_snr{snr}": r2_a.A.reshape(-1),
+                    f"tcB_snr{snr}": tc_b.A.reshape(-1), f"r2B_snr{snr}": r2_b.A.reshape(-1)})
+    save("g2_cfg2_8echo.npz", x=x, **out)
+
+
+def g3():
+    """Edge cases: skip rule, negatives, pure noise, flat signal, maxfev exhaustion, far p0, int input."""
+    rng = np.random.default_rng(3)
+    E = 8
+    x = np.arange(1, E + 1) * 10.0
+    cols = []
+    cols.append(np.zeros(E))                                   # all zero -> skipped
+    cols.append(np.r_[0.0, 500 * np.exp(-x[1:] / 40)])         # zero only in echo 0
+    cols.append(-500 * np.exp(-x / 40))                        # negative signal
+    cols.append(np.full(E, 700.0))                             # flat (b -> 0)
+    cols.append(500 * np.exp(+x / 60))                         # growing
+    cols.append(np.r_[1000.0, np.zeros(E - 1)])                # spike
+    cols.append(1e-3 * np.exp(-x / 25))                        # tiny amplitude
+    cols.append(3e4 * np.exp(-x / 5))                          # very fast decay
+    noise = 20 * rng.standard_normal((E, 600))                 # pure-noise background (maxfev cases)
+    y = np.concatenate([np.stack(cols, axis=1), noise], axis=1)
+    p0 = (1.0, -1 / 30.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        popt, r2 = dosma.curve_fit(dosma.monoexponential, x, y, p0=p0)
+        ier, nfev = scipy_info(x, y, p0)
+        popt_none, r2_none = dosma.curve_fit(dosma.monoexponential, x, y)  # p0=None -> ones
+        y3 = y.reshape(E, -1, 1, 1)
+        tc_pf, r2_pf = dosma.MonoExponentialFit(tc0="polyfit", bounds=(0, np.inf),
+                                                decimal_precision=3).fit(x, vols(y3))  # Cones recipe
+        # the reference tests' far initial guess (test_fitting.py:98 p0=(1.0, 50.0), x = 1..4)
+        x4 = np.asarray([1, 2, 3, 4])
+        a = rng.random(50)
+        b = rng.random(50)
+        y4 = np.stack([dosma.monoexponential(x4, a[i], b[i]) for i in range(50)], axis=-1)
+        popt_1_50, r2_1_50 = dosma.curve_fit(dosma.monoexponential, x4, y4, p0=(1.0, 50.0))
+        popt_1_1, r2_1_1 = dosma.curve_fit(dosma.monoexponential, x4, y4)
+        # integer input (DICOM-like int16)
+        yi = np.clip(np.rint(900 * np.exp(-x[:, None] / rng.uniform(20, 70, 300))
+                             + 15 * rng.standard_normal((E, 300))), -32768, 32767).astype(np.int16)
+        popt_i, r2_i = dosma.curve_fit(dosma.monoexponential, x, yi, p0=p0)
+        tc_i, r2_ti = dosma.MonoExponentialFit(tc0="polyfit", decimal_precision=3).fit(
+            x, vols(yi.reshape(E, -1, 1, 1)))
+    save("g3_edges.npz", x=x, y=y, popt=popt, r2=r2, ier=ier, nfev=nfev, popt_p0none=popt_none,
+         r2_p0none=r2_none, tc_cones=tc_pf.A.reshape(-1), r2_cones=r2_pf.A.reshape(-1),
+         x4=x4, y4=y4, popt_1_50=popt_1_50, r2_1_50=r2_1_50, popt_1_1=popt_1_1, r2_1_1=r2_1_1,
+         y_int16=yi, popt_int16=popt_i, r2_int16=r2_i, tc_int16=tc_i.A.reshape(-1),
+         r2_tc_int16=r2_ti.A.reshape(-1))
+
+
+def g4():
+    """Scan recipes: CubeQuant T1rho (cube_quant.py:170-176) with an ROI mask,
+    Mapss echo subsets (mapss.py:170-204)."""
+    rng = np.random.default_rng(4)
+    shape = (24, 24, 6)
+    tsl = np.asarray([1.0, 10.0, 30.0, 60.0])
+    t1r = rng.uniform(20, 90, shape)
+    s0 = rng.uniform(400, 1200, shape)
+    y = s0 * np.exp(-tsl[:, None, None, None] / t1r) + 12 * rng.standard_normal((4,) + shape)
+    y = np.rint(y).astype(np.int16)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    r = np.sqrt((zz - 12) ** 2 + (yy - 12) ** 2)
+    mask = ((r > 6) & (r < 9)).astype(np.uint8)  # shell-like ROI
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tc, r2 = dosma.MonoExponentialFit(bounds=(0, 500), tc0="polyfit", decimal_precision=3,
+                                          num_workers=NW).fit(tsl, vols(y), MV(mask, np.eye(4)))
+        tc_nomask, r2_nomask = dosma.MonoExponentialFit(
+            bounds=(0, 500), tc0="polyfit", decimal_precision=3, num_workers=NW).fit(tsl, vols(y))
+        # Mapss: 7 echoes; T1rho from echoes 0-3, T2 from echoes [0,4,5,6]
+        te_all = np.asarray([0.0, 10.0, 40.0, 80.0, 12.87, 25.69, 51.39])
+        ym = np.stack([s0 * np.exp(-t / t1r) for t in te_all]) + 8 * rng.standard_normal((7,) + shape)
+        ym = ym.astype(np.float32)
+        idx = [0, 4, 5, 6]
+        tc_t2, r2_t2 = dosma.MonoExponentialFit(bounds=(0, 100), tc0="polyfit", decimal_precision=3,
+                                                num_workers=NW).fit(te_all[idx], vols(ym[idx]))
+    save("g4_recipes.npz", tsl=tsl, y=y, mask=mask, tc=tc.A, r2=r2.A, tc_nomask=tc_nomask.A,
+         r2_nomask=r2_nomask.A, te_mapss=te_all[idx], y_mapss=ym[idx], tc_mapss=tc_t2.A,
+         r2_mapss=r2_t2.A)
+
+
+def g5():
+    """_process_params matrix (fitting.py:109-146; tests/core/test_fitting.py:325-412)."""
+    rng = np.random.default_rng(5)
+    shape = (10, 10, 4)
+    x = np.asarray([0.5, 1.0, 2.0, 4.0])
+    a = np.ones(shape)
+    a[5:] = 1.5
+    b = rng.random(shape) + 0.1
+    b[:5] = 1.5
+    y = np.stack([dosma.monoexponential(t, a, b) for t in x])
+    y += 0.02 * rng.standard_normal(y.shape)
+    out = {}
+    ufunc = lambda v: 2 * np.abs(v) + 5  # noqa: E731
+    cases = {
+        "bounds_all": dict(out_bounds=(0, 1.2)),
+        "bounds_second": dict(out_bounds=[(-np.inf, np.inf), (0, 1.2)]),
+        "bounds_first": dict(out_bounds=[(0, 1.2)]),
+        "nan_to_num": dict(out_bounds=(0, 1.2), nan_to_num=0.0),
+        "ufunc_all": dict(out_ufuncs=ufunc),
+        "ufunc_second": dict(out_ufuncs=[None, ufunc]),
+        "ufunc_first": dict(out_ufuncs=[ufunc]),
+        "r2_none": dict(r2_threshold=None),
+        "r2_099": dict(r2_threshold=0.9999, nan_to_num=-1.0),
+        "p0_tuple": dict(p0=(1.0, 0.5)),
+    }
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k, kw in cases.items():
+            popt, r2 = dosma.CurveFitter(dosma.monoexponential, **kw).fit(x, vols(y))
+            out[f"popt_{k}"] = popt.A
+            out[f"r2_{k}"] = r2.A
+    save("g5_process_params.npz", x=x, y=y, **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    for name in which:
+        t = time.time()
+        print(name, "...")
+        globals()[name]()
+        print(f"  {time.time() - t:.1f}s")

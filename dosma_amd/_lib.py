@@ -1,0 +1,249 @@
+"""ctypes binding of the C ABI in include/qmri.h (libqmri_hip.so).
+
+This is the only place Python touches the native library.  There is NO CPU fallback: if the
+library is missing or no HIP device is present, calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libqmri_hip.so")
+
+QMRI_OK = 0
+QMRI_ERR_ARG = -1
+QMRI_ERR_UNSUPPORTED = -2
+QMRI_ERR_HIP = -3
+QMRI_ERR_NONFINITE = -4
+
+QMRI_F32, QMRI_F64, QMRI_I16, QMRI_U16 = 0, 1, 2, 3
+INIT_SCALAR, INIT_PER_VOXEL, INIT_LOGLIN = 0, 1, 2
+MAX_ECHOES = 32
+
+_NP2Q = {np.dtype(np.float32): QMRI_F32, np.dtype(np.float64): QMRI_F64,
+         np.dtype(np.int16): QMRI_I16, np.dtype(np.uint16): QMRI_U16}
+
+
+class QmriPost(ctypes.Structure):
+    _fields_ = [
+        ("enable", ctypes.c_int32), ("inv_abs_b", ctypes.c_int32), ("use_bounds", ctypes.c_int32),
+        ("use_r2_thr", ctypes.c_int32), ("use_nan_to_num", ctypes.c_int32),
+        ("decimals", ctypes.c_int32),
+        ("lb", ctypes.c_double * 2), ("ub", ctypes.c_double * 2),
+        ("r2_threshold", ctypes.c_double), ("nan_value", ctypes.c_double),
+    ]
+
+
+class QmriMonoexpArgs(ctypes.Structure):
+    _fields_ = [
+        ("y", ctypes.c_void_p), ("y_dtype", ctypes.c_int32), ("E", ctypes.c_int32),
+        ("N", ctypes.c_int64), ("ld", ctypes.c_int64),
+        ("x", ctypes.POINTER(ctypes.c_double)), ("mask", ctypes.c_void_p),
+        ("init", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("a0", ctypes.c_double), ("b0", ctypes.c_double),
+        ("a0v", ctypes.c_void_p), ("b0v", ctypes.c_void_p),
+        ("ftol", ctypes.c_double), ("xtol", ctypes.c_double), ("gtol", ctypes.c_double),
+        ("factor", ctypes.c_double), ("r2_eps", ctypes.c_double),
+        ("maxfev", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+        ("post", QmriPost),
+        ("popt", ctypes.c_void_p), ("r2", ctypes.c_void_p), ("tc", ctypes.c_void_p),
+        ("out_dtype", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("info", ctypes.c_void_p), ("nfev", ctypes.c_void_p),
+        ("device", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+EXPORTS = (
+    "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
+    "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
+    "qmri_monoexp_kernel_name",
+)
+
+_lib = None
+_lock = threading.Lock()
+
+
+class QmriError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _SO
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and load it
+    by file name; libqmri_hip.so asks for the SONAME.  If ours pulled in /opt/rocm's copy first, a
+    later ``import torch`` would bring a SECOND runtime into the process and see no GPU.  Loading
+    torch's copy first (cheap: no ``import torch``) makes both resolve to the same runtime, so
+    device pointers and streams can be shared (bench.py, multi-GPU driver).
+    """
+    import importlib.util
+    import sys
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            if "torch" in sys.modules:
+                raise
+
+
+def load():
+    """Load libqmri_hip.so (raises if it has not been built: ``python -m dosma_amd.build``)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_SO):
+            raise QmriError(
+                f"{_SO} not found: the HIP extension is not built (run `python -m dosma_amd.build`). "
+                "dosma_amd has no CPU fallback.")
+        _share_hip_runtime_with_torch()
+        lib = ctypes.CDLL(_SO)
+        lib.qmri_version.restype = ctypes.c_int
+        lib.qmri_device_count.restype = ctypes.c_int
+        lib.qmri_last_error.restype = ctypes.c_char_p
+        lib.qmri_monoexp_kernel_name.restype = ctypes.c_char_p
+        lib.qmri_monoexp_kernel_name.argtypes = [ctypes.POINTER(QmriMonoexpArgs)]
+        lib.qmri_monoexp_defaults.argtypes = [ctypes.POINTER(QmriMonoexpArgs)]
+        lib.qmri_monoexp_defaults.restype = None
+        lib.qmri_monoexp_fit_device.argtypes = [ctypes.POINTER(QmriMonoexpArgs), ctypes.c_void_p]
+        lib.qmri_monoexp_fit_device.restype = ctypes.c_int
+        lib.qmri_monoexp_fit_host.argtypes = [ctypes.POINTER(QmriMonoexpArgs)]
+        lib.qmri_monoexp_fit_host.restype = ctypes.c_int
+        lib.qmri_set_timing.argtypes = [ctypes.c_int]
+        lib.qmri_set_timing.restype = None
+        lib.qmri_last_kernel_ms.restype = ctypes.c_float
+        _lib = lib
+        return lib
+
+
+def check(rc: int):
+    if rc == QMRI_OK:
+        return
+    msg = load().qmri_last_error().decode("utf-8", "replace")
+    if rc in (QMRI_ERR_ARG, QMRI_ERR_NONFINITE):
+        raise ValueError(msg)
+    if rc == QMRI_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise QmriError(msg)
+
+
+def require_device() -> int:
+    n = load().qmri_device_count()
+    if n <= 0:
+        raise QmriError("no HIP device visible: dosma_amd computes on the GPU only (no CPU fallback)")
+    return n
+
+
+def default_args() -> QmriMonoexpArgs:
+    a = QmriMonoexpArgs()
+    load().qmri_monoexp_defaults(ctypes.byref(a))
+    return a
+
+
+def qdtype(dt) -> int:
+    dt = np.dtype(dt)
+    if dt not in _NP2Q:
+        raise ValueError(f"unsupported sample dtype {dt}")
+    return _NP2Q[dt]
+
+
+def _ptr(arr):
+    return None if arr is None else ctypes.c_void_p(arr.ctypes.data)
+
+
+def set_post(a: QmriMonoexpArgs, inv_abs_b=False, bounds=None, r2_threshold=None, nan_to_num=None,
+             decimals=None):
+    """Fill the fused post-processing block (``_Fitter._process_params`` semantics)."""
+    p = a.post
+    p.enable = 1
+    p.inv_abs_b = 1 if inv_abs_b else 0
+    p.use_bounds = 0
+    if bounds is not None:
+        p.use_bounds = 1
+        for j in range(2):
+            p.lb[j] = float(bounds[j][0])
+            p.ub[j] = float(bounds[j][1])
+    p.use_r2_thr = 0 if r2_threshold is None else 1
+    p.r2_threshold = 0.0 if r2_threshold is None else float(r2_threshold)
+    p.use_nan_to_num = 0 if nan_to_num is None else 1
+    p.nan_value = 0.0 if nan_to_num is None else float(nan_to_num)
+    p.decimals = -1000000 if decimals is None else int(decimals)
+
+
+def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=None, b0v=None,
+                     post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=0,
+                     ftol=None, maxfev=None, r2_eps=None):
+    """Run the HIP fit on host (numpy) buffers.  ``y``: (E, N) C-contiguous, echo-major.
+
+    Returns dict(popt (N,2), r2 (N,), [tc (N,)], [info (N,) int8, nfev (N,) int16]).
+    """
+    lib = load()
+    require_device()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.asarray(y)
+    if y.ndim != 2:
+        raise ValueError("y must be (E, N)")
+    if not y.flags.c_contiguous:
+        y = np.ascontiguousarray(y)
+    E, N = y.shape
+    if x.shape != (E,):
+        raise ValueError(f"x has shape {x.shape}, expected ({E},)")
+    a = default_args()
+    a.y = _ptr(y)
+    a.y_dtype = qdtype(y.dtype)
+    a.E, a.N, a.ld = E, N, N
+    a.x = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    keep = [x, y]
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+        if mask.shape[0] != N:
+            raise ValueError("mask length mismatch")
+        a.mask = _ptr(mask)
+        keep.append(mask)
+    a.init = init
+    a.a0, a.b0 = float(p0[0]), float(p0[1])
+    for name, arr in (("a0v", a0v), ("b0v", b0v)):
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+            if arr.shape[0] != N:
+                raise ValueError(f"Got {arr.shape[0]} values for {name}. Expected {N}")
+            setattr(a, name, _ptr(arr))
+            keep.append(arr)
+    if ftol is not None:
+        a.ftol = float(ftol)
+    if maxfev is not None:
+        a.maxfev = int(maxfev)
+    if r2_eps is not None:
+        a.r2_eps = float(r2_eps)
+    if post is not None:
+        set_post(a, **post)
+    od = np.dtype(out_dtype)
+    a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
+    out = {"popt": np.empty((N, 2), dtype=od), "r2": np.empty(N, dtype=od)}
+    a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
+    if want_tc:
+        out["tc"] = np.empty(N, dtype=od)
+        a.tc = _ptr(out["tc"])
+    if want_info:
+        out["info"] = np.empty(N, dtype=np.int8)
+        out["nfev"] = np.empty(N, dtype=np.int16)
+        a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
+    a.device = int(device)
+    check(lib.qmri_monoexp_fit_host(ctypes.byref(a)))
+    del keep
+    return out

@@ -1,0 +1,713 @@
+// monoexp_lm.hip -- per-voxel mono-exponential Levenberg-Marquardt fit for gfx950 (MI355X).
+//
+// Replaces the per-voxel Python loop of the reference
+//     /root/reference/dosma/core/fitting.py:855-868   (curve_fit: for i in range(N): fitter(y_T[i]))
+//     /root/reference/dosma/core/fitting.py:1026-1073 (_curve_fit: skip rule, scipy.optimize.curve_fit,
+//                                                     r2, RuntimeError -> NaN)
+// whose arithmetic is MINPACK lmdif as configured by scipy.optimize.leastsq (mode 1, factor 100,
+// xtol 1.49012e-8, gtol 0) with DOSMA's ftol = 1e-5 and maxfev = 100.
+//
+// Design (CDNA4, no MFMA -- this is not a dense contraction):
+//   * one voxel per lane, the whole LM state (x, R, Q^T f, diag, delta, par, ...) in fp64 VGPRs;
+//     fp64 because the parity target is an EARLY-STOPPED solver: the stop tests compare
+//     1 - (|f+|/|f|)^2 against 1e-5, which fp32 cannot resolve;
+//   * MINPACK's control flow is kept exactly (lmpar trust region, ratio tests, info codes, nfev
+//     accounting with +n per Jacobian) but the Jacobian is analytic and shares the E exponentials
+//     of the trial point, so one LM iteration costs E exps;
+//   * waves are independent persistent workers: a wave claims a tile of SUB consecutive voxels
+//     with one atomic, stages it echo-major into its private LDS slice with coalesced
+//     16-byte-per-lane loads, and its lanes *pull* voxels from that tile whenever they finish one
+//     (wave ballot + mbcnt rank) -- so masked-out / all-zero voxels and early-converging voxels do
+//     not leave lanes idle behind the slowest voxel of a fixed 64-voxel group;
+//   * newly pulled voxels enter the same instruction stream as running ones (state INIT shares the
+//     model evaluation and the QR with state ITER), so there is no separate divergent init path;
+//   * the epilogue of MonoExponentialFit (1/|b|, bounds, r2 threshold, nan_to_num, rounding) is fused
+//     into the lane's final store.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "qmri_internal.h"
+
+namespace qmri {
+
+constexpr int kSub = 256;        // voxels per tile (per wave): 4 per lane -> 16-byte loads for f32
+constexpr int kRefillIdle = 16;  // refill the wave when at least this many lanes are idle
+
+__device__ __forceinline__ double norm2(double a, double b) {
+    const double s = a * a + b * b;
+    if (s > 1e-280 && s < 1e300) return sqrt(s);
+    const double m = fmax(fabs(a), fabs(b));
+    if (!(m > 0.0) || isinf(m)) return (isnan(a) || isnan(b)) ? (a + b) : m;
+    const double ra = a / m, rb = b / m;
+    return m * sqrt(ra * ra + rb * rb);
+}
+
+// Givens rotation of MINPACK qrsolv
+__device__ __forceinline__ void givens(double rkk, double sdk, double &c, double &s) {
+    if (fabs(rkk) < fabs(sdk)) {
+        const double cotan = rkk / sdk;
+        s = 0.5 / sqrt(0.25 + 0.25 * cotan * cotan);
+        c = s * cotan;
+    } else {
+        const double tn = sdk / rkk;
+        c = 0.5 / sqrt(0.25 + 0.25 * tn * tn);
+        s = c * tn;
+    }
+}
+
+// qrsolv for n = 2.  R = [r11 r12; 0 r22] (pivoted columns l0, l1), dg = sqrt(par)*diag by ORIGINAL
+// parameter index, qtb = Q^T f.  Returns x by original index and the triangular factor S
+// (sd0, sd1 diagonal, s10 off-diagonal) that lmpar's Newton correction needs.
+__device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, int l0, double dg0,
+                                        double dg1, double qtb0, double qtb1, double &x0, double &x1,
+                                        double &sd0, double &sd1, double &s10) {
+    const double dl0 = l0 ? dg1 : dg0;
+    const double dl1 = l0 ? dg0 : dg1;
+    double rr00 = r11, rr11 = r22, wa0 = qtb0, wa1 = qtb1;
+    s10 = r12;
+    if (dl0 != 0.0) {
+        double c, s;
+        givens(rr00, dl0, c, s);
+        rr00 = c * rr00 + s * dl0;
+        double qtbpj = -s * wa0;
+        wa0 = c * wa0;
+        const double sdi = -s * s10;
+        s10 = c * s10;
+        if (sdi != 0.0) {
+            givens(rr11, sdi, c, s);
+            rr11 = c * rr11 + s * sdi;
+            wa1 = c * wa1 + s * qtbpj;
+        }
+    }
+    sd0 = rr00;
+    if (dl1 != 0.0) {
+        double c, s;
+        givens(rr11, dl1, c, s);
+        rr11 = c * rr11 + s * dl1;
+        wa1 = c * wa1;
+    }
+    sd1 = rr11;
+    if (sd0 == 0.0) {
+        wa0 = 0.0;
+        wa1 = 0.0;
+    } else if (sd1 == 0.0) {
+        wa1 = 0.0;
+        wa0 = wa0 / sd0;
+    } else {
+        wa1 = wa1 / sd1;
+        wa0 = (wa0 - s10 * wa1) / sd0;
+    }
+    x0 = l0 ? wa1 : wa0;
+    x1 = l0 ? wa0 : wa1;
+}
+
+// MINPACK lmpar for n = 2: step p (by original index) with ||diag*p|| ~ delta, and the LM parameter.
+__device__ __forceinline__ void lmpar2(double r11, double r12, double r22, int l0, double dg0,
+                                       double dg1, double qtb0, double qtb1, double delta,
+                                       double &par, double &x0, double &x1) {
+    const double dwarf = DBL_MIN;
+    const double dl0 = l0 ? dg1 : dg0;  // diag(ipvt(0))
+    const double dl1 = l0 ? dg0 : dg1;  // diag(ipvt(1))
+    // Gauss-Newton direction
+    double w0 = qtb0, w1 = qtb1;
+    int nsing = 2;
+    if (r11 == 0.0) {
+        nsing = 0;
+        w0 = 0.0;
+        w1 = 0.0;
+    } else if (r22 == 0.0) {
+        nsing = 1;
+        w1 = 0.0;
+        w0 = w0 / r11;
+    } else {
+        w1 = w1 / r22;
+        w0 = (w0 - r12 * w1) / r11;
+    }
+    x0 = l0 ? w1 : w0;
+    x1 = l0 ? w0 : w1;
+    double wa20 = dg0 * x0, wa21 = dg1 * x1;
+    double dxnorm = norm2(wa20, wa21);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) {
+        par = 0.0;
+        return;
+    }
+    double parl = 0.0;
+    if (nsing >= 2) {
+        double t0 = dl0 * ((l0 ? wa21 : wa20) / dxnorm);
+        double t1 = dl1 * ((l0 ? wa20 : wa21) / dxnorm);
+        t0 = t0 / r11;
+        t1 = (t1 - r12 * t0) / r22;
+        const double temp = norm2(t0, t1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+    const double g0 = (r11 * qtb0) / dl0;
+    const double g1 = (r12 * qtb0 + r22 * qtb1) / dl1;
+    const double gnorm = norm2(g0, g1);
+    double paru = gnorm / delta;
+    if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
+    par = fmax(par, parl);
+    par = fmin(par, paru);
+    if (par == 0.0) par = gnorm / dxnorm;
+    for (int iter = 1;; ++iter) {
+        if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
+        const double sp = sqrt(par);
+        double sd0, sd1, s10;
+        qrsolv2(r11, r12, r22, l0, sp * dg0, sp * dg1, qtb0, qtb1, x0, x1, sd0, sd1, s10);
+        wa20 = dg0 * x0;
+        wa21 = dg1 * x1;
+        dxnorm = norm2(wa20, wa21);
+        const double fp_old = fp;
+        fp = dxnorm - delta;
+        if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || iter == 10)
+            break;
+        double t0 = dl0 * ((l0 ? wa21 : wa20) / dxnorm);
+        double t1 = dl1 * ((l0 ? wa20 : wa21) / dxnorm);
+        t0 = t0 / sd0;
+        t1 = (t1 - s10 * t0) / sd1;
+        const double temp = norm2(t0, t1);
+        const double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0.0) parl = fmax(parl, par);
+        if (fp < 0.0) paru = fmin(paru, par);
+        par = fmax(parl, par + parc);
+    }
+}
+
+__device__ __forceinline__ double nan_to_num(double v, double nanv) {
+    if (isnan(v)) return nanv;
+    if (isinf(v)) return v > 0 ? DBL_MAX : -DBL_MAX;
+    return v;
+}
+
+// numpy.around(v, d): multiply by 10**d, rint, divide (d >= 0); divide / rint / multiply (d < 0)
+__device__ __forceinline__ double around(double v, int decimals, double p10) {
+    if (decimals == 0) return rint(v);
+    if (decimals > 0) return rint(v * p10) / p10;
+    return rint(v / p10) * p10;
+}
+
+// final store of one voxel: raw (a, b, r2) -> reference post-processing -> popt / r2 / tc / info / nfev
+__device__ __forceinline__ void finish_voxel(const FitKArgs &A, long long v, double pa, double pb,
+                                             double r2, int info, int nfev, bool outside_mask) {
+    double tc = pb;
+    const qmri_post &P = A.post;
+    if (outside_mask) {
+        // scatter fill (fitting.py:205-215): nan_to_num value if given, else NaN -- also for r2
+        const double fill = (P.enable && P.use_nan_to_num) ? P.nan_value : NAN;
+        pa = pb = tc = r2 = fill;
+    } else if (P.enable) {
+        if (P.inv_abs_b) pb = 1.0 / fabs(pb);
+        if (P.use_bounds) {
+            if (pa < P.lb[0] || pa > P.ub[0]) pa = NAN;
+            if (pb < P.lb[1] || pb > P.ub[1]) pb = NAN;
+        }
+        if (P.use_r2_thr && r2 < P.r2_threshold) pa = pb = NAN;
+        if (P.use_nan_to_num) {
+            pa = nan_to_num(pa, P.nan_value);
+            pb = nan_to_num(pb, P.nan_value);
+        }
+        tc = pb;
+    }
+    if (A.out_f64) {
+        double2 o;
+        o.x = pa;
+        o.y = pb;
+        static_cast<double2 *>(A.popt)[v] = o;
+        static_cast<double *>(A.r2)[v] = r2;
+    } else {
+        float2 o;
+        o.x = static_cast<float>(pa);
+        o.y = static_cast<float>(pb);
+        static_cast<float2 *>(A.popt)[v] = o;
+        static_cast<float *>(A.r2)[v] = static_cast<float>(r2);
+    }
+    if (A.tc) {
+        if (P.enable && P.decimals != QMRI_NO_ROUND) tc = around(tc, P.decimals, A.p10);
+        if (A.out_f64)
+            static_cast<double *>(A.tc)[v] = tc;
+        else
+            static_cast<float *>(A.tc)[v] = static_cast<float>(tc);
+    }
+    if (A.info) A.info[v] = static_cast<signed char>(info);
+    if (A.nfev) A.nfev[v] = static_cast<short>(nfev);
+}
+
+// ---- tile staging: global (any dtype, echo-major) -> wave-private LDS slice [E][kSub] of LT --------
+template <typename S, typename LT>
+__device__ __forceinline__ void stage_rows(const S *__restrict__ g, long long ld, int E, int count,
+                                           LT *__restrict__ tile, int lane, bool vec_ok) {
+    for (int e = 0; e < E; ++e) {
+        const S *row = g + (long long)e * ld;
+        LT *dst = tile + e * kSub;
+        if (vec_ok && count == kSub) {
+            // 4 consecutive elements per lane: one 16-byte (f32) / 8-byte (i16) / 2x16-byte (f64) load
+            struct alignas(sizeof(S) * 4) V4 {
+                S v[4];
+            };
+            const V4 q = *reinterpret_cast<const V4 *>(row + lane * 4);
+            struct alignas(sizeof(LT) * 4) L4 {
+                LT v[4];
+            };
+            L4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.v[k] = static_cast<LT>(q.v[k]);
+            *reinterpret_cast<L4 *>(dst + lane * 4) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kSub / 64; ++k) {
+                const int j = k * 64 + lane;
+                dst[j] = j < count ? static_cast<LT>(row[j]) : LT(0);
+            }
+        }
+    }
+}
+
+enum : int { ST_IDLE = 0, ST_INIT = 1, ST_ITER = 2 };
+
+template <int EMAX, bool FULL, typename LT>
+__global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int E = FULL ? EMAX : A.E;
+    LT *tile = reinterpret_cast<LT *>(smem) + (size_t)wave * E * kSub;
+    const double epsmch = DBL_EPSILON;
+
+    // ---- per-lane LM state (fp64 registers) ----
+    int state = ST_IDLE;
+    long long vox = 0;
+    LT yv[EMAX];
+    double pa = 0, pb = 0;                    // current point x = (a, b)
+    double fnorm = 0, par = 0, delta = 0, xnorm = 0, gnorm = 0;
+    double dg0 = 1, dg1 = 1;                  // diag (by parameter)
+    double r11 = 0, r12 = 0, r22 = 0;         // R of the pivoted QR
+    double qtf0 = 0, qtf1 = 0;                // first two components of Q^T fvec
+    double sstot = 0;
+    int l0 = 0;                               // ipvt(0): 0 = columns in order, 1 = swapped
+    int nfev = 0;
+    bool first = true;                        // MINPACK iter == 1
+
+    // ---- wave-uniform queue over the current tile ----
+    long long tile_base = 0;
+    int qpos = 0, qend = 0;
+    bool more = true;
+
+    for (;;) {
+        // ======================= refill: idle lanes pull voxels =======================
+        {
+            unsigned long long idle = __ballot(state == ST_IDLE);
+            const int nidle = __popcll(idle);
+            if (nidle >= kRefillIdle || nidle == 64) {
+                while (idle) {
+                    if (qpos >= qend) {
+                        if (!more) break;
+                        unsigned int t = 0;
+                        if (lane == 0) t = atomicAdd(A.tile_counter, 1u);
+                        t = __builtin_amdgcn_readfirstlane(t);
+                        const long long start = (long long)t * kSub;
+                        if (start >= A.N) {
+                            more = false;
+                            break;
+                        }
+                        tile_base = start;
+                        const long long rem = A.N - start;
+                        qend = rem < kSub ? (int)rem : kSub;
+                        qpos = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        switch (A.y_dtype) {
+                            case QMRI_F32:
+                                stage_rows(static_cast<const float *>(A.y) + start, A.ld, E, qend,
+                                           tile, lane, A.vec_ok);
+                                break;
+                            case QMRI_F64:
+                                stage_rows(static_cast<const double *>(A.y) + start, A.ld, E, qend,
+                                           tile, lane, A.vec_ok);
+                                break;
+                            case QMRI_I16:
+                                stage_rows(static_cast<const short *>(A.y) + start, A.ld, E, qend,
+                                           tile, lane, A.vec_ok);
+                                break;
+                            default:
+                                stage_rows(static_cast<const unsigned short *>(A.y) + start, A.ld, E,
+                                           qend, tile, lane, A.vec_ok);
+                                break;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // rank of this lane among the idle lanes
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                    const int j = qpos + rank;
+                    if (state == ST_IDLE && j < qend) {
+                        const long long v = tile_base + j;
+                        bool selected = true;
+                        if (A.mask) selected = A.mask[v] != 0;
+                        if (!selected) {
+                            finish_voxel(A, v, 0, 0, 0, -1, 0, true);
+                        } else {
+                            bool allzero = true, finite = true;
+                            double mean = 0.0;
+#pragma unroll
+                            for (int i = 0; i < EMAX; ++i)
+                                if (FULL || i < E) {
+                                    const LT s = tile[i * kSub + j];
+                                    yv[i] = s;
+                                    allzero = allzero && (s == LT(0));
+                                    finite = finite && isfinite(static_cast<double>(s));
+                                    mean += static_cast<double>(s);
+                                }
+                            if (!finite) {
+                                // reference: ValueError for the whole call (scipy check_finite)
+                                *A.nonfinite = 1;
+                                finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                            } else if (allzero) {
+                                // skip rule, fitting.py:1065-1067
+                                finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                            } else {
+                                mean = mean / (double)E;
+                                double st = 0.0;
+#pragma unroll
+                                for (int i = 0; i < EMAX; ++i)
+                                    if (FULL || i < E) {
+                                        const double d = static_cast<double>(yv[i]) - mean;
+                                        st += d * d;
+                                    }
+                                sstot = st;
+                                vox = v;
+                                pa = A.a0;
+                                pb = A.b0;
+                                if (A.init == QMRI_INIT_PER_VOXEL) {
+                                    if (A.a0v) pa = A.a0v[v];
+                                    if (A.b0v) pb = A.b0v[v];
+                                } else if (A.init == QMRI_INIT_LOGLIN) {
+                                    // fitting.py:701-718: v + 1e-10*(v==0); log; degree-1 LS in x;
+                                    // r2 on the log data; r2 < 0 or NaN -> params 0 -> p0 = (1, 0)
+                                    double sl = 0.0;
+                                    double lg[EMAX];
+#pragma unroll
+                                    for (int i = 0; i < EMAX; ++i)
+                                        if (FULL || i < E) {
+                                            double s = static_cast<double>(yv[i]);
+                                            if (s == 0.0) s = 1e-10;
+                                            lg[i] = log(s);
+                                            sl += lg[i];
+                                        }
+                                    const double lmean = sl / (double)E;
+                                    double sxy = 0.0, syy = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < EMAX; ++i)
+                                        if (FULL || i < E) {
+                                            const double dy = lg[i] - lmean;
+                                            sxy += (A.x[i] - A.xmean) * dy;
+                                            syy += dy * dy;
+                                        }
+                                    const double slope = sxy / A.sxx;
+                                    const double icpt = lmean - slope * A.xmean;
+                                    double ssr = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < EMAX; ++i)
+                                        if (FULL || i < E) {
+                                            const double r = (slope * A.x[i] + icpt) - lg[i];
+                                            ssr += r * r;
+                                        }
+                                    const double r2l = 1.0 - ssr / (syy + 1e-8);
+                                    if (r2l >= 0.0 && !isnan(slope) && !isnan(icpt)) {
+                                        pa = exp(icpt);
+                                        pb = slope;
+                                    } else {
+                                        pa = 1.0;
+                                        pb = 0.0;
+                                    }
+                                }
+                                state = ST_INIT;
+                            }
+                        }
+                    }
+                    qpos = qpos + __popcll(idle);
+                    if (qpos > qend) qpos = qend;
+                    idle = __ballot(state == ST_IDLE);
+                }
+            }
+        }
+        if (!__ballot(state != ST_IDLE)) break;
+
+        // ======================= one LM step for every busy lane =======================
+        if (state != ST_IDLE) {
+            double ta, tb;           // trial point
+            double p0 = 0, p1 = 0;   // step (by parameter)
+            double pnorm = 0;
+            if (state == ST_ITER) {
+                lmpar2(r11, r12, r22, l0, dg0, dg1, qtf0, qtf1, delta, par, p0, p1);
+                p0 = -p0;
+                p1 = -p1;
+                ta = pa + p0;
+                tb = pb + p1;
+                pnorm = norm2(dg0 * p0, dg1 * p1);
+                if (first) delta = fmin(delta, pnorm);
+            } else {
+                ta = pa;
+                tb = pb;
+            }
+            // ---- evaluate the model at the trial point: E exps shared by fvec and the Jacobian ----
+            double ev[EMAX], fv[EMAX];
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < EMAX; ++i)
+                if (FULL || i < E) {
+                    ev[i] = exp(tb * A.x[i]);
+                    fv[i] = ta * ev[i] - static_cast<double>(yv[i]);
+                    ss += fv[i] * fv[i];
+                }
+            double fnorm1;
+            if (ss > 1e-280 && ss < 1e300) {
+                fnorm1 = sqrt(ss);
+            } else {
+                double m = 0.0;
+                bool anynan = false;
+#pragma unroll
+                for (int i = 0; i < EMAX; ++i)
+                    if (FULL || i < E) {
+                        m = fmax(m, fabs(fv[i]));
+                        anynan = anynan || isnan(fv[i]);
+                    }
+                if (anynan) {
+                    fnorm1 = NAN;
+                } else if (!(m > 0.0) || isinf(m)) {
+                    fnorm1 = m;
+                } else {
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            const double r = fv[i] / m;
+                            s2 += r * r;
+                        }
+                    fnorm1 = m * sqrt(s2);
+                }
+            }
+            ++nfev;
+
+            bool accepted;
+            int info = 0;
+            if (state == ST_ITER) {
+                double actred = -1.0;
+                if (0.1 * fnorm1 < fnorm) {
+                    const double t = fnorm1 / fnorm;
+                    actred = 1.0 - t * t;
+                }
+                // R * P^T p
+                const double pl0 = l0 ? p1 : p0, pl1 = l0 ? p0 : p1;
+                const double w0 = r11 * pl0 + r12 * pl1, w1 = r22 * pl1;
+                const double temp1 = norm2(w0, w1) / fnorm;
+                const double temp2 = (sqrt(par) * pnorm) / fnorm;
+                const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+                const double dirder = -(temp1 * temp1 + temp2 * temp2);
+                double ratio = 0.0;
+                if (prered != 0.0) ratio = actred / prered;
+                if (ratio <= 0.25) {
+                    double temp = 0.5;
+                    if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                    delta = temp * fmin(delta, pnorm / 0.1);
+                    par = par / temp;
+                } else if (par == 0.0 || ratio >= 0.75) {
+                    delta = pnorm / 0.5;
+                    par = 0.5 * par;
+                }
+                accepted = ratio >= 1e-4;
+                if (accepted) {
+                    pa = ta;
+                    pb = tb;
+                    xnorm = norm2(dg0 * pa, dg1 * pb);
+                    fnorm = fnorm1;
+                    first = false;
+                }
+                const bool small = fabs(actred) <= A.ftol && prered <= A.ftol && 0.5 * ratio <= 1.0;
+                if (small) info = 1;
+                if (delta <= A.xtol * xnorm) info = small ? 3 : 2;
+                if (info == 0) {
+                    if (nfev >= A.maxfev) info = 5;
+                    if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
+                    if (delta <= epsmch * xnorm) info = 7;
+                    if (gnorm <= epsmch) info = 8;
+                }
+            } else {
+                accepted = true;
+                fnorm = fnorm1;
+                par = 0.0;
+                first = true;
+            }
+
+            if (info == 0 && accepted) {
+                // ---- Jacobian at the (new) current point + Householder QR with column pivoting ----
+                // J = [ e_i , a x_i e_i ];  lmdif charges n = 2 evaluations for it
+                nfev += 2;
+                double c2[EMAX];
+                double n1 = 0.0, n2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < EMAX; ++i)
+                    if (FULL || i < E) {
+                        c2[i] = pa * A.x[i] * ev[i];
+                        n1 += ev[i] * ev[i];
+                        n2 += c2[i] * c2[i];
+                    }
+                // (E-vector norms: exps of finite args squared can only overflow to inf, never NaN)
+                const double acn0 = sqrt(n1), acn1 = sqrt(n2);
+                l0 = acn1 > acn0 ? 1 : 0;
+                // P = pivot column, Q = the other one (in place: ev <- P, c2 <- Q)
+                if (l0) {
+#pragma unroll
+                    for (int i = 0; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            const double t = ev[i];
+                            ev[i] = c2[i];
+                            c2[i] = t;
+                        }
+                }
+                double ajn = l0 ? acn1 : acn0;
+                if (ajn != 0.0) {
+                    if (ev[0] < 0.0) ajn = -ajn;
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            ev[i] = ev[i] / ajn;
+                            if (i == 0) ev[0] += 1.0;
+                            s1 += ev[i] * c2[i];
+                            s2 += ev[i] * fv[i];
+                        }
+                    const double t1 = s1 / ev[0];
+                    const double t2 = -s2 / ev[0];
+#pragma unroll
+                    for (int i = 0; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            c2[i] -= t1 * ev[i];
+                            fv[i] += t2 * ev[i];
+                        }
+                }
+                r11 = -ajn;
+                r12 = c2[0];
+                qtf0 = fv[0];
+                double m2 = 0.0;
+#pragma unroll
+                for (int i = 1; i < EMAX; ++i)
+                    if (FULL || i < E) m2 += c2[i] * c2[i];
+                double ajn2 = sqrt(m2);
+                if (ajn2 != 0.0) {
+                    if (c2[1] < 0.0) ajn2 = -ajn2;
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 1; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            c2[i] = c2[i] / ajn2;
+                            if (i == 1) c2[1] += 1.0;
+                            s += c2[i] * fv[i];
+                        }
+                    // only the 2nd component of Q^T fvec is needed after the 2nd reflection:
+                    // fv[1] += (-s / v[1]) * v[1]
+                    fv[1] -= s;
+                }
+                r22 = -ajn2;
+                qtf1 = fv[1];
+                if (state == ST_INIT) {
+                    dg0 = acn0 == 0.0 ? 1.0 : acn0;
+                    dg1 = acn1 == 0.0 ? 1.0 : acn1;
+                    xnorm = norm2(dg0 * pa, dg1 * pb);
+                    delta = A.factor * xnorm;
+                    if (delta == 0.0) delta = A.factor;
+                }
+                // scaled gradient norm
+                gnorm = 0.0;
+                if (fnorm != 0.0) {
+                    const double al0 = l0 ? acn1 : acn0, al1 = l0 ? acn0 : acn1;
+                    if (al0 != 0.0) gnorm = fabs((r11 * (qtf0 / fnorm)) / al0);
+                    if (al1 != 0.0)
+                        gnorm = fmax(gnorm,
+                                     fabs((r12 * (qtf0 / fnorm) + r22 * (qtf1 / fnorm)) / al1));
+                }
+                if (gnorm <= A.gtol) info = 4;
+                dg0 = fmax(dg0, acn0);
+                dg1 = fmax(dg1, acn1);
+                state = ST_ITER;
+            }
+
+            if (info != 0) {
+                // fitting.py:1032-1035 (success) / :1069-1072 (RuntimeError -> NaN, 0)
+                double oa = NAN, ob = NAN, r2 = 0.0;
+                if (info >= 1 && info <= 4) {
+                    oa = pa;
+                    ob = pb;
+                    r2 = 1.0 - (fnorm * fnorm) / (sstot + A.r2_eps);
+                }
+                finish_voxel(A, vox, oa, ob, r2, info, nfev, false);
+                state = ST_IDLE;
+                nfev = 0;
+            }
+        }
+    }
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------------------
+template <int EMAX, bool FULL, typename LT>
+static hipError_t launch_one(const FitKArgs &k, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)4 * k.E * kSub * sizeof(LT);
+    auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, stream, k);
+    return hipGetLastError();
+}
+
+template <int EMAX, bool FULL, typename LT>
+static int occupancy_one(int E) {
+    int nb = 0;
+    const size_t lds = (size_t)4 * E * kSub * sizeof(LT);
+    auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess) nb = 1;
+    return nb < 1 ? 1 : nb;
+}
+
+#define QMRI_DISPATCH(EM, FN, ...)                                                     \
+    (k.y_dtype == QMRI_F64                                                             \
+         ? (k.E == EM ? FN<EM, true, double>(__VA_ARGS__) : FN<EM, false, double>(__VA_ARGS__)) \
+         : (k.E == EM ? FN<EM, true, float>(__VA_ARGS__) : FN<EM, false, float>(__VA_ARGS__)))
+
+int monoexp_tile_voxels() { return kSub; }
+
+const char *monoexp_variant_name(int E, int y_dtype) {
+    const bool d = y_dtype == QMRI_F64;
+    if (E <= 4) return d ? (E == 4 ? "monoexp_lm<4,full,f64>" : "monoexp_lm<4,part,f64>")
+                         : (E == 4 ? "monoexp_lm<4,full,f32>" : "monoexp_lm<4,part,f32>");
+    if (E <= 8) return d ? (E == 8 ? "monoexp_lm<8,full,f64>" : "monoexp_lm<8,part,f64>")
+                         : (E == 8 ? "monoexp_lm<8,full,f32>" : "monoexp_lm<8,part,f32>");
+    if (E <= 16) return d ? (E == 16 ? "monoexp_lm<16,full,f64>" : "monoexp_lm<16,part,f64>")
+                          : (E == 16 ? "monoexp_lm<16,full,f32>" : "monoexp_lm<16,part,f32>");
+    return d ? (E == 32 ? "monoexp_lm<32,full,f64>" : "monoexp_lm<32,part,f64>")
+             : (E == 32 ? "monoexp_lm<32,full,f32>" : "monoexp_lm<32,part,f32>");
+}
+
+int monoexp_blocks_per_cu(const FitKArgs &k) {
+    if (k.E <= 4) return QMRI_DISPATCH(4, occupancy_one, k.E);
+    if (k.E <= 8) return QMRI_DISPATCH(8, occupancy_one, k.E);
+    if (k.E <= 16) return QMRI_DISPATCH(16, occupancy_one, k.E);
+    return QMRI_DISPATCH(32, occupancy_one, k.E);
+}
+
+hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream) {
+    if (k.E <= 4) return QMRI_DISPATCH(4, launch_one, k, grid, stream);
+    if (k.E <= 8) return QMRI_DISPATCH(8, launch_one, k, grid, stream);
+    if (k.E <= 16) return QMRI_DISPATCH(16, launch_one, k, grid, stream);
+    return QMRI_DISPATCH(32, launch_one, k, grid, stream);
+}
+
+}  // namespace qmri

@@ -1,0 +1,345 @@
+// qmri_capi.hip -- the C ABI declared in include/qmri.h (extern "C", plain pointers and sizes).
+//
+// Boundary it implements: the reference's Python seam  _Fitter._fit / curve_fit
+//   /root/reference/dosma/core/fitting.py:422-435, 755-870
+// i.e. "(E, N) echo-major samples + x + p0  ->  (N, 2) popt + (N,) r2", for func = monoexponential.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "qmri_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local int g_timing = 0;
+thread_local float g_last_ms = 0.f;
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+constexpr int kMaxDevices = 16;
+constexpr int kSlots = 64;  // concurrent calls per device before counters are reused
+
+struct DeviceCtx {
+    std::once_flag once;
+    hipError_t init_err = hipSuccess;
+    unsigned int *counters = nullptr;  // [kSlots][16] (64-byte spaced): tile counter + non-finite flag
+    int num_cu = 0;
+    std::atomic<unsigned> next{0};
+};
+DeviceCtx g_ctx[kMaxDevices];
+
+hipError_t ctx_get(int device, DeviceCtx **out) {
+    DeviceCtx &c = g_ctx[device];
+    std::call_once(c.once, [&] {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.counters), kSlots * 64);
+        if (e == hipSuccess) e = hipMemset(c.counters, 0, kSlots * 64);
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) c.num_cu = prop.multiProcessorCount;
+        c.init_err = e;
+    });
+    *out = &c;
+    return c.init_err;
+}
+
+size_t dtype_size(int dt) {
+    switch (dt) {
+        case QMRI_F32: return 4;
+        case QMRI_F64: return 8;
+        case QMRI_I16:
+        case QMRI_U16: return 2;
+        default: return 0;
+    }
+}
+
+int validate(const qmri_monoexp_args *a) {
+    if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
+    if (!a->y || !a->x || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, x, popt and r2 are required");
+    if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
+    if (a->out_dtype != QMRI_F32 && a->out_dtype != QMRI_F64)
+        return fail(QMRI_ERR_ARG, "out_dtype must be QMRI_F32 or QMRI_F64");
+    if (a->E < 2)
+        return fail(QMRI_ERR_ARG, "E=%d: need at least as many samples as parameters (2)", a->E);
+    if (a->E > QMRI_MAX_ECHOES)
+        return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds QMRI_MAX_ECHOES=%d", a->E, QMRI_MAX_ECHOES);
+    if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
+    if (a->init < QMRI_INIT_SCALAR || a->init > QMRI_INIT_LOGLIN)
+        return fail(QMRI_ERR_ARG, "unknown init mode %d", a->init);
+    if (a->maxfev <= 0 || a->ftol < 0 || a->xtol < 0 || a->gtol < 0 || a->factor <= 0)
+        return fail(QMRI_ERR_ARG, "bad solver constants (MINPACK 'improper input parameters')");
+    if (a->device < 0 || a->device >= kMaxDevices) return fail(QMRI_ERR_ARG, "bad device %d", a->device);
+    if (a->post.enable && a->post.decimals > 300) return fail(QMRI_ERR_ARG, "bad decimals");
+    for (int i = 0; i < a->E; ++i)
+        if (!std::isfinite(a->x[i]))
+            return fail(QMRI_ERR_NONFINITE, "x holds a non-finite value");
+    return QMRI_OK;
+}
+
+void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
+    std::memset(&k, 0, sizeof(k));
+    k.y = a->y;
+    k.ld = a->ld;
+    k.N = a->N;
+    k.E = a->E;
+    k.y_dtype = a->y_dtype;
+    const size_t es = dtype_size(a->y_dtype);
+    k.vec_ok = (reinterpret_cast<uintptr_t>(a->y) % (4 * es) == 0) && (a->ld % 4 == 0);
+    k.init = a->init;
+    k.mask = a->mask;
+    k.a0v = a->init == QMRI_INIT_PER_VOXEL ? a->a0v : nullptr;
+    k.b0v = a->init == QMRI_INIT_PER_VOXEL ? a->b0v : nullptr;
+    k.a0 = a->a0;
+    k.b0 = a->b0;
+    k.ftol = a->ftol;
+    k.xtol = a->xtol;
+    k.gtol = a->gtol;
+    k.factor = a->factor;
+    k.r2_eps = a->r2_eps;
+    k.maxfev = a->maxfev;
+    k.out_f64 = a->out_dtype == QMRI_F64;
+    k.post = a->post;
+    if (!k.post.enable || k.post.decimals < -300) k.post.decimals = QMRI_NO_ROUND;
+    k.p10 = k.post.decimals == QMRI_NO_ROUND ? 1.0 : std::pow(10.0, std::abs(k.post.decimals));
+    k.popt = a->popt;
+    k.r2 = a->r2;
+    k.tc = a->tc;
+    k.info = a->info;
+    k.nfev = a->nfev;
+    double xm = 0.0;
+    for (int i = 0; i < a->E; ++i) {
+        k.x[i] = a->x[i];
+        xm += a->x[i];
+    }
+    xm /= a->E;
+    double sxx = 0.0;
+    for (int i = 0; i < a->E; ++i) sxx += (a->x[i] - xm) * (a->x[i] - xm);
+    k.xmean = xm;
+    k.sxx = sxx;
+}
+
+// issue one fit launch on `stream`; flag_out (device) receives the non-finite flag if non-NULL
+int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    hipStream_t stream = static_cast<hipStream_t>(a->stream);
+    if (a->N == 0) return QMRI_OK;
+
+    qmri::FitKArgs k;
+    fill_kargs(a, k);
+    const unsigned slot = ctx->next.fetch_add(1) % kSlots;
+    unsigned int *cnt = ctx->counters + slot * 16;
+    k.tile_counter = cnt;
+    k.nonfinite = flag_out ? flag_out : reinterpret_cast<int *>(cnt + 1);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 8, stream));
+
+    const long long tiles = (a->N + qmri::monoexp_tile_voxels() - 1) / qmri::monoexp_tile_voxels();
+    const int per_cu = qmri::monoexp_blocks_per_cu(k);
+    long long grid = (long long)ctx->num_cu * per_cu;
+    const long long need = (tiles + 3) / 4;  // 4 waves per block, one tile per wave at a time
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_timing) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    HIP_TRY(qmri::monoexp_launch(k, static_cast<int>(grid), stream));
+    if (g_timing) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        HIP_TRY(hipEventElapsedTime(&g_last_ms, ev0, ev1));
+        hipEventDestroy(ev0);
+        hipEventDestroy(ev1);
+    }
+    return QMRI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qmri_version(void) { return QMRI_VERSION; }
+
+const char *qmri_last_error(void) { return g_err; }
+
+int qmri_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void qmri_set_timing(int enable) { g_timing = enable; }
+float qmri_last_kernel_ms(void) { return g_last_ms; }
+
+void qmri_monoexp_defaults(qmri_monoexp_args *a) {
+    if (!a) return;
+    // dosma/core/fitting.py:761-763 (maxfev, ftol, eps) + scipy.optimize.leastsq defaults
+    a->ftol = 1e-5;
+    a->xtol = 1.49012e-8;
+    a->gtol = 0.0;
+    a->factor = 100.0;
+    a->r2_eps = 1e-8;
+    a->maxfev = 100;
+    a->init = QMRI_INIT_SCALAR;
+    a->a0 = 1.0;  // scipy: p0 = ones(n) when p0 is None
+    a->b0 = 1.0;
+    std::memset(&a->post, 0, sizeof(a->post));
+    a->post.decimals = -1;
+    a->post.lb[0] = a->post.lb[1] = -INFINITY;
+    a->post.ub[0] = a->post.ub[1] = INFINITY;
+    a->out_dtype = QMRI_F64;
+}
+
+const char *qmri_monoexp_kernel_name(const qmri_monoexp_args *a) {
+    if (!a) return "";
+    return qmri::monoexp_variant_name(a->E, a->y_dtype);
+}
+
+int qmri_monoexp_fit_device(const qmri_monoexp_args *a, int32_t *nonfinite_flag) {
+    const int rc = validate(a);
+    if (rc != QMRI_OK) return rc;
+    return launch_fit(a, nonfinite_flag);
+}
+
+int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
+    const int rc = validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(a->device));
+
+    const size_t es = dtype_size(a->y_dtype);
+    const size_t os = a->out_dtype == QMRI_F64 ? 8 : 4;
+    // slab size: keep the device footprint modest and give the copy engines something to overlap
+    const long long kSlab = 1LL << 22;  // 4 Mi voxels
+    const long long S = a->N < kSlab ? ((a->N + 255) / 256) * 256 : kSlab;
+    const int nbuf = a->N > S ? 2 : 1;
+
+    struct Buf {
+        void *y = nullptr, *popt = nullptr, *r2 = nullptr, *tc = nullptr;
+        uint8_t *mask = nullptr;
+        double *a0v = nullptr, *b0v = nullptr;
+        int8_t *info = nullptr;
+        int16_t *nfev = nullptr;
+        hipStream_t stream = nullptr;
+    } buf[2];
+    int32_t *flag = nullptr;
+    int status = QMRI_OK;
+    auto cleanup = [&] {
+        for (int b = 0; b < 2; ++b) {
+            hipFree(buf[b].y);
+            hipFree(buf[b].popt);
+            hipFree(buf[b].r2);
+            hipFree(buf[b].tc);
+            hipFree(buf[b].mask);
+            hipFree(buf[b].a0v);
+            hipFree(buf[b].b0v);
+            hipFree(buf[b].info);
+            hipFree(buf[b].nfev);
+            if (buf[b].stream) hipStreamDestroy(buf[b].stream);
+        }
+        hipFree(flag);
+    };
+#define HIP_TRY_C(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            status = fail(QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                          __FILE__, __LINE__);                                                   \
+            cleanup();                                                                           \
+            return status;                                                                       \
+        }                                                                                        \
+    } while (0)
+
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&flag), 4));
+    HIP_TRY_C(hipMemset(flag, 0, 4));
+    const bool per_voxel = a->init == QMRI_INIT_PER_VOXEL;
+    for (int b = 0; b < nbuf; ++b) {
+        HIP_TRY_C(hipStreamCreateWithFlags(&buf[b].stream, hipStreamNonBlocking));
+        HIP_TRY_C(hipMalloc(&buf[b].y, (size_t)a->E * S * es));
+        HIP_TRY_C(hipMalloc(&buf[b].popt, (size_t)S * 2 * os));
+        HIP_TRY_C(hipMalloc(&buf[b].r2, (size_t)S * os));
+        if (a->tc) HIP_TRY_C(hipMalloc(&buf[b].tc, (size_t)S * os));
+        if (a->mask) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].mask), (size_t)S));
+        if (per_voxel && a->a0v) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].a0v), (size_t)S * 8));
+        if (per_voxel && a->b0v) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].b0v), (size_t)S * 8));
+        if (a->info) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].info), (size_t)S));
+        if (a->nfev) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].nfev), (size_t)S * 2));
+    }
+
+    int ib = 0;
+    for (long long s0 = 0; s0 < a->N; s0 += S, ib ^= 1) {
+        Buf &B = buf[nbuf == 1 ? 0 : ib];
+        const long long cnt = (a->N - s0) < S ? (a->N - s0) : S;
+        hipStream_t st = B.stream;
+        // the previous use of this buffer pair must have drained (its D2H copies are on `st`)
+        HIP_TRY_C(hipStreamSynchronize(st));
+        HIP_TRY_C(hipMemcpy2DAsync(B.y, (size_t)S * es,
+                                   static_cast<const char *>(a->y) + (size_t)s0 * es,
+                                   (size_t)a->ld * es, (size_t)cnt * es, (size_t)a->E,
+                                   hipMemcpyHostToDevice, st));
+        if (a->mask) HIP_TRY_C(hipMemcpyAsync(B.mask, a->mask + s0, (size_t)cnt, hipMemcpyHostToDevice, st));
+        if (B.a0v) HIP_TRY_C(hipMemcpyAsync(B.a0v, a->a0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+        if (B.b0v) HIP_TRY_C(hipMemcpyAsync(B.b0v, a->b0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+
+        qmri_monoexp_args d = *a;
+        d.y = B.y;
+        d.ld = S;
+        d.N = cnt;
+        d.mask = B.mask;
+        d.a0v = B.a0v;
+        d.b0v = B.b0v;
+        d.popt = B.popt;
+        d.r2 = B.r2;
+        d.tc = B.tc;
+        d.info = B.info;
+        d.nfev = B.nfev;
+        d.stream = st;
+        const int lrc = launch_fit(&d, flag);
+        if (lrc != QMRI_OK) {
+            cleanup();
+            return lrc;
+        }
+        HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->popt) + (size_t)s0 * 2 * os, B.popt,
+                                 (size_t)cnt * 2 * os, hipMemcpyDeviceToHost, st));
+        HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->r2) + (size_t)s0 * os, B.r2, (size_t)cnt * os,
+                                 hipMemcpyDeviceToHost, st));
+        if (a->tc)
+            HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->tc) + (size_t)s0 * os, B.tc,
+                                     (size_t)cnt * os, hipMemcpyDeviceToHost, st));
+        if (a->info) HIP_TRY_C(hipMemcpyAsync(a->info + s0, B.info, (size_t)cnt, hipMemcpyDeviceToHost, st));
+        if (a->nfev) HIP_TRY_C(hipMemcpyAsync(a->nfev + s0, B.nfev, (size_t)cnt * 2, hipMemcpyDeviceToHost, st));
+    }
+    for (int b = 0; b < nbuf; ++b) HIP_TRY_C(hipStreamSynchronize(buf[b].stream));
+    int32_t hflag = 0;
+    HIP_TRY_C(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
+    cleanup();
+    if (hflag) return fail(QMRI_ERR_NONFINITE, "array must not contain infs or NaNs");
+    return QMRI_OK;
+#undef HIP_TRY_C
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+/*
+ * qmri.h -- C ABI of the MI355X-native qMRI hot path (libqmri_hip.so, built from dosma_amd/csrc).
+ *
+ * The reference (ad12/DOSMA) is pure Python and has no FFI: the seam this library plugs into is
+ * the Python-level method  _Fitter._fit(x, y, **kw) -> (popt, r2)
+ *     /root/reference/dosma/core/fitting.py:148-155 (abstract), :422-435 (CurveFitter override)
+ * which forwards to the module function  curve_fit(func, x, y, ...)
+ *     /root/reference/dosma/core/fitting.py:755-870
+ * whose body is a per-voxel Python loop over scipy.optimize.curve_fit (:855-868 -> :1026-1073).
+ * Everything below replaces exactly that loop (+ the elementwise plumbing around it that
+ * MonoExponentialFit.fit adds, :701-737), for func == monoexponential (:1016-1018).
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned; no torch / numpy types cross this line;
+ *   - every entry returns 0 on success or a negative qmri_status; qmri_last_error() gives the
+ *     message for the calling thread;
+ *   - "device" pointers are HIP device pointers on args->device; "host" pointers are ordinary
+ *     process memory;  x (the E sample positions) is ALWAYS a host pointer (E <= QMRI_MAX_ECHOES);
+ *   - no global mutable state besides one lazily created context per device (a 64-byte tile
+ *     counter); calls on different streams / devices may run concurrently from different threads.
+ */
+#ifndef QMRI_H
+#define QMRI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMRI_VERSION 100 /* 0.1.0 */
+#define QMRI_MAX_ECHOES 32
+
+typedef enum qmri_status {
+    QMRI_OK = 0,
+    QMRI_ERR_ARG = -1,         /* bad argument (shape, dtype, NULL)        -> ValueError          */
+    QMRI_ERR_UNSUPPORTED = -2, /* valid request this build does not cover -> NotImplementedError */
+    QMRI_ERR_HIP = -3,         /* HIP runtime error / no device            -> RuntimeError        */
+    QMRI_ERR_NONFINITE = -4    /* y holds NaN/Inf: the reference raises ValueError for the whole
+                                  call (scipy check_finite, via fitting.py:1030)                   */
+} qmri_status;
+
+/* element type of y (what a MedicalVolume of DICOM / NIfTI data holds) */
+typedef enum qmri_dtype {
+    QMRI_F32 = 0,
+    QMRI_F64 = 1,
+    QMRI_I16 = 2,
+    QMRI_U16 = 3
+} qmri_dtype;
+
+/* initial guess p0 = (a0, b0) of  y = a * exp(b * x) */
+typedef enum qmri_init {
+    QMRI_INIT_SCALAR = 0,    /* (a0, b0) for every voxel: MonoExponentialFit(tc0=float) -> (1, -1/tc0)
+                                fitting.py:720; curve_fit(p0=tuple) fitting.py:822-825            */
+    QMRI_INIT_PER_VOXEL = 1, /* a0v[N] and/or b0v[N] (NULL -> scalar): curve_fit(p0=arrays),
+                                fitting.py:849-851, 1039-1053                                      */
+    QMRI_INIT_LOGLIN = 2     /* log-linear least squares computed on-chip:
+                                MonoExponentialFit(tc0="polyfit"), fitting.py:701-718             */
+} qmri_init;
+
+/*
+ * Post-processing of the (N,2) parameter array, _Fitter._process_params (fitting.py:109-146), in the
+ * reference's order:  ufunc (b -> 1/|b|, fitting.py:725)  ->  bounds (value < lb or > ub -> NaN)
+ * ->  r2 < threshold -> whole row NaN  ->  nan_to_num (NaN -> value, +-inf -> +-DBL_MAX), then the
+ * scatter fill for voxels outside the mask (fitting.py:205-215) and np.around of the tc map (:736-737).
+ */
+typedef struct qmri_post {
+    int32_t enable;         /* 0: popt/r2 are curve_fit()'s raw outputs                              */
+    int32_t inv_abs_b;      /* 1: param 1 <- 1/|b|                                                   */
+    int32_t use_bounds;     /* 1: apply lb/ub below                                                  */
+    int32_t use_r2_thr;     /* 1: rows with r2 < r2_threshold -> NaN                                 */
+    int32_t use_nan_to_num; /* 1: np.nan_to_num(x, nan=nan_value); also the fill outside the mask    */
+    int32_t decimals;       /* >= 0: tc = around(param 1, decimals) written to args->tc; < 0: none   */
+    double lb[2], ub[2];    /* per-parameter bounds (use -inf/+inf for "none")                       */
+    double r2_threshold;
+    double nan_value;
+} qmri_post;
+
+typedef struct qmri_monoexp_args {
+    /* ---- inputs ---- */
+    const void *y;       /* [E][ld] echo-major samples (the (E, N) C-contiguous array of fitting.py:194-196) */
+    int32_t y_dtype;     /* qmri_dtype                                                                */
+    int32_t E;           /* samples per voxel, 2 <= E <= QMRI_MAX_ECHOES                              */
+    int64_t N;           /* voxels                                                                    */
+    int64_t ld;          /* elements between consecutive echoes (>= N)                                */
+    const double *x;     /* HOST [E] sample positions (echo / spin-lock times)                        */
+    const uint8_t *mask; /* nullable [N]: fit only voxels with mask != 0 (fitting.py:107, 199-200)    */
+    int32_t init;        /* qmri_init                                                                 */
+    int32_t reserved0;
+    double a0, b0;       /* scalar initial guess                                                      */
+    const double *a0v;   /* nullable [N] (indexed by voxel, not by position in the mask)              */
+    const double *b0v;   /* nullable [N]                                                              */
+    /* ---- solver constants (fitting.py:761-763 + scipy.optimize.leastsq defaults) ---- */
+    double ftol;         /* 1e-5  (DOSMA)                                                             */
+    double xtol;         /* 1.49012e-8 (scipy)                                                        */
+    double gtol;         /* 0.0   (scipy)                                                             */
+    double factor;       /* 100.0 (scipy)                                                             */
+    double r2_eps;       /* 1e-8  (DOSMA, fitting.py:752)                                             */
+    int32_t maxfev;      /* 100   (DOSMA)                                                             */
+    int32_t reserved1;
+    qmri_post post;
+    /* ---- outputs ---- */
+    void *popt;          /* [N][2] (a, b)  -- or (a, tc) after post.inv_abs_b                         */
+    void *r2;            /* [N]                                                                       */
+    void *tc;            /* nullable [N]: rounded time-constant map (post.decimals >= 0)              */
+    int32_t out_dtype;   /* QMRI_F32 or QMRI_F64 (the reference returns float64)                      */
+    int32_t reserved2;
+    int8_t *info;        /* nullable [N]: MINPACK info (1..4 success, 5..8 failure), 0 = skipped
+                            (all-zero voxel, fitting.py:1065-1067), -1 = outside mask                 */
+    int16_t *nfev;       /* nullable [N]: function evaluations as lmdif counts them                   */
+    /* ---- placement ---- */
+    int32_t device;      /* HIP device ordinal                                                        */
+    int32_t reserved3;
+    void *stream;        /* hipStream_t (NULL = default stream); the call is asynchronous on it       */
+} qmri_monoexp_args;
+
+/* Fill the solver constants and post block with the reference's defaults. */
+void qmri_monoexp_defaults(qmri_monoexp_args *args);
+
+/*
+ * Per-voxel mono-exponential Levenberg-Marquardt fit on the GPU; all data pointers are DEVICE
+ * pointers (except x).  Asynchronous on args->stream.  Replaces the loop at fitting.py:855-868.
+ * If `nonfinite_flag` (device int32, nullable) is given it is set to 1 when a fitted voxel holds a
+ * non-finite sample; the caller maps that to the reference's ValueError.
+ */
+int qmri_monoexp_fit_device(const qmri_monoexp_args *args, int32_t *nonfinite_flag);
+
+/*
+ * Same, but y / mask / a0v / b0v / popt / r2 / tc / info / nfev are HOST pointers: the library
+ * stages them through device memory in slabs (H2D, fit, D2H overlapped on two streams) and returns
+ * when the outputs are complete.  Returns QMRI_ERR_NONFINITE like the reference's ValueError.
+ * This is what the Python drop-in (dosma_amd.fitting) calls for CPU MedicalVolumes.
+ */
+int qmri_monoexp_fit_host(const qmri_monoexp_args *args);
+
+/* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
+ * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */
+void qmri_set_timing(int enable);
+float qmri_last_kernel_ms(void);
+
+int qmri_version(void);
+int qmri_device_count(void);
+const char *qmri_last_error(void);
+/* name of the fit kernel variant that `args` would dispatch to (for profiles / tests) */
+const char *qmri_monoexp_kernel_name(const qmri_monoexp_args *args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMRI_H */

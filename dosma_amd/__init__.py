@@ -1,0 +1,20 @@
+"""dosma_amd -- MI355X-native hot path of DOSMA (per-voxel mono-exponential fitting, 2D-UNet seg).
+
+Drop-in names of the reference's public API for this path (``dosma/__init__.py:12-31``):
+``MedicalVolume``, ``CurveFitter``, ``PolyFitter``, ``MonoExponentialFit``, ``curve_fit``, ``polyfit``,
+``monoexponential``, ``biexponential``.  Everything per-voxel runs in ``libqmri_hip.so`` (see
+``include/qmri.h``); there is no CPU fallback.
+"""
+from dosma_amd.defaults import preferences  # noqa: F401
+from dosma_amd.fitting import (  # noqa: F401
+    CurveFitter,
+    MonoExponentialFit,
+    PolyFitter,
+    biexponential,
+    curve_fit,
+    monoexponential,
+    polyfit,
+)
+from dosma_amd.med_volume import MedicalVolume  # noqa: F401
+
+__version__ = "0.1.0"

@@ -41,7 +41,8 @@ class QmriMonoexpArgs(ctypes.Structure):
         ("y", ctypes.c_void_p), ("y_dtype", ctypes.c_int32), ("E", ctypes.c_int32),
         ("N", ctypes.c_int64), ("ld", ctypes.c_int64),
         ("x", ctypes.POINTER(ctypes.c_double)), ("mask", ctypes.c_void_p),
-        ("init", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("init", ctypes.c_int32), ("use_y_bounds", ctypes.c_int32),
+        ("y_lo", ctypes.c_double), ("y_hi", ctypes.c_double),
         ("a0", ctypes.c_double), ("b0", ctypes.c_double),
         ("a0v", ctypes.c_void_p), ("b0v", ctypes.c_void_p),
         ("ftol", ctypes.c_double), ("xtol", ctypes.c_double), ("gtol", ctypes.c_double),
@@ -56,10 +57,24 @@ class QmriMonoexpArgs(ctypes.Structure):
     ]
 
 
+class QmriLinfitArgs(ctypes.Structure):
+    _fields_ = [
+        ("y", ctypes.c_void_p), ("y_dtype", ctypes.c_int32), ("E", ctypes.c_int32),
+        ("N", ctypes.c_int64), ("ld", ctypes.c_int64),
+        ("x", ctypes.POINTER(ctypes.c_double)),
+        ("log_transform", ctypes.c_int32), ("skip_rules", ctypes.c_int32),
+        ("use_y_bounds", ctypes.c_int32), ("out_dtype", ctypes.c_int32),
+        ("y_lo", ctypes.c_double), ("y_hi", ctypes.c_double), ("r2_eps", ctypes.c_double),
+        ("popt", ctypes.c_void_p), ("r2", ctypes.c_void_p),
+        ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
-    "qmri_monoexp_kernel_name",
+    "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
 )
 
 _lib = None
@@ -127,6 +142,10 @@ def load():
         lib.qmri_set_timing.argtypes = [ctypes.c_int]
         lib.qmri_set_timing.restype = None
         lib.qmri_last_kernel_ms.restype = ctypes.c_float
+        for name in ("qmri_linfit_device", "qmri_linfit_host"):
+            fn = getattr(lib, name)
+            fn.argtypes = [ctypes.POINTER(QmriLinfitArgs)]
+            fn.restype = ctypes.c_int
         _lib = lib
         return lib
 
@@ -187,7 +206,7 @@ def set_post(a: QmriMonoexpArgs, inv_abs_b=False, bounds=None, r2_threshold=None
 
 def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=None, b0v=None,
                      post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=0,
-                     ftol=None, maxfev=None, r2_eps=None):
+                     ftol=None, maxfev=None, r2_eps=None, y_bounds=None):
     """Run the HIP fit on host (numpy) buffers.  ``y``: (E, N) C-contiguous, echo-major.
 
     Returns dict(popt (N,2), r2 (N,), [tc (N,)], [info (N,) int8, nfev (N,) int16]).
@@ -230,6 +249,9 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
         a.maxfev = int(maxfev)
     if r2_eps is not None:
         a.r2_eps = float(r2_eps)
+    if y_bounds is not None:
+        a.use_y_bounds = 1
+        a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
     if post is not None:
         set_post(a, **post)
     od = np.dtype(out_dtype)
@@ -246,4 +268,33 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
     a.device = int(device)
     check(lib.qmri_monoexp_fit_host(ctypes.byref(a)))
     del keep
+    return out
+
+
+def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds=None, r2_eps=1e-8,
+                out_dtype=np.float64, device=0):
+    """Degree-1 least squares per column of ``y`` (E, N) on the GPU -> dict(popt (N,2), r2 (N,))."""
+    lib = load()
+    require_device()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y)
+    E, N = y.shape
+    if x.shape != (E,):
+        raise ValueError(f"x has shape {x.shape}, expected ({E},)")
+    a = QmriLinfitArgs()
+    a.y, a.y_dtype, a.E, a.N, a.ld = _ptr(y), qdtype(y.dtype), E, N, N
+    a.x = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    a.log_transform = 1 if log_transform else 0
+    a.skip_rules = 1 if per_sequence_rules else 0
+    a.y_lo, a.y_hi = -np.inf, np.inf
+    if y_bounds is not None:
+        a.use_y_bounds = 1
+        a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
+    a.r2_eps = float(r2_eps)
+    od = np.dtype(out_dtype)
+    a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
+    out = {"popt": np.empty((N, 2), dtype=od), "r2": np.empty(N, dtype=od)}
+    a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
+    a.device = int(device)
+    check(lib.qmri_linfit_host(ctypes.byref(a)))
     return out

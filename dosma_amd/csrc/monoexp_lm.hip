@@ -12,8 +12,8 @@
 //     fp64 because the parity target is an EARLY-STOPPED solver: the stop tests compare
 //     1 - (|f+|/|f|)^2 against 1e-5, which fp32 cannot resolve;
 //   * MINPACK's control flow is kept exactly (lmpar trust region, ratio tests, info codes, nfev
-//     accounting with +n per Jacobian) but the Jacobian is analytic and shares the E exponentials
-//     of the trial point, so one LM iteration costs E exps;
+//     accounting with +n per Jacobian); the forward-difference Jacobian is reproduced from the E
+//     exponentials of the accepted trial point (no extra exps), so one LM iteration costs E exps;
 //   * waves are independent persistent workers: a wave claims a tile of SUB consecutive voxels
 //     with one atomic, stages it echo-major into its private LDS slice with coalesced
 //     16-byte-per-lane loads, and its lanes *pull* voxels from that tile whenever they finish one
@@ -34,6 +34,18 @@ namespace qmri {
 
 constexpr int kSub = 256;        // voxels per tile (per wave): 4 per lane -> 16-byte loads for f32
 constexpr int kRefillIdle = 16;  // refill the wave when at least this many lanes are idle
+
+// Separately rounded product / difference (no FMA contraction): numpy evaluates the model as
+// a * exp(b * x) - y with one rounding per operation, and lmdif's forward-difference Jacobian is
+// sensitive to exactly that rounding (it can cancel to 0), so the model evaluation keeps it.
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double sub_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 __device__ __forceinline__ double norm2(double a, double b) {
     const double s = a * a + b * b;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                         if (!selected) {
                             finish_voxel(A, v, 0, 0, 0, -1, 0, true);
                         } else {
-                            bool allzero = true, finite = true;
+                            bool allzero = true, finite = true, oob = false;
                             double mean = 0.0;
 #pragma unroll
                             for (int i = 0; i < EMAX; ++i)
@@ -358,14 +370,17 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                                     yv[i] = s;
                                     allzero = allzero && (s == LT(0));
                                     finite = finite && isfinite(static_cast<double>(s));
+                                    if (A.use_y_bounds)
+                                        oob = oob || static_cast<double>(s) < A.y_lo ||
+                                              static_cast<double>(s) > A.y_hi;
                                     mean += static_cast<double>(s);
                                 }
                             if (!finite) {
                                 // reference: ValueError for the whole call (scipy check_finite)
                                 *A.nonfinite = 1;
                                 finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
-                            } else if (allzero) {
-                                // skip rule, fitting.py:1065-1067
+                            } else if (allzero || oob) {
+                                // skip rule, fitting.py:1064-1067
                                 finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
                             } else {
                                 mean = mean / (double)E;
@@ -458,8 +473,8 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
 #pragma unroll
             for (int i = 0; i < EMAX; ++i)
                 if (FULL || i < E) {
-                    ev[i] = exp(tb * A.x[i]);
-                    fv[i] = ta * ev[i] - static_cast<double>(yv[i]);
+                    ev[i] = exp(mul_rn(tb, A.x[i]));
+                    fv[i] = sub_rn(mul_rn(ta, ev[i]), static_cast<double>(yv[i]));
                     ss += fv[i] * fv[i];
                 }
             double fnorm1;
@@ -518,6 +533,10 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                     delta = pnorm / 0.5;
                     par = 0.5 * par;
                 }
+#ifdef QMRI_TRACE
+                printf("it nfev=%d trial=(%.17g,%.17g) p=(%.6g,%.6g) par=%.6g delta=%.6g fnorm=%.17g fnorm1=%.17g actred=%.6g prered=%.6g ratio=%.6g\n",
+                       nfev, ta, tb, p0, p1, par, delta, fnorm, fnorm1, actred, prered, ratio);
+#endif
                 accepted = ratio >= 1e-4;
                 if (accepted) {
                     pa = ta;
@@ -544,17 +563,35 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
 
             if (info == 0 && accepted) {
                 // ---- Jacobian at the (new) current point + Householder QR with column pivoting ----
-                // J = [ e_i , a x_i e_i ];  lmdif charges n = 2 evaluations for it
+                // lmdif's forward differences (fdjac2: h_j = sqrt(eps)*|x_j|, J_j = (f(x+h_j e_j)-f)/h_j),
+                // charged n = 2 evaluations, but evaluated WITHOUT new exponentials: the a-column reuses
+                // e_i exactly; the b-column uses e_i * exp(d_i), d_i = (b+h)x_i - b x_i ~ 1e-8 |b x_i|,
+                // exp(d) = 1 + d + d^2/2 + d^3/6 (error < 1e-30).  This keeps the truncation bias and
+                // the cancellation-to-zero behaviour of the reference's Jacobian (an analytic J does
+                // not: it keeps iterating where lmdif sees a zero gradient and stops with info = 4).
                 nfev += 2;
                 double c2[EMAX];
                 double n1 = 0.0, n2 = 0.0;
+                {
+                    const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+                    double ha = eps * fabs(pa), hb = eps * fabs(pb);
+                    if (ha == 0.0) ha = eps;
+                    if (hb == 0.0) hb = eps;
+                    const double a1 = pa + ha, b1 = pb + hb;
+                    const double rha = 1.0 / ha, rhb = 1.0 / hb;
 #pragma unroll
-                for (int i = 0; i < EMAX; ++i)
-                    if (FULL || i < E) {
-                        c2[i] = pa * A.x[i] * ev[i];
-                        n1 += ev[i] * ev[i];
-                        n2 += c2[i] * c2[i];
-                    }
+                    for (int i = 0; i < EMAX; ++i)
+                        if (FULL || i < E) {
+                            const double yi = static_cast<double>(yv[i]);
+                            const double e = ev[i];
+                            const double d = sub_rn(mul_rn(b1, A.x[i]), mul_rn(pb, A.x[i]));
+                            const double e1 = e + e * (d + d * d * (0.5 + d * (1.0 / 6.0)));
+                            c2[i] = sub_rn(sub_rn(mul_rn(pa, e1), yi), fv[i]) * rhb;
+                            ev[i] = sub_rn(sub_rn(mul_rn(a1, e), yi), fv[i]) * rha;
+                            n1 += ev[i] * ev[i];
+                            n2 += c2[i] * c2[i];
+                        }
+                }
                 // (E-vector norms: exps of finite args squared can only overflow to inf, never NaN)
                 const double acn0 = sqrt(n1), acn1 = sqrt(n2);
                 l0 = acn1 > acn0 ? 1 : 0;
@@ -629,6 +666,10 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                         gnorm = fmax(gnorm,
                                      fabs((r12 * (qtf0 / fnorm) + r22 * (qtf1 / fnorm)) / al1));
                 }
+#ifdef QMRI_TRACE
+                printf("qr x=(%.17g,%.17g) acn=(%.17g,%.17g) l0=%d R=(%.17g,%.17g,%.17g) qtf=(%.17g,%.17g) gnorm=%.6g\n",
+                       pa, pb, acn0, acn1, l0, r11, r12, r22, qtf0, qtf1, gnorm);
+#endif
                 if (gnorm <= A.gtol) info = 4;
                 dg0 = fmax(dg0, acn0);
                 dg1 = fmax(dg1, acn1);
@@ -652,29 +693,50 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------------
+// waves per block: each wave owns E * kSub * sizeof(LT) bytes of LDS; keep two blocks per CU when the
+// tile is small enough (<= 80 KB per block), otherwise one block of up to 160 KB.
+template <typename LT>
+static int waves_per_block(int E) {
+    const size_t tile = (size_t)E * kSub * sizeof(LT);
+    int w = (int)((80 * 1024) / tile);
+    if (w < 1) w = (int)((160 * 1024) / tile);
+    if (w > 4) w = 4;
+    return w;  // 0 -> does not fit (cannot happen for E <= QMRI_MAX_ECHOES)
+}
+
 template <int EMAX, bool FULL, typename LT>
 static hipError_t launch_one(const FitKArgs &k, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)4 * k.E * kSub * sizeof(LT);
+    const int wpb = waves_per_block<LT>(k.E);
+    if (wpb < 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)wpb * k.E * kSub * sizeof(LT);
     auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
+    (void)hipGetLastError();  // do not inherit a stale error from an unrelated earlier call
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, stream, k);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wpb), lds, stream, k);
     return hipGetLastError();
 }
 
 template <int EMAX, bool FULL, typename LT>
 static int occupancy_one(int E) {
     int nb = 0;
-    const size_t lds = (size_t)4 * E * kSub * sizeof(LT);
+    const int wpb = waves_per_block<LT>(E);
+    const size_t lds = (size_t)wpb * E * kSub * sizeof(LT);
     auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * wpb, lds) != hipSuccess) nb = 1;
+    (void)hipGetLastError();
     return nb < 1 ? 1 : nb;
+}
+
+template <int EMAX, bool FULL, typename LT>
+static int wpb_one(int E) {
+    return waves_per_block<LT>(E);
 }
 
 #define QMRI_DISPATCH(EM, FN, ...)                                                     \
@@ -694,6 +756,13 @@ const char *monoexp_variant_name(int E, int y_dtype) {
                           : (E == 16 ? "monoexp_lm<16,full,f32>" : "monoexp_lm<16,part,f32>");
     return d ? (E == 32 ? "monoexp_lm<32,full,f64>" : "monoexp_lm<32,part,f64>")
              : (E == 32 ? "monoexp_lm<32,full,f32>" : "monoexp_lm<32,part,f32>");
+}
+
+int monoexp_waves_per_block(const FitKArgs &k) {
+    if (k.E <= 4) return QMRI_DISPATCH(4, wpb_one, k.E);
+    if (k.E <= 8) return QMRI_DISPATCH(8, wpb_one, k.E);
+    if (k.E <= 16) return QMRI_DISPATCH(16, wpb_one, k.E);
+    return QMRI_DISPATCH(32, wpb_one, k.E);
 }
 
 int monoexp_blocks_per_cu(const FitKArgs &k) {

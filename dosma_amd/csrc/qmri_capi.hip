@@ -106,6 +106,9 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     const size_t es = dtype_size(a->y_dtype);
     k.vec_ok = (reinterpret_cast<uintptr_t>(a->y) % (4 * es) == 0) && (a->ld % 4 == 0);
     k.init = a->init;
+    k.use_y_bounds = a->use_y_bounds;
+    k.y_lo = a->y_lo;
+    k.y_hi = a->y_hi;
     k.mask = a->mask;
     k.a0v = a->init == QMRI_INIT_PER_VOXEL ? a->a0v : nullptr;
     k.b0v = a->init == QMRI_INIT_PER_VOXEL ? a->b0v : nullptr;
@@ -157,7 +160,8 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
     const long long tiles = (a->N + qmri::monoexp_tile_voxels() - 1) / qmri::monoexp_tile_voxels();
     const int per_cu = qmri::monoexp_blocks_per_cu(k);
     long long grid = (long long)ctx->num_cu * per_cu;
-    const long long need = (tiles + 3) / 4;  // 4 waves per block, one tile per wave at a time
+    const int wpb = qmri::monoexp_waves_per_block(k);
+    const long long need = (tiles + wpb - 1) / wpb;  // one tile per wave at a time
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
 
@@ -205,6 +209,9 @@ void qmri_monoexp_defaults(qmri_monoexp_args *a) {
     a->r2_eps = 1e-8;
     a->maxfev = 100;
     a->init = QMRI_INIT_SCALAR;
+    a->use_y_bounds = 0;
+    a->y_lo = -INFINITY;
+    a->y_hi = INFINITY;
     a->a0 = 1.0;  // scipy: p0 = ones(n) when p0 is None
     a->b0 = 1.0;
     std::memset(&a->post, 0, sizeof(a->post));
@@ -340,6 +347,93 @@ int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
     if (hflag) return fail(QMRI_ERR_NONFINITE, "array must not contain infs or NaNs");
     return QMRI_OK;
 #undef HIP_TRY_C
+}
+
+
+static int linfit_validate(const qmri_linfit_args *a) {
+    if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
+    if (!a->y || !a->x || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, x, popt and r2 are required");
+    if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
+    if (a->out_dtype != QMRI_F32 && a->out_dtype != QMRI_F64)
+        return fail(QMRI_ERR_ARG, "out_dtype must be QMRI_F32 or QMRI_F64");
+    if (a->E < 2) return fail(QMRI_ERR_ARG, "E=%d: a line needs at least 2 samples", a->E);
+    if (a->E > QMRI_MAX_ECHOES)
+        return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds QMRI_MAX_ECHOES=%d", a->E, QMRI_MAX_ECHOES);
+    if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
+    if (a->device < 0 || a->device >= kMaxDevices) return fail(QMRI_ERR_ARG, "bad device %d", a->device);
+    return QMRI_OK;
+}
+
+int qmri_linfit_device(const qmri_linfit_args *a) {
+    const int rc = linfit_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    qmri::LinfitKArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.y = a->y;
+    k.ld = a->ld;
+    k.N = a->N;
+    k.E = a->E;
+    k.y_dtype = a->y_dtype;
+    k.log_transform = a->log_transform;
+    k.skip_rules = a->skip_rules;
+    k.use_y_bounds = a->use_y_bounds;
+    k.out_f64 = a->out_dtype == QMRI_F64;
+    k.y_lo = a->y_lo;
+    k.y_hi = a->y_hi;
+    k.r2_eps = a->r2_eps;
+    k.popt = a->popt;
+    k.r2 = a->r2;
+    double xm = 0.0;
+    for (int i = 0; i < a->E; ++i) {
+        k.x[i] = a->x[i];
+        xm += a->x[i];
+    }
+    xm /= a->E;
+    double sxx = 0.0;
+    for (int i = 0; i < a->E; ++i) sxx += (a->x[i] - xm) * (a->x[i] - xm);
+    k.xmean = xm;
+    k.sxx = sxx;
+    HIP_TRY(qmri::linfit_launch(k, ctx->num_cu, static_cast<hipStream_t>(a->stream)));
+    return QMRI_OK;
+}
+
+int qmri_linfit_host(const qmri_linfit_args *a) {
+    const int rc = linfit_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const size_t es = dtype_size(a->y_dtype);
+    const size_t os = a->out_dtype == QMRI_F64 ? 8 : 4;
+    void *dy = nullptr, *dp = nullptr, *dr = nullptr;
+    int status = QMRI_OK;
+    hipError_t e = hipMalloc(&dy, (size_t)a->E * a->N * es);
+    if (e == hipSuccess) e = hipMalloc(&dp, (size_t)a->N * 2 * os);
+    if (e == hipSuccess) e = hipMalloc(&dr, (size_t)a->N * os);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(dy, (size_t)a->N * es, a->y, (size_t)a->ld * es, (size_t)a->N * es, (size_t)a->E,
+                        hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        qmri_linfit_args d = *a;
+        d.y = dy;
+        d.ld = a->N;
+        d.popt = dp;
+        d.r2 = dr;
+        d.stream = nullptr;
+        status = qmri_linfit_device(&d);
+        if (status == QMRI_OK) {
+            e = hipMemcpy(a->popt, dp, (size_t)a->N * 2 * os, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(a->r2, dr, (size_t)a->N * os, hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(dy);
+    hipFree(dp);
+    hipFree(dr);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "linfit_host: %s", hipGetErrorString(e));
+    return status;
 }
 
 }  // extern "C"

@@ -19,6 +19,9 @@ struct FitKArgs {
     int y_dtype;
     int vec_ok;  // rows are 4-element aligned: 16-byte-per-lane staging loads are legal
     int init;
+    int use_y_bounds;
+    int pad0;
+    double y_lo, y_hi;
     const unsigned char *mask;
     const double *a0v;
     const double *b0v;
@@ -39,9 +42,30 @@ struct FitKArgs {
     double x[QMRI_MAX_ECHOES];
 };
 
+// Kernel-argument block of the degree-1 least-squares kernel (linfit.hip).
+struct LinfitKArgs {
+    const void *y;
+    long long ld;
+    long long N;
+    int E;
+    int y_dtype;
+    int log_transform;
+    int skip_rules;
+    int use_y_bounds;
+    int out_f64;
+    double y_lo, y_hi;
+    double r2_eps;
+    void *popt;
+    void *r2;
+    double xmean, sxx;
+    double x[QMRI_MAX_ECHOES];
+};
+hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
+
 int monoexp_tile_voxels();
 const char *monoexp_variant_name(int E, int y_dtype);
 int monoexp_blocks_per_cu(const FitKArgs &k);
+int monoexp_waves_per_block(const FitKArgs &k);
 hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream);
 
 }  // namespace qmri

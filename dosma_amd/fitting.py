@@ -1,0 +1,630 @@
+"""Drop-in fitting interface of DOSMA on the MI355X kernels.
+
+Mirrors the public surface of the reference's ``dosma/core/fitting.py`` for the hot path named in
+BASELINE.json -- same names, arguments and error behaviour:
+
+* :func:`curve_fit`               (reference :755-870)   <- the seam: the per-voxel loop becomes ONE HIP launch
+* :class:`CurveFitter`            (reference :238-458)
+* :class:`MonoExponentialFit`     (reference :607-749)   <- init, fit and post-processing fused in the kernel
+* :func:`polyfit`, :class:`PolyFitter` (reference :461-604, 873-1013) for degree 1 (the log-linear fit)
+* :func:`monoexponential`, :func:`biexponential` (reference :1016-1023)
+
+What runs where: everything per-voxel runs in ``libqmri_hip.so`` (include/qmri.h).  Python only does
+what the reference's Python does *around* the loop: argument checking, reorientation, flattening to
+the (E, N) echo-major array, p0 formatting, wrapping results in MedicalVolumes.  There is no CPU
+solver in this package: an unsupported request raises ``NotImplementedError``; a missing library
+or GPU raises ``dosma_amd._lib.QmriError``.
+
+Like the reference (:403-406, 745-746, 809-810) inputs must live on the CPU; the library stages
+them to the GPU itself.
+"""
+import inspect
+import warnings
+from copy import deepcopy
+from numbers import Number
+from typing import Callable, Mapping, Sequence
+
+import numpy as np
+
+from dosma_amd import _lib
+from dosma_amd import defaults
+from dosma_amd.defaults import preferences
+from dosma_amd.med_volume import MedicalVolume
+
+__all__ = [
+    "CurveFitter",
+    "PolyFitter",
+    "MonoExponentialFit",
+    "curve_fit",
+    "polyfit",
+    "monoexponential",
+    "biexponential",
+]
+
+__EPSILON__ = 1e-8
+
+
+def monoexponential(x, a, b):
+    """Function: :math:`f(x) = a * e^{b*x}` (reference :1016-1018)."""
+    return a * np.exp(b * x)
+
+
+def biexponential(x, a1, b1, a2, b2):
+    """Function: :math:`f(x) = a1*e^{b1*x} + a2*e^{b2*x}` (reference :1021-1023)."""
+    return a1 * np.exp(b1 * x) + a2 * np.exp(b2 * x)
+
+
+def _inv_abs(v):
+    """``1 / |v|`` -- the time-constant transform of MonoExponentialFit (reference :725)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return 1 / np.abs(v)
+
+
+_inv_abs.__qmri_ufunc__ = "inv_abs"
+
+
+def _model_of(func) -> str:
+    """Which built-in kernel model ``func`` is.  Raises NotImplementedError for anything else.
+
+    ``func`` is recognised by identity, by a ``__qmri_model__`` attribute, or -- for a user's own
+    2-parameter callable such as ``lambda x, a, b: a * np.exp(b * x)`` -- by evaluating it on a few
+    probe points against ``a * exp(b * x)``.
+    """
+    if func is monoexponential or getattr(func, "__qmri_model__", None) == "monoexponential":
+        return "monoexponential"
+    try:
+        params = list(inspect.signature(func).parameters)
+    except (TypeError, ValueError):
+        params = []
+    nparams = len(params) - 2 if "self" in params else len(params) - 1
+    if nparams == 2:
+        rng = np.random.default_rng(12345)
+        xs = rng.uniform(0.1, 3.0, 7)
+        try:
+            ok = all(
+                np.allclose(np.asarray(func(xs, a, b), dtype=float), a * np.exp(b * xs),
+                            rtol=1e-12, atol=0)
+                for a, b in rng.uniform(-2, 2, (4, 2)))
+        except Exception:
+            ok = False
+        if ok:
+            return "monoexponential"
+    name = getattr(func, "__name__", type(func).__name__)
+    raise NotImplementedError(
+        f"dosma_amd fits the mono-exponential model y = a*exp(b*x) on the GPU; func={name!r} is not "
+        "that model and there is no CPU fallback (SURVEY.md section 8f, row N4).")
+
+
+def _func_param_names(func):
+    args = list(inspect.signature(func).parameters)
+    return args[2:] if "self" in args else args[1:]
+
+
+def _format_p0(p0, param_args, N):
+    """Normalise ``p0`` like the reference's module-level ``_format_p0`` (:1106-1161).
+
+    Returns a list with one entry per parameter: a float, or a float64 array of length N.
+    """
+    nparams = len(param_args)
+    if p0 is None:
+        return [1.0] * nparams  # scipy: p0 = ones(n)
+    if isinstance(p0, Number):
+        p0 = (p0,) * nparams
+    elif isinstance(p0, np.ndarray) and p0.ndim > 1:
+        p0 = tuple(p0[..., i] for i in range(p0.shape[-1]))
+
+    if isinstance(p0, Mapping):
+        extra = set(p0) - set(param_args)
+        if extra:
+            raise ValueError(f"`p0` has unknown keys: {extra}. "
+                             f"Function signature has parameters {param_args}.")
+        merged = {p: 1.0 for p in param_args}
+        merged.update(p0)
+        p0 = [merged[k] for k in param_args]
+    elif isinstance(p0, (np.ndarray, Sequence)):
+        if len(p0) != nparams:
+            raise ValueError(f"`p0` has length {len(p0)} but function has {nparams} parameters")
+        p0 = list(p0)
+    else:
+        raise ValueError(f"p0={p0} not supported")
+
+    out = []
+    for name, v in zip(param_args, p0):
+        if v is None:
+            out.append(1.0)
+        elif isinstance(v, np.ndarray) and v.ndim >= 1:
+            if len(v) != N:
+                raise ValueError(f"Got {len(v)} values for param '{name}'. Expected {N}")
+            out.append(np.ascontiguousarray(v, dtype=np.float64).reshape(-1))
+        else:
+            out.append(float(v))
+    return out
+
+
+_SUPPORTED_DTYPES = (np.float32, np.float64, np.int16, np.uint16)
+
+
+def _as_kernel_samples(y):
+    """Samples in a dtype the kernel reads natively; other real dtypes are widened losslessly."""
+    if y.dtype in [np.dtype(t) for t in _SUPPORTED_DTYPES]:
+        return np.ascontiguousarray(y)
+    if y.dtype == np.bool_ or (np.issubdtype(y.dtype, np.integer) and y.dtype.itemsize <= 1):
+        return np.ascontiguousarray(y, dtype=np.int16)
+    if np.issubdtype(y.dtype, np.floating) and y.dtype.itemsize < 4:
+        return np.ascontiguousarray(y, dtype=np.float32)
+    if np.issubdtype(y.dtype, np.integer) or np.issubdtype(y.dtype, np.floating):
+        # int32/int64/longdouble: scipy converts the samples to float64 anyway (asarray_chkfinite)
+        return np.ascontiguousarray(y, dtype=np.float64)
+    raise TypeError(f"Cannot fit data of dtype {y.dtype}")
+
+
+def curve_fit(
+    func,
+    x,
+    y,
+    y_bounds=None,
+    p0=None,
+    maxfev=100,
+    ftol=1e-5,
+    eps=1e-8,
+    show_pbar=False,
+    num_workers=0,
+    chunksize: int = None,
+    **kwargs,
+):
+    """Non-linear least squares fit of ``func`` to every column of ``y`` -- one GPU launch.
+
+    Same contract as the reference's ``curve_fit`` (:755-870): ``x`` (E,), ``y`` (E,) or (E, N)
+    echo-major, ``p0`` None / number / sequence / dict / (N, P) array with scalar or length-N entries;
+    returns ``popts`` (N, P) float64 and ``r_squared`` (N,) float64; a voxel that is all zero, out of
+    ``y_bounds``, or whose fit does not converge (MINPACK info not in 1..4) is ``(nan, nan), 0``.
+    ``show_pbar`` / ``num_workers`` / ``chunksize`` are accepted for compatibility and ignored (there
+    is no per-voxel Python loop to parallelise).  Extra scipy ``**kwargs`` (``bounds=``, ``sigma=``,
+    ``method=`` ...) select solvers this library does not implement -> NotImplementedError.
+    """
+    _model_of(func)
+    if kwargs:
+        raise NotImplementedError(
+            f"curve_fit(**{sorted(kwargs)}): only scipy's default unbounded Levenberg-Marquardt "
+            "('lm') configuration is implemented on the GPU; there is no CPU fallback.")
+    if isinstance(x, MedicalVolume) or isinstance(y, MedicalVolume):
+        raise TypeError("`x` and `y` must be array-like (use CurveFitter for MedicalVolumes)")
+    x = np.asarray(x)
+    y = np.asarray(y)
+    if y.ndim == 1:
+        y = y.reshape(y.shape + (1,))
+    if y.ndim != 2:
+        raise ValueError("`y` must have shape (M,) or (M, N)")
+    N = y.shape[-1]
+    param_args = _func_param_names(func)
+    p0 = _format_p0(p0, param_args, N)
+
+    if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
+        warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+
+    per_voxel = any(isinstance(v, np.ndarray) for v in p0)
+    out = _lib.monoexp_fit_host(
+        x.astype(np.float64).reshape(-1), _as_kernel_samples(y),
+        init=_lib.INIT_PER_VOXEL if per_voxel else _lib.INIT_SCALAR,
+        p0=tuple(1.0 if isinstance(v, np.ndarray) else v for v in p0),
+        a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
+        b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,
+        ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds,
+    )
+    return out["popt"], out["r2"]
+
+
+def polyfit(x, y, deg: int, rcond=None, full=False, w=None, cov=False, eps=1e-8, y_bounds=None,
+            show_pbar=False, num_workers=None, chunksize: int = None):
+    """Least-squares polynomial fit of every column of ``y`` (reference :873-1013), degree 1 on the GPU.
+
+    Returns ``popts`` (N, deg+1) in ``numpy.polyfit`` order (highest power first) and r2 (N,).
+    """
+    if deg != 1 or full or cov or w is not None or rcond is not None:
+        raise NotImplementedError(
+            "polyfit: only deg=1 without weights/cov/full is implemented on the GPU "
+            "(the log-linear fit of the mono-exponential path); there is no CPU fallback.")
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    y = np.asarray(y)
+    if y.ndim == 1:
+        y = y.reshape(y.shape + (1,))
+    if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
+        warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+    out = _lib.linfit_host(x, _as_kernel_samples(y), r2_eps=eps, y_bounds=y_bounds,
+                           per_sequence_rules=num_workers is not None)
+    return out["popt"], out["r2"]
+
+
+class _Fitter:
+    """Plumbing shared by the fitters: validation of the post-processing options, the mask, and the
+    wrapping of (N, P) / (N,) results into MedicalVolumes (reference :51-235)."""
+
+    nan_to_num = None
+    out_ufuncs = None
+    out_bounds = None
+    r2_threshold = None
+    y_bounds = None
+
+    def _format_out_ufuncs(self, _out_ufuncs, _func_nparams):
+        if not isinstance(_out_ufuncs, Callable) and not all(
+            isinstance(u, Callable) or u is None for u in _out_ufuncs
+        ):
+            raise TypeError(
+                f"`out_ufuncs` must be callable or sequence of callables. Got {_out_ufuncs}")
+        if isinstance(_out_ufuncs, Sequence) and len(_out_ufuncs) > _func_nparams:
+            warnings.warn(f"len(out_ufuncs)={len(_out_ufuncs)}, but only {_func_nparams} parameters. "
+                          f"Extra ufuncs will be ignored.")
+        return _out_ufuncs
+
+    def _format_out_bounds(self, _out_bounds):
+        out_bounds = np.asarray(_out_bounds)
+        if out_bounds.shape[-1] != 2 or out_bounds.ndim > 2:
+            raise ValueError("Invalid `out_bounds` - shape must be ([num_params,] 2)")
+        if np.any(out_bounds[..., 0] > out_bounds[..., 1]):
+            raise ValueError("Invalid `out_bounds` - lower bound must be <= upper bound")
+        return out_bounds
+
+    def _format_r2_threshold(self, _r2_threshold):
+        if isinstance(_r2_threshold, str):
+            if _r2_threshold != "preferences":
+                raise ValueError(
+                    f"Invalid value r2_threshold='{_r2_threshold}'. "
+                    f"Expected `None`, a number between [0, 1], or 'preferences'.")
+            _r2_threshold = preferences.fitting_r2_threshold
+        return _r2_threshold
+
+    def _process_mask(self, mask, y: MedicalVolume):
+        if isinstance(mask, np.ndarray):
+            mask = y._partial_clone(volume=mask, headers=None)
+        elif not isinstance(mask, MedicalVolume):
+            raise TypeError("`mask` must be a MedicalVolume or ndarray")
+        mask = mask.reformat_as(y)
+        if not mask.is_same_dimensions(y, defaults.AFFINE_DECIMAL_PRECISION):
+            raise RuntimeError("`mask` and `y` dimension mismatch")
+        return mask > 0
+
+    def _process_params(self, x, r_squared):
+        """Host post-processing for the general case (arbitrary Python ``out_ufuncs``): ufuncs ->
+        bounds -> r2 threshold -> nan_to_num, in the reference's order (:109-146).  The
+        MonoExponentialFit recipe never comes here: it is fused into the kernel."""
+        nparams = x.shape[-1]
+        out_ufuncs, out_bounds = self.out_ufuncs, self.out_bounds
+        with np.errstate(all="ignore"):
+            if isinstance(out_ufuncs, Callable):
+                x = out_ufuncs(x)
+            elif isinstance(out_ufuncs, Sequence):
+                for i in range(min(nparams, len(out_ufuncs))):
+                    if out_ufuncs[i] is not None:
+                        x[..., i] = out_ufuncs[i](x[..., i])
+            if out_bounds is not None:
+                lb, ub = self._bounds_per_param(nparams)
+                x[(x < lb) | (x > ub)] = np.nan
+            if self.r2_threshold is not None:
+                x[(r_squared < self.r2_threshold)] = np.nan
+            if self.nan_to_num is not None:
+                x = np.nan_to_num(x, nan=self.nan_to_num, copy=False)
+        return x
+
+    def _bounds_per_param(self, nparams):
+        ob = np.asarray(self.out_bounds, dtype=np.float64)
+        if ob.ndim == 1:
+            ob = np.tile(ob, (nparams, 1))
+        elif ob.shape[0] < nparams:
+            pad = np.tile([[-np.inf, np.inf]], (nparams - ob.shape[0], 1))
+            ob = np.concatenate([ob, pad], axis=0)
+        ob = ob[:nparams]
+        return ob[:, 0].copy(), ob[:, 1].copy()
+
+    # ---- shared front half of fit(): checks + flatten to (E, N) ----
+    def _prepare(self, x, y, mask):
+        if (not isinstance(y, (list, tuple))) or (not all(isinstance(_y, MedicalVolume) for _y in y)):
+            raise TypeError("`y` must be sequence of MedicalVolumes.")
+        x = np.asarray(x)
+        if x.shape[-1] != len(y):
+            raise ValueError(
+                "Dimension mismatch: x.shape[-1]={:d}, but len(y)={:d}".format(x.shape[-1], len(y)))
+        orientation = y[0].orientation
+        y = [_y.reformat(orientation) for _y in y]
+        mask_flat = None
+        if mask is not None:
+            mask = self._process_mask(mask, y[0])
+            mask_flat = np.ascontiguousarray(mask.volume.reshape(-1))
+        svs = np.concatenate([_y.volume.reshape((1, -1)) for _y in y], axis=0)
+        return x, y, svs, mask_flat
+
+    def _wrap(self, y0: MedicalVolume, popt, r_squared, copy_headers):
+        original_shape = y0.shape
+        popt = popt.reshape(original_shape + popt.shape[-1:])
+        r_squared = r_squared.reshape(original_shape)
+        if copy_headers:
+            headers = y0.headers()
+            if headers is not None:
+                headers = deepcopy(headers)
+                headers = np.expand_dims(headers, axis=-1)
+            popt_headers, r2_headers = headers, True
+        else:
+            popt_headers, r2_headers = None, None
+        return (y0._partial_clone(volume=popt, headers=popt_headers),
+                y0._partial_clone(volume=r_squared, headers=r2_headers))
+
+
+class CurveFitter(_Fitter):
+    """Non-linear least squares fit of ``func`` per voxel of co-registered MedicalVolumes.
+
+    Same constructor and ``fit`` contract as the reference's ``CurveFitter`` (:238-458).  ``func`` must
+    be the mono-exponential model (see :func:`curve_fit`).  ``num_workers`` / ``chunksize`` / ``verbose``
+    are accepted and ignored.
+    """
+
+    def __init__(
+        self,
+        func: Callable,
+        p0: Sequence[float] = None,
+        y_bounds=None,
+        out_ufuncs=None,
+        out_bounds=None,
+        r2_threshold="preferences",
+        nan_to_num: float = None,
+        num_workers: int = 0,
+        chunksize: int = None,
+        verbose: bool = False,
+        **kwargs,
+    ):
+        func_name = func.__name__ if hasattr(func, "__name__") else type(func).__name__
+        func_args = list(inspect.signature(func).parameters)
+        func_nparams = len(func_args) - 2 if "self" in func_args else len(func_args) - 1
+        if out_ufuncs is not None:
+            out_ufuncs = self._format_out_ufuncs(out_ufuncs, func_nparams)
+        if out_bounds is not None:
+            out_bounds = self._format_out_bounds(out_bounds)
+        r2_threshold = self._format_r2_threshold(r2_threshold)
+
+        self._func = func
+        self._func_name = func_name
+        self._func_nparams = func_nparams
+        self.p0 = self._format_p0(p0)
+        self.y_bounds = y_bounds
+        self.out_ufuncs = out_ufuncs
+        self.out_bounds = out_bounds
+        self.r2_threshold = r2_threshold
+        self.nan_to_num = nan_to_num
+        self.num_workers = num_workers
+        self.chunksize = chunksize
+        self.verbose = verbose
+        self.kwargs = kwargs
+
+    def _format_p0(self, p0, ref: MedicalVolume = None, flatten: bool = False, depth: int = 0):
+        """Per-parameter structure of scalars / flattened full-volume arrays (reference :344-380).
+
+        Unlike the reference the arrays are NOT mask-selected here: the kernel indexes per-voxel
+        guesses by voxel, and skips voxels outside the mask itself.
+        """
+        if p0 is None or isinstance(p0, Number):
+            return p0
+        if isinstance(p0, MedicalVolume) and depth > 0:
+            if ref is not None:
+                p0 = p0.reformat_as(ref)
+                assert p0.is_same_dimensions(ref, err=True)
+            return p0.A.flatten() if flatten else p0
+        if isinstance(p0, np.ndarray) and depth > 0:
+            if ref is not None and p0.shape != ref.shape:
+                raise ValueError(f"Got p0.shape={p0.shape}, but y.shape={ref.shape}")
+            return p0.flatten() if flatten else p0
+        if isinstance(p0, Mapping):
+            return {k: self._format_p0(v, ref, flatten, depth + 1) for k, v in p0.items()}
+        if isinstance(p0, Sequence):
+            return tuple(self._format_p0(v, ref, flatten, depth + 1) for v in p0)
+        if isinstance(p0, (np.ndarray, MedicalVolume)):
+            # a single array: the last axis is the parameter axis
+            return tuple(self._format_p0(p0[..., i], ref, flatten, depth + 1)
+                         for i in range(p0.shape[-1]))
+        raise ValueError(f"p0={p0} not supported")
+
+    def _fusable_post(self):
+        """Post-processing block for the kernel if ``out_ufuncs`` is expressible there, else None."""
+        uf = self.out_ufuncs
+        inv = False
+        if uf is not None:
+            if isinstance(uf, Callable):
+                return None
+            uf = list(uf)[: self._func_nparams]
+            if len(uf) > 0 and uf[0] is not None:
+                return None
+            if len(uf) > 1 and uf[1] is not None:
+                if getattr(uf[1], "__qmri_ufunc__", None) != "inv_abs":
+                    return None
+                inv = True
+        bounds = None
+        if self.out_bounds is not None:
+            lb, ub = self._bounds_per_param(2)
+            bounds = ((lb[0], ub[0]), (lb[1], ub[1]))
+        return dict(inv_abs_b=inv, bounds=bounds, r2_threshold=self.r2_threshold,
+                    nan_to_num=self.nan_to_num)
+
+    def fit(self, x, y: Sequence[MedicalVolume], mask=None, p0=np._NoValue, copy_headers: bool = True,
+            _decimals=None):
+        """Fit every voxel; returns ``(popt, r2)`` MedicalVolumes (``popt`` has a trailing parameter
+        axis).  Voxels outside ``mask`` hold NaN (or ``nan_to_num``) like the reference (:205-215)."""
+        _model_of(self._func)
+        if self.kwargs:
+            raise NotImplementedError(
+                f"CurveFitter(**{sorted(self.kwargs)}): extra scipy arguments are not implemented "
+                "on the GPU; there is no CPU fallback.")
+        if isinstance(x, MedicalVolume):
+            raise RuntimeError("`x` must be on the CPU")
+        x, y, svs, mask_flat = self._prepare(x, y, mask)
+        N = svs.shape[1]
+        if p0 is np._NoValue:
+            p0 = self.p0
+        p0 = self._format_p0(p0, ref=y[0], flatten=True)
+        p0 = _format_p0(p0, _func_param_names(self._func), N)
+        per_voxel = any(isinstance(v, np.ndarray) for v in p0)
+        init = _lib.INIT_PER_VOXEL if per_voxel else _lib.INIT_SCALAR
+        if getattr(self, "_loglin_init", False):
+            init = _lib.INIT_LOGLIN
+
+        if self.y_bounds is not None and ((svs < self.y_bounds[0]).any() or (svs > self.y_bounds[1]).any()):
+            warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+
+        post = self._fusable_post()
+        if post is not None and _decimals is not None:
+            post["decimals"] = _decimals
+        out = _lib.monoexp_fit_host(
+            x.astype(np.float64).reshape(-1), _as_kernel_samples(svs), mask=mask_flat, init=init,
+            p0=tuple(1.0 if isinstance(v, np.ndarray) else v for v in p0),
+            a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
+            b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,
+            post=post, want_tc=_decimals is not None and post is not None,
+            y_bounds=self.y_bounds,
+        )
+        popt, r2 = out["popt"], out["r2"]
+        if post is None:
+            # arbitrary Python ufuncs: the reference's own post-processing, on the fitted rows only
+            if mask_flat is None:
+                popt = self._process_params(popt, r2)
+            else:
+                popt[mask_flat] = self._process_params(popt[mask_flat], r2[mask_flat])
+                if self.nan_to_num is not None:
+                    popt[~mask_flat] = self.nan_to_num
+                    r2[~mask_flat] = self.nan_to_num
+        popt_mv, r2_mv = self._wrap(y[0], popt, r2, copy_headers)
+        if "tc" in out:
+            self._last_tc = out["tc"]
+        return popt_mv, r2_mv
+
+    def __str__(self) -> str:
+        attrs = ["p0", "y_bounds", "out_bounds", "r2_threshold", "nan_to_num", "num_workers",
+                 "chunksize", "verbose"]
+        vals = [f"func={self._func_name}"]
+        vals += [f"{k}={getattr(self, k)}" for k in attrs]
+        vals += [f"{k}={v}" for k, v in self.kwargs.items()]
+        return f"{self.__class__.__name__}(\n\t" + "\n\t".join(v + "," for v in vals) + "\n)"
+
+
+class PolyFitter(_Fitter):
+    """Linear least squares polynomial fit per voxel (reference :461-604); degree 1 on the GPU."""
+
+    def __init__(self, deg: int, rcond: float = None, y_bounds=None, out_ufuncs=None,
+                 out_bounds=None, r2_threshold="preferences", nan_to_num: float = None,
+                 num_workers: int = None, chunksize: int = None, verbose: bool = False):
+        if out_ufuncs is not None:
+            out_ufuncs = self._format_out_ufuncs(out_ufuncs, deg + 1)
+        if out_bounds is not None:
+            out_bounds = self._format_out_bounds(out_bounds)
+        self.deg = deg
+        self.rcond = rcond
+        self.y_bounds = y_bounds
+        self.out_ufuncs = out_ufuncs
+        self.out_bounds = out_bounds
+        self.r2_threshold = self._format_r2_threshold(r2_threshold)
+        self.nan_to_num = nan_to_num
+        self.num_workers = num_workers
+        self.chunksize = chunksize
+        self.verbose = verbose
+
+    def fit(self, x, y: Sequence[MedicalVolume], mask=None, copy_headers: bool = True):
+        x, y, svs, mask_flat = self._prepare(x, y, mask)
+        sel = svs if mask_flat is None else np.ascontiguousarray(svs[:, mask_flat])
+        popt, r2 = polyfit(x, sel, deg=self.deg, rcond=self.rcond, y_bounds=self.y_bounds,
+                           num_workers=self.num_workers, chunksize=self.chunksize)
+        popt = self._process_params(popt, r2)
+        if mask_flat is not None:
+            fill = np.nan if self.nan_to_num is None else self.nan_to_num
+            popt_full = np.full((svs.shape[1], popt.shape[-1]), fill, dtype=np.float64)
+            r2_full = np.full(svs.shape[1], fill, dtype=np.float64)
+            popt_full[mask_flat] = popt
+            r2_full[mask_flat] = r2
+            popt, r2 = popt_full, r2_full
+        return self._wrap(y[0], popt, r2, copy_headers)
+
+    def __str__(self) -> str:
+        attrs = ["deg", "rcond", "y_bounds", "out_bounds", "r2_threshold", "nan_to_num",
+                 "num_workers", "chunksize", "verbose"]
+        vals = [f"{k}={getattr(self, k)}" for k in attrs]
+        return f"{self.__class__.__name__}(\n\t" + "\n\t".join(v + "," for v in vals) + "\n)"
+
+
+class MonoExponentialFit:
+    """Per-voxel time constant of ``y = a * exp(-x / tc)`` (T2, T1rho, T2* maps).
+
+    Same constructor, ``fit`` contract and defaults as the reference's ``MonoExponentialFit``
+    (:607-749).  The whole recipe -- optional log-linear initial guess (``tc0="polyfit"``, :701-718),
+    the LM fit, ``tc = 1/|b|``, bounds, r2 threshold, ``nan_to_num(0)`` and rounding (:722-737) -- is ONE
+    kernel launch.
+    """
+
+    def __init__(self, x: Sequence[float] = None, y: Sequence[MedicalVolume] = None,
+                 mask: MedicalVolume = None, bounds=(0, 100.0), tc0=30.0,
+                 r2_threshold="preferences", decimal_precision: int = 1, num_workers: int = 0,
+                 chunksize: int = 1000, verbose: bool = False):
+        self.x = x
+        if y is not None:
+            warnings.warn(
+                f"Setting `y` in the constructor can result in significant memory overhead. "
+                f"Specify `y` in `{type(self).__name__}.fit(y=...)` instead.")
+            self._check_y(x, y)
+        self.y = y
+        if mask is not None:
+            warnings.warn(
+                f"Setting `mask` in the constructor can result in significant memory overhead. "
+                f"Specify `mask` in `{type(self).__name__}.fit(mask=...)` instead.")
+        self.mask = mask
+        if not (isinstance(tc0, Number) or (isinstance(tc0, str) and tc0 == "polyfit")):
+            raise ValueError("`tc0` must either be a float or the string 'polyfit'.")
+        self.verbose = verbose
+        self.num_workers = num_workers
+        if len(bounds) != 2:
+            raise ValueError("`bounds` should provide lower/upper bound in format (lb, ub)")
+        self.bounds = bounds
+        self.chunksize = chunksize
+        self.r2_threshold = r2_threshold
+        self.tc0 = tc0
+        self.decimal_precision = decimal_precision
+        self._eps = 1e-10  # epsilon for polyfit (reference :676) -- fixed in the kernel
+
+    def fit(self, x=None, y: Sequence[MedicalVolume] = None, mask=None):
+        """Returns ``(tc, r2)`` MedicalVolumes (float64), like the reference (:678-739)."""
+        x = self.x if x is None else x
+        y = self.y if y is None else y
+        mask = self.mask if mask is None else mask
+        self._check_y(x, y)
+        orientation = y[0].orientation
+        y = [sv.reformat(orientation) for sv in y]
+        if isinstance(mask, np.ndarray):
+            mask = MedicalVolume(mask, affine=y[0].affine)
+        if mask is not None and not isinstance(mask, MedicalVolume):
+            raise TypeError("`mask` must be a MedicalVolume")
+        mask = mask.reformat(orientation) if mask is not None else None
+
+        fitter = CurveFitter(
+            monoexponential,
+            y_bounds=None,
+            out_ufuncs=(None, _inv_abs),
+            out_bounds=((-np.inf, np.inf), self.bounds),
+            r2_threshold=self.r2_threshold,
+            num_workers=self.num_workers,
+            chunksize=self.chunksize,
+            verbose=self.verbose,
+            nan_to_num=0.0,
+        )
+        if isinstance(self.tc0, str):
+            fitter._loglin_init = True
+            p0 = None
+        else:
+            p0 = {"a": 1.0, "b": -1 / self.tc0}
+        decimals = self.decimal_precision
+        popt, r_squared = fitter.fit(x, y, mask=mask, p0=p0,
+                                     _decimals=decimals if decimals is not None else None)
+        if decimals is not None:
+            tc = fitter._last_tc.reshape(y[0].shape)
+            tc_map = popt[..., 1]
+            tc_map._volume = tc
+        else:
+            tc_map = popt[..., 1]
+        return tc_map, r_squared
+
+    def _check_y(self, x, y):
+        if (not isinstance(y, Sequence)) or (not all(isinstance(sv, MedicalVolume) for sv in y)):
+            raise TypeError("`y` must be list of MedicalVolumes.")
+        if len(x) != len(y):
+            raise ValueError("`len(x)`={:d}, but `len(y)`={:d}".format(len(x), len(y)))

@@ -87,7 +87,9 @@ typedef struct qmri_monoexp_args {
     const double *x;     /* HOST [E] sample positions (echo / spin-lock times)                        */
     const uint8_t *mask; /* nullable [N]: fit only voxels with mask != 0 (fitting.py:107, 199-200)    */
     int32_t init;        /* qmri_init                                                                 */
-    int32_t reserved0;
+    int32_t use_y_bounds;/* 1: voxels with a sample < y_lo or > y_hi are skipped like all-zero ones
+                            (curve_fit(y_bounds=...), fitting.py:1064-1067)                           */
+    double y_lo, y_hi;
     double a0, b0;       /* scalar initial guess                                                      */
     const double *a0v;   /* nullable [N] (indexed by voxel, not by position in the mask)              */
     const double *b0v;   /* nullable [N]                                                              */
@@ -133,6 +135,37 @@ int qmri_monoexp_fit_device(const qmri_monoexp_args *args, int32_t *nonfinite_fl
  * This is what the Python drop-in (dosma_amd.fitting) calls for CPU MedicalVolumes.
  */
 int qmri_monoexp_fit_host(const qmri_monoexp_args *args);
+
+/*
+ * Degree-1 least squares per voxel: popt[N][2] = (slope, intercept) in numpy.polyfit order, r2[N].
+ * Replaces polyfit(x, y, 1) of the reference (fitting.py:873-1013; joint solve :974-984, r2 :926-944).
+ *   log_transform 1: fit log(v + 1e-10*(v==0)) -- the log-linearisation of
+ *                    MonoExponentialFit(tc0="polyfit") (fitting.py:710-715);
+ *   skip_rules    1: all-zero / out-of-y_bounds voxels -> (NaN, NaN), r2 = 0 (fitting.py:1095-1097,
+ *                    the per-sequence branch taken when num_workers is not None).
+ */
+typedef struct qmri_linfit_args {
+    const void *y;       /* [E][ld] echo-major */
+    int32_t y_dtype;     /* qmri_dtype */
+    int32_t E;           /* 2 <= E <= QMRI_MAX_ECHOES */
+    int64_t N;
+    int64_t ld;
+    const double *x;     /* HOST [E] */
+    int32_t log_transform;
+    int32_t skip_rules;
+    int32_t use_y_bounds;
+    int32_t out_dtype;   /* QMRI_F32 | QMRI_F64 */
+    double y_lo, y_hi;
+    double r2_eps;       /* 1e-8 */
+    void *popt;          /* [N][2] */
+    void *r2;            /* [N] */
+    int32_t device;
+    int32_t reserved;
+    void *stream;
+} qmri_linfit_args;
+
+int qmri_linfit_device(const qmri_linfit_args *args); /* device pointers, asynchronous on args->stream */
+int qmri_linfit_host(const qmri_linfit_args *args);   /* host pointers, synchronous */
 
 /* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
  * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */

@@ -26,13 +26,17 @@
  * by running the real reference code (oracle/make_golden.py -> tests/golden/).
  *
  * jac_mode: 0 = forward-difference Jacobian (what lmdif/scipy does; the parity anchor)
- *           1 = analytic Jacobian with lmdif's nfev accounting (what the HIP kernel does;
- *               lets tests separate "analytic-vs-FD" differences from HIP bugs)
+ *           1 = analytic Jacobian with lmdif's nfev accounting
+ *           2 = forward differences emulated without extra exponentials (what the HIP kernel does;
+ *               lets tests separate "emulated-vs-true FD" differences from HIP bugs)
  */
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifdef ORACLE_TRACE
+#include <stdio.h>
+#endif
 
 #define MAXN 8   /* parameters */
 #define MAXM 64  /* samples per voxel */
@@ -300,6 +304,24 @@ static int lm_solve(model_fn fcn, jac_fn jac, int jac_mode, int m, int n, double
                 x[j] = temp;
                 for (int i = 0; i < m; ++i) fjac[(size_t)j * ld + i] = (wa4[i] - fvec[i]) / h;
             }
+        } else if (jac_mode == 2) {
+            /* forward differences emulated WITHOUT extra exps (monoexponential only; what the HIP
+             * kernel does): column a is lmdif's difference quotient exactly (same e_i); column b uses
+             * e_i * exp(delta_i) with exp(delta) = 1 + d + d^2/2 + d^3/6 for the ~1e-8 argument shift. */
+            const double eps = sqrt(epsfcn > epsmch ? epsfcn : epsmch);
+            const double a = x[0], b = x[1];
+            double ha = eps * fabs(a), hb = eps * fabs(b);
+            if (ha == 0.0) ha = eps;
+            if (hb == 0.0) hb = eps;
+            const double a1 = a + ha, b1 = b + hb;
+            for (int i = 0; i < m; ++i) {
+                const double bx = b * xs[i];
+                const double e = exp(bx);
+                fjac[i] = ((a1 * e - ys[i]) - fvec[i]) / ha;
+                const double d = b1 * xs[i] - bx;
+                const double e1 = e + e * (d + d * d * (0.5 + d * (1.0 / 6.0)));
+                fjac[ld + i] = ((a * e1 - ys[i]) - fvec[i]) / hb;
+            }
         } else {
             jac(m, n, x, xs, fjac, ld);
         }
@@ -338,6 +360,10 @@ static int lm_solve(model_fn fcn, jac_fn jac, int jac_mode, int m, int n, double
                 if (g > gnorm) gnorm = g;
             }
         }
+#ifdef ORACLE_TRACE
+        printf("qr x=(%.17g,%.17g) acn=(%.17g,%.17g) l0=%d R=(%.17g,%.17g,%.17g) qtf=(%.17g,%.17g) gnorm=%.6g\n",
+               x[0], x[1], wa2[0], wa2[1], ipvt[0], fjac[0], fjac[ld], fjac[ld + 1], qtf[0], qtf[1], gnorm);
+#endif
         if (gnorm <= gtol) info = 4;
         if (info != 0) break;
         for (int j = 0; j < n; ++j)
@@ -372,6 +398,10 @@ static int lm_solve(model_fn fcn, jac_fn jac, int jac_mode, int m, int n, double
             const double dirder = -(temp1 * temp1 + temp2 * temp2);
             ratio = 0.0;
             if (prered != 0.0) ratio = actred / prered;
+#ifdef ORACLE_TRACE
+            printf("it nfev=%d trial=(%.17g,%.17g) p=(%.6g,%.6g) par=%.6g delta=%.6g fnorm=%.17g fnorm1=%.17g actred=%.6g prered=%.6g ratio=%.6g\n",
+                   nfev, wa2[0], wa2[1], wa1[0], wa1[1], par, delta, fnorm, fnorm1, actred, prered, ratio);
+#endif
             if (ratio <= 0.25) {
                 double temp = 0.5;
                 if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);

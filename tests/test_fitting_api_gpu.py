@@ -1,0 +1,381 @@
+"""The drop-in Python API on the GPU, exercised the way the reference's own tests exercise theirs
+(/root/reference/tests/core/test_fitting.py: TestCurveFit :70-140, TestMonoExponentialFit :199-277,
+TestCurveFitter :280-571, TestPolyFitter :574-674) -- same generators (seeded here), same
+assertions, our classes.
+"""
+import numpy as np
+import pytest
+
+from dosma_amd import (CurveFitter, MedicalVolume, MonoExponentialFit, PolyFitter, curve_fit,
+                       monoexponential, polyfit)
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(2024)
+
+
+def gen_monoexp(shape=None, x=None, a=1.0, b=None):
+    """y = a * exp(b * x), b ~ U[0.1, 1.1) (reference tests :18-31)."""
+    if b is None:
+        b = RNG.random(shape) + 0.1
+    if x is None:
+        x = np.asarray([0.5, 1.0, 2.0, 4.0])
+    y = [MedicalVolume(monoexponential(t, a, b), affine=np.eye(4)) for t in x]
+    return x, y, b
+
+
+def gen_affine(shape=None, x=None, a=None, b=1.0):
+    if a is None:
+        a = RNG.random(shape) + 0.1
+    if x is None:
+        x = np.asarray([0.5, 1.0, 2.0, 4.0])
+    if b is None:
+        b = RNG.random(a.shape)
+    return x, [MedicalVolume(a * t + b, affine=np.eye(4)) for t in x], a, b
+
+
+class Header(dict):
+    """Stand-in for a pydicom dataset: the path only deep-copies and reshapes header arrays."""
+
+
+def dummy_headers(shape, fields=None):
+    arr = np.empty(shape, dtype=object)
+    for idx in np.ndindex(*shape):
+        arr[idx] = Header(fields or {})
+    return arr
+
+
+# --------------------------------------------------------------------------- curve_fit
+class TestCurveFit:
+    def test_workers_and_pbar_are_accepted(self):
+        x = np.asarray([1, 2, 3, 4])
+        ys = np.stack([monoexponential(x, RNG.random(), RNG.random()) for _ in range(1000)], axis=-1)
+        popt, r2 = curve_fit(monoexponential, x, ys)
+        assert popt.shape == (1000, 2) and popt.dtype == np.float64 and r2.shape == (1000,)
+        popt_mw, _ = curve_fit(monoexponential, x, ys, num_workers=4)
+        assert np.allclose(popt, popt_mw)
+        popt_mw, _ = curve_fit(monoexponential, x, ys, num_workers=4, show_pbar=True, chunksize=10)
+        assert np.allclose(popt, popt_mw)
+
+    def test_p0_spellings(self):
+        x = np.asarray([1, 2, 3, 4])
+        num = 50
+        ys = np.stack([monoexponential(x, RNG.random(), RNG.random()) for _ in range(num)], axis=-1)
+        popt_1_1, _ = curve_fit(monoexponential, x, ys)
+        popt_1_50, _ = curve_fit(monoexponential, x, ys, p0=(1.0, 50.0))
+        eq = lambda a, b: np.allclose(a, b, equal_nan=True)  # noqa: E731
+        assert eq(curve_fit(monoexponential, x, ys, p0=(1.0, 1.0))[0], popt_1_1)
+        assert eq(curve_fit(monoexponential, x, ys, p0=(None, 1.0))[0], popt_1_1)
+        assert eq(curve_fit(monoexponential, x, ys, p0=(1.0, None))[0], popt_1_1)
+        assert eq(curve_fit(monoexponential, x, ys, p0=1.0)[0], popt_1_1)
+        assert eq(curve_fit(monoexponential, x, ys, p0={"a": 1.0, "b": 1.0})[0], popt_1_1)
+        assert eq(curve_fit(monoexponential, x, ys, p0={"b": 50.0})[0], popt_1_50)
+        assert eq(curve_fit(monoexponential, x, ys, p0=np.ones((num, 2)))[0], popt_1_1)
+        p0 = np.stack([np.ones(num), 50 * np.ones(num)], axis=-1)
+        assert eq(curve_fit(monoexponential, x, ys, p0=p0)[0], popt_1_50)
+        assert eq(curve_fit(monoexponential, x, ys, p0=[np.ones(num), 50])[0], popt_1_50)
+        with pytest.raises(ValueError):
+            curve_fit(monoexponential, x, ys, p0=(1.0, 1.0, 1.0))
+        with pytest.raises(ValueError):
+            curve_fit(monoexponential, x, ys, p0={"c": 1.0})
+        with pytest.raises(ValueError):
+            curve_fit(monoexponential, x, ys, p0=[np.ones(num + 1), 50])
+
+    def test_recovers_parameters_and_single_sequence(self):
+        x = np.asarray([1.0, 2.0, 3.0, 4.0])
+        y = monoexponential(x, 0.7, 0.3)
+        popt, r2 = curve_fit(monoexponential, x, y)  # 1-D y
+        assert popt.shape == (1, 2) and np.allclose(popt[0], (0.7, 0.3)) and r2[0] > 0.999999
+        popt, _ = curve_fit(lambda t, a, b: a * np.exp(b * t), x, y)  # user's own lambda
+        assert np.allclose(popt[0], (0.7, 0.3))
+
+    def test_unsupported_requests_fail_loudly(self):
+        x = np.asarray([1.0, 2.0, 3.0, 4.0])
+        y = np.ones((4, 3))
+        with pytest.raises(NotImplementedError):
+            curve_fit(lambda t, a: a * t, x, y)
+        with pytest.raises(NotImplementedError):
+            curve_fit(monoexponential, x, y, bounds=(0, 1))
+        with pytest.raises(ValueError):
+            curve_fit(monoexponential, x, np.full((4, 3), np.nan))
+
+
+# --------------------------------------------------------------------------- MonoExponentialFit
+class TestMonoExponentialFit:
+    def test_basic(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        t = 1 / np.abs(b)
+        t_hat, r2 = MonoExponentialFit(decimal_precision=8).fit(x, y)
+        assert isinstance(t_hat, MedicalVolume) and t_hat.dtype == np.float64
+        assert t_hat.shape == (10, 10, 20) and r2.shape == (10, 10, 20)
+        assert np.allclose(t_hat.volume, t)
+        with pytest.warns(UserWarning):
+            fitter = MonoExponentialFit(x, y, decimal_precision=8)
+        assert np.allclose(fitter.fit(x, y)[0].volume, t)
+        assert np.allclose(fitter.fit()[0].volume, t)
+        with pytest.raises(ValueError), pytest.warns(UserWarning):
+            MonoExponentialFit(list(x) + [5], y)
+        with pytest.raises(TypeError), pytest.warns(UserWarning):
+            MonoExponentialFit(x, [_y.A for _y in y])
+        with pytest.raises(ValueError):
+            MonoExponentialFit(tc0="a value")
+        with pytest.raises(ValueError):
+            MonoExponentialFit(bounds=(0, 1, 2))
+
+    def test_defaults_round_and_threshold(self):
+        """decimal_precision=1, bounds (0, 100), r2 >= 0.9, nan_to_num 0 (reference :632-644)."""
+        x = np.arange(1, 9) * 10.0
+        t2 = RNG.uniform(15, 150, (8, 8, 4))
+        y = [MedicalVolume((1000 * np.exp(-t / t2)).astype(np.float32), np.eye(4)) for t in x]
+        tc, r2 = MonoExponentialFit().fit(x, y)
+        inb = t2 <= 99.9
+        assert np.allclose(tc.volume[inb], np.round(t2[inb], 1), atol=0.11)
+        assert np.all(tc.volume[t2 > 100.1] == 0)  # out of bounds -> NaN -> 0
+        assert np.all(np.round(tc.volume * 10) == tc.volume * 10) or np.allclose(
+            np.round(tc.volume, 1), tc.volume)
+
+    def test_headers(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        for idx, _y in enumerate(y):
+            _y._headers = dummy_headers((1, 1, 20), {"StudyDescription": "Sample study",
+                                                     "EchoNumbers": idx})
+        t_hat, r2 = MonoExponentialFit(decimal_precision=8).fit(x, y)
+        assert np.allclose(t_hat.volume, 1 / np.abs(b))
+        assert t_hat.headers() is not None and t_hat.headers().shape == (1, 1, 20)
+        for h in t_hat.headers().flatten():
+            assert h.get("StudyDescription") == "Sample study"
+        assert t_hat.headers()[0, 0, 0] is not y[0].headers()[0, 0, 0]  # deep copy
+        assert r2.headers().shape == (1, 1, 20)
+
+    def test_mask(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        mask_arr = RNG.random(y[0].shape) > 0.5
+        t = 1 / np.abs(b)
+        mask = MedicalVolume(mask_arr, np.eye(4))
+        t_hat = MonoExponentialFit(decimal_precision=8).fit(x, y, mask)[0]
+        assert np.allclose(t_hat.volume[mask_arr != 0], t[mask_arr != 0])
+        assert np.all(t_hat.volume[mask_arr == 0] == 0)
+        t_hat2 = MonoExponentialFit(decimal_precision=8).fit(x, y, mask_arr)[0]
+        assert np.allclose(t_hat2.volume, t_hat.volume)
+        with pytest.warns(UserWarning):
+            fitter3 = MonoExponentialFit(mask=mask, decimal_precision=8)
+        assert np.allclose(fitter3.fit(x, y)[0].volume, t_hat.volume)
+        # integer (uint8) masks and masks in another orientation
+        t_hat4 = MonoExponentialFit(decimal_precision=8).fit(
+            x, y, MedicalVolume(mask_arr.astype(np.uint8), np.eye(4)).reformat(("SI", "AP", "LR")))[0]
+        assert np.allclose(t_hat4.volume, t_hat.volume)
+
+    def test_polyfit_initialization(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        t = 1 / np.abs(b)
+        t_hat = MonoExponentialFit(tc0="polyfit", decimal_precision=8).fit(x, y)[0]
+        assert np.allclose(t_hat.volume, t)
+        # zeros in echo 0: those voxels are off, the rest must be unaffected
+        x, y, b = gen_monoexp((10, 10, 20))
+        t = 1 / np.abs(b)
+        mask_arr = np.zeros(y[0].shape, dtype=bool)
+        mask_arr[:5, :5] = 1
+        y[0].volume[mask_arr] = 0
+        t_hat = MonoExponentialFit(tc0="polyfit", decimal_precision=8).fit(x, y)[0]
+        assert np.allclose(t_hat.volume[mask_arr == 0], t[mask_arr == 0])
+
+    def test_orientation_of_inputs_is_harmonised(self):
+        """fit() reformats every echo to y[0]'s orientation (reference :692-694)."""
+        x, y, b = gen_monoexp((6, 7, 8))
+        y_mixed = [y[0]] + [v.reformat(("SI", "AP", "LR")) for v in y[1:]]
+        t1 = MonoExponentialFit(decimal_precision=8).fit(x, y)[0]
+        t2 = MonoExponentialFit(decimal_precision=8).fit(x, y_mixed)[0]
+        assert t2.orientation == y[0].orientation and np.array_equal(t1.volume, t2.volume)
+
+
+# --------------------------------------------------------------------------- CurveFitter
+class TestCurveFitter:
+    def test_basic(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        popt, r2 = CurveFitter(monoexponential).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert popt.shape == (10, 10, 20, 2)
+        assert np.allclose(a_hat.volume, 1.0) and np.allclose(b_hat.volume, b)
+        assert np.all(popt.affine == y[0].affine) and np.all(r2.affine == y[0].affine)
+
+    def test_mask(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        mask_arr = RNG.random(y[0].shape) > 0.5
+        for mask in (MedicalVolume(mask_arr, y[0].affine), mask_arr):
+            popt, r2 = CurveFitter(monoexponential).fit(x, y, mask=mask)
+            a_hat, b_hat = popt[..., 0], popt[..., 1]
+            assert np.allclose(a_hat.volume[mask_arr != 0], 1.0)
+            assert np.allclose(b_hat.volume[mask_arr != 0], b[mask_arr != 0])
+            assert np.all(np.isnan(a_hat.volume[mask_arr == 0]))
+            assert np.all(np.isnan(b_hat.volume[mask_arr == 0]))
+            assert np.all(np.isnan(r2.volume[mask_arr == 0]))
+        with pytest.raises(TypeError):
+            CurveFitter(monoexponential).fit(x, y, mask="foo")
+        with pytest.raises(RuntimeError):
+            CurveFitter(monoexponential).fit(x, y, mask=RNG.random((5, 5, 5)) > 0.5)
+
+    def _ab(self, shape=(10, 10, 20)):
+        a = np.ones(shape)
+        a[5:] = 1.5
+        b = RNG.random(shape) + 0.1
+        b[:5] = 1.5
+        return a, b
+
+    def test_bounds(self):
+        a, b = self._ab()
+        x, y, _ = gen_monoexp(a=a, b=b)
+        popt, _ = CurveFitter(monoexponential, out_bounds=(0, 1.2)).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat[:5].volume, 1.0) and np.all(np.isnan(a_hat[5:].volume))
+        assert np.allclose(b_hat[5:].volume, b[5:]) and np.all(np.isnan(b_hat[:5].volume))
+        popt, _ = CurveFitter(monoexponential, out_bounds=[(-np.inf, np.inf), (0, 1.2)]).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat.volume, a)
+        assert np.allclose(b_hat[5:].volume, b[5:]) and np.all(np.isnan(b_hat[:5].volume))
+        popt, _ = CurveFitter(monoexponential, out_bounds=[(0, 1.2)]).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat[:5].volume, 1.0) and np.all(np.isnan(a_hat[5:].volume))
+        assert np.allclose(b_hat.volume, b)
+        with pytest.raises(ValueError):
+            CurveFitter(monoexponential, out_bounds=[(0, 0.5, 1.0)])
+        with pytest.raises(ValueError):
+            CurveFitter(monoexponential, out_bounds=[(1.2, 0)])
+
+    def test_out_ufuncs(self):
+        shape = (10, 10, 20)
+        a = -1
+        b = RNG.random(shape) - 1.1
+        x, y, _ = gen_monoexp(a=a, b=b)
+        ufunc = lambda v: 2 * np.abs(v) + 5  # noqa: E731
+        popt, _ = CurveFitter(monoexponential, out_ufuncs=ufunc).fit(x, y)
+        assert np.allclose(popt[..., 0].volume, ufunc(a)) and np.allclose(popt[..., 1].volume, ufunc(b))
+        popt, _ = CurveFitter(monoexponential, out_ufuncs=[None, ufunc]).fit(x, y)
+        assert np.allclose(popt[..., 0].volume, a) and np.allclose(popt[..., 1].volume, ufunc(b))
+        popt, _ = CurveFitter(monoexponential, out_ufuncs=[ufunc]).fit(x, y)
+        assert np.allclose(popt[..., 0].volume, ufunc(a)) and np.allclose(popt[..., 1].volume, b)
+        with pytest.raises(TypeError):
+            CurveFitter(monoexponential, out_ufuncs=[None, 5])
+        with pytest.warns(UserWarning):
+            CurveFitter(monoexponential, out_ufuncs=[None, ufunc, ufunc])
+
+    def test_nan_to_num(self):
+        a, b = self._ab()
+        x, y, _ = gen_monoexp(a=a, b=b)
+        popt, _ = CurveFitter(monoexponential, out_bounds=(0, 1.2), nan_to_num=0.0).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat[:5].volume, 1.0) and np.allclose(a_hat[5:].volume, 0.0)
+        assert np.allclose(b_hat[5:].volume, b[5:]) and np.allclose(b_hat[:5].volume, 0.0)
+
+    def test_matches_monoexponential_fit(self):
+        x, y, _ = gen_monoexp((10, 10, 20))
+        t_mef = MonoExponentialFit(tc0=30.0, bounds=(0, 100), decimal_precision=8).fit(x, y)[0]
+        fitter = CurveFitter(monoexponential, p0=(1.0, -1 / 30),
+                             out_ufuncs=[None, lambda v: 1 / np.abs(v)], out_bounds=(0, 100),
+                             nan_to_num=0)
+        t_cf = np.round(fitter.fit(x, y)[0][..., 1], decimals=8)
+        assert np.allclose(t_mef.volume, t_cf.volume)
+
+    def test_headers(self):
+        x, y, b = gen_monoexp((10, 10, 20, 4))
+        for idx, _y in enumerate(y):
+            _y._headers = dummy_headers((1, 1, 20, 4), {"EchoNumbers": idx})
+        popt, _ = CurveFitter(monoexponential).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat.volume, 1.0) and np.allclose(b_hat.volume, b)
+        assert popt.headers().shape == (1, 1, 20, 4, 1)
+        assert b_hat.headers() is not None and b_hat.headers().shape == (1, 1, 20, 4)
+        popt, _ = CurveFitter(monoexponential).fit(x, y, copy_headers=False)
+        assert popt[..., 0].headers() is None and popt[..., 1].headers() is None
+
+    def test_p0(self):
+        x, y, b = gen_monoexp((10, 10, 20))
+        aff = y[0].affine
+
+        def check(popt, sel=None):
+            a_hat, b_hat = popt[..., 0].volume, popt[..., 1].volume
+            if sel is None:
+                assert np.allclose(a_hat, 1.0) and np.allclose(b_hat, b)
+            else:
+                assert np.allclose(a_hat[sel], 1.0) and np.allclose(b_hat[sel], b[sel])
+                assert np.all(np.isnan(a_hat[~sel])) and np.all(np.isnan(b_hat[~sel]))
+
+        check(CurveFitter(monoexponential, p0=(1.0, b)).fit(x, y)[0])
+        check(CurveFitter(monoexponential, p0={"a": 1.0, "b": b}).fit(x, y)[0])
+        check(CurveFitter(monoexponential, p0={"a": 1.0, "b": MedicalVolume(b, aff)}).fit(x, y)[0])
+        check(CurveFitter(monoexponential).fit(x, y, p0=(1.0, b))[0])
+        check(CurveFitter(monoexponential).fit(x, y, p0={"a": 1.0, "b": b})[0])
+        check(CurveFitter(monoexponential).fit(x, y, p0={"a": 1.0, "b": MedicalVolume(b, aff)})[0])
+        p0 = np.stack([MedicalVolume(np.ones(b.shape), aff), MedicalVolume(b, aff)], axis=-1)
+        check(CurveFitter(monoexponential).fit(x, y, p0=p0)[0])
+        mask_arr = RNG.random(y[0].shape) > 0.5
+        check(CurveFitter(monoexponential).fit(
+            x, y, p0={"a": 1.0, "b": MedicalVolume(b, aff)}, mask=MedicalVolume(mask_arr, aff))[0],
+            mask_arr)
+        check(CurveFitter(monoexponential).fit(x, y, p0=(1.0, b), mask=mask_arr)[0], mask_arr)
+        with pytest.raises(ValueError):
+            CurveFitter(monoexponential).fit(x, y, p0=(1.0, b[:5]))
+
+    def test_y_bounds_and_errors(self):
+        x, y, b = gen_monoexp((6, 6, 6))
+        with pytest.warns(UserWarning):
+            popt, r2 = CurveFitter(monoexponential, y_bounds=(0, 20.0), r2_threshold=None).fit(x, y)
+        oob = np.stack([v.volume for v in y]).max(axis=0) > 20.0
+        assert oob.any() and np.all(np.isnan(popt.volume[oob])) and np.all(r2.volume[oob] == 0)
+        assert np.allclose(popt[..., 1].volume[~oob], b[~oob])
+        with pytest.raises(TypeError):
+            CurveFitter(monoexponential).fit(x, [v.A for v in y])
+        with pytest.raises(ValueError):
+            CurveFitter(monoexponential).fit(x[:3], y)
+        with pytest.raises(ValueError):
+            CurveFitter(monoexponential, r2_threshold="bogus")
+        with pytest.raises(NotImplementedError):
+            CurveFitter(lambda t, a: a * t).fit(x, y)
+
+    def test_str(self):
+        s = str(CurveFitter(monoexponential, p0=(1.0, -1 / 30),
+                            out_ufuncs=[None, lambda v: 1 / np.abs(v)], out_bounds=(0, 100),
+                            nan_to_num=0))
+        assert "func=monoexponential" in s and "nan_to_num=0" in s
+
+
+# --------------------------------------------------------------------------- PolyFitter / polyfit
+class TestPolyFitter:
+    def test_polyfit_matches_numpy(self):
+        x = np.asarray([0.5, 1.0, 2.0, 4.0])
+        a = RNG.random(500) + 0.1
+        b = RNG.random(500)
+        y = np.stack([a * t + b for t in x]) + 0.01 * RNG.standard_normal((4, 500))
+        popt, r2 = polyfit(x, y, 1)
+        ref = np.polyfit(x, y, 1).T
+        assert np.allclose(popt, ref, rtol=1e-10, atol=1e-12)
+        yhat = np.stack([ref[:, 0] * t + ref[:, 1] for t in x])
+        r2_ref = 1 - ((yhat - y) ** 2).sum(0) / (((y - y.mean(0)) ** 2).sum(0) + 1e-8)
+        assert np.allclose(r2, r2_ref, atol=1e-10)
+        with pytest.raises(NotImplementedError):
+            polyfit(x, y, 2)
+
+    def test_basic_and_mask(self):
+        x, y, a, b = gen_affine((10, 10, 20))
+        popt, r2 = PolyFitter(deg=1, r2_threshold=None).fit(x, y)
+        assert np.allclose(popt[..., 0].volume, a) and np.allclose(popt[..., 1].volume, b)
+        assert np.all(popt.affine == y[0].affine)
+        mask_arr = RNG.random(y[0].shape) > 0.5
+        popt = PolyFitter(deg=1).fit(x, y, mask=MedicalVolume(mask_arr, y[0].affine))[0]
+        assert np.allclose(popt[..., 0].volume[mask_arr], a[mask_arr])
+        assert np.all(np.isnan(popt[..., 0].volume[~mask_arr]))
+
+    def test_nan_to_num_and_ufuncs(self):
+        shape = (10, 10, 20)
+        a = np.ones(shape)
+        a[5:] = 1.5
+        b = RNG.random(shape) + 0.1
+        b[:5] = 1.5
+        x, y, _, _ = gen_affine(a=a, b=b)
+        popt, _ = PolyFitter(deg=1, out_bounds=(0, 1.2), nan_to_num=0.0).fit(x, y)
+        a_hat, b_hat = popt[..., 0], popt[..., 1]
+        assert np.allclose(a_hat[:5].volume, 1.0) and np.allclose(a_hat[5:].volume, 0.0)
+        assert np.allclose(b_hat[5:].volume, b[5:]) and np.allclose(b_hat[:5].volume, 0.0)
+        x, y, a, b = gen_affine((6, 6, 6, 4), b=None)
+        popt, _ = PolyFitter(deg=1, out_ufuncs=[lambda v: v + 1, lambda v: v + 2]).fit(x, y)
+        assert np.allclose(popt[..., 0].A, a + 1) and np.allclose(popt[..., 1].A, b + 2)
+        assert "deg=2" in str(PolyFitter(deg=2, rcond=0.5, y_bounds=(0, 200), r2_threshold=0.9))

@@ -176,8 +176,8 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
         HIP_TRY(hipEventRecord(ev1, stream));
         HIP_TRY(hipEventSynchronize(ev1));
         HIP_TRY(hipEventElapsedTime(&g_last_ms, ev0, ev1));
-        hipEventDestroy(ev0);
-        hipEventDestroy(ev1);
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
     }
     return QMRI_OK;
 }
@@ -257,18 +257,18 @@ int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
     int status = QMRI_OK;
     auto cleanup = [&] {
         for (int b = 0; b < 2; ++b) {
-            hipFree(buf[b].y);
-            hipFree(buf[b].popt);
-            hipFree(buf[b].r2);
-            hipFree(buf[b].tc);
-            hipFree(buf[b].mask);
-            hipFree(buf[b].a0v);
-            hipFree(buf[b].b0v);
-            hipFree(buf[b].info);
-            hipFree(buf[b].nfev);
-            if (buf[b].stream) hipStreamDestroy(buf[b].stream);
+            (void)hipFree(buf[b].y);
+            (void)hipFree(buf[b].popt);
+            (void)hipFree(buf[b].r2);
+            (void)hipFree(buf[b].tc);
+            (void)hipFree(buf[b].mask);
+            (void)hipFree(buf[b].a0v);
+            (void)hipFree(buf[b].b0v);
+            (void)hipFree(buf[b].info);
+            (void)hipFree(buf[b].nfev);
+            if (buf[b].stream) (void)hipStreamDestroy(buf[b].stream);
         }
-        hipFree(flag);
+        (void)hipFree(flag);
     };
 #define HIP_TRY_C(expr)                                                                          \
     do {                                                                                         \
@@ -429,9 +429,9 @@ int qmri_linfit_host(const qmri_linfit_args *a) {
             if (e == hipSuccess) e = hipMemcpy(a->r2, dr, (size_t)a->N * os, hipMemcpyDeviceToHost);
         }
     }
-    hipFree(dy);
-    hipFree(dp);
-    hipFree(dr);
+    (void)hipFree(dy);
+    (void)hipFree(dp);
+    (void)hipFree(dr);
     if (e != hipSuccess) return fail(QMRI_ERR_HIP, "linfit_host: %s", hipGetErrorString(e));
     return status;
 }

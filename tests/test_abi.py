@@ -1,0 +1,126 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/qmri.h declares; the
+ctypes mirrors of the argument structs have the C compiler's layout.  No compute calls (no GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "qmri.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dosma_amd import build as hip_build
+    from dosma_amd import _lib
+
+    hip_build.build()  # no-op when up to date; hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qmri_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from dosma_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/qmri.h but not exported"
+    assert sorted(_lib.EXPORTS) == names
+    assert lib.qmri_version() == 100
+
+
+def test_struct_layout_matches_the_c_compiler(tmp_path):
+    from dosma_amd import _lib
+
+    prog = tmp_path / "layout.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "qmri.h"\n'
+        "int main(void){\n"
+        '  printf("%zu %zu %zu\\n", sizeof(qmri_post), sizeof(qmri_monoexp_args), sizeof(qmri_linfit_args));\n'
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(qmri_monoexp_args, x), offsetof(qmri_monoexp_args, a0),\n'
+        "         offsetof(qmri_monoexp_args, post), offsetof(qmri_monoexp_args, popt),\n"
+        "         offsetof(qmri_monoexp_args, info), offsetof(qmri_monoexp_args, stream));\n"
+        '  printf("%zu %zu %zu\\n", offsetof(qmri_linfit_args, x), offsetof(qmri_linfit_args, popt),\n'
+        "         offsetof(qmri_linfit_args, stream));\n"
+        "  return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = list(map(int, out))
+    A, P, Lf = _lib.QmriMonoexpArgs, _lib.QmriPost, _lib.QmriLinfitArgs
+    want = [ctypes.sizeof(P), ctypes.sizeof(A), ctypes.sizeof(Lf),
+            A.x.offset, A.a0.offset, A.post.offset, A.popt.offset, A.info.offset, A.stream.offset,
+            Lf.x.offset, Lf.popt.offset, Lf.stream.offset]
+    assert got == want
+
+
+def test_defaults_are_the_reference_constants(lib):
+    """dosma/core/fitting.py:761-763 (maxfev=100, ftol=1e-5, eps=1e-8) + scipy leastsq defaults."""
+    from dosma_amd import _lib
+
+    a = _lib.default_args()
+    assert (a.ftol, a.xtol, a.gtol, a.factor, a.r2_eps, a.maxfev) == (1e-5, 1.49012e-8, 0.0, 100.0, 1e-8, 100)
+    assert (a.a0, a.b0) == (1.0, 1.0) and a.post.enable == 0 and a.out_dtype == _lib.QMRI_F64
+
+
+def test_argument_validation_without_a_gpu(lib):
+    """Validation happens before any HIP call, so error codes can be checked on a CPU-only box."""
+    import numpy as np
+
+    from dosma_amd import _lib
+
+    a = _lib.default_args()
+    assert lib.qmri_monoexp_fit_device(ctypes.byref(a), None) == _lib.QMRI_ERR_ARG  # NULL buffers
+    x = np.arange(1, 41, dtype=np.float64)
+    buf = np.zeros(64)
+    a.y = a.popt = a.r2 = buf.ctypes.data
+    a.x = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    a.N, a.ld = 4, 4
+    a.E = 1
+    assert lib.qmri_monoexp_fit_device(ctypes.byref(a), None) == _lib.QMRI_ERR_ARG
+    assert b"at least as many samples" in lib.qmri_last_error()
+    a.E = 40
+    assert lib.qmri_monoexp_fit_device(ctypes.byref(a), None) == _lib.QMRI_ERR_UNSUPPORTED
+    a.E = 4
+    a.y_dtype = 9
+    assert lib.qmri_monoexp_fit_device(ctypes.byref(a), None) == _lib.QMRI_ERR_ARG
+    a.y_dtype = _lib.QMRI_F32
+    a.maxfev = 0
+    assert lib.qmri_monoexp_fit_device(ctypes.byref(a), None) == _lib.QMRI_ERR_ARG
+    assert lib.qmri_monoexp_kernel_name(ctypes.byref(a)) == b"monoexp_lm<4,full,f32>"
+
+
+def test_no_cpu_fallback(lib):
+    """On a box without a GPU the product path must fail loudly, not compute on the CPU."""
+    import numpy as np
+
+    from dosma_amd import _lib, curve_fit, monoexponential
+
+    if lib.qmri_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.QmriError):
+        curve_fit(monoexponential, np.arange(1.0, 5.0), np.ones((4, 3)))
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "dosma_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "import scipy" not in text and "from scipy" not in text, f
+    code = ("import sys; sys.path.insert(0, %r); import dosma_amd; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules); "
+            "assert 'scipy.optimize' not in sys.modules" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])

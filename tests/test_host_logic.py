@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: MedicalVolume / orientation shims, p0 formatting, model
+recognition, argument errors -- and, when the reference is importable (build container), the shims
+are compared with the reference's own classes."""
+import numpy as np
+import pytest
+
+from dosma_amd import CurveFitter, MedicalVolume, MonoExponentialFit, monoexponential
+from dosma_amd import fitting as F
+from dosma_amd import orientation as stdo
+from oracle import ref_harness
+
+ORIENTS = [("LR", "PA", "IS"), ("SI", "AP", "LR"), ("AP", "LR", "SI"), ("RL", "IS", "PA"),
+           ("IS", "RL", "AP"), ("PA", "SI", "RL")]
+
+
+def test_orientation_roundtrip():
+    rng = np.random.default_rng(0)
+    vol = rng.random((3, 4, 5, 2))
+    aff = np.diag([0.5, 0.7, 2.0, 1.0])
+    aff[:3, 3] = [10.0, -20.0, 30.0]
+    mv = MedicalVolume(vol, aff)
+    assert mv.orientation == ("LR", "PA", "IS")
+    assert np.allclose(mv.pixel_spacing, (0.5, 0.7, 2.0))
+    for o in ORIENTS:
+        r = mv.reformat(o)
+        assert r.orientation == o
+        assert np.allclose(sorted(r.pixel_spacing), [0.5, 0.7, 2.0])
+        back = r.reformat(mv.orientation)
+        assert np.array_equal(back.volume, vol) and np.allclose(back.affine, aff)
+        # a voxel keeps its world position: index (1,2,3) of mv
+        idx = np.array([1, 2, 3, 1.0])
+        world = aff @ idx
+        perm = stdo.get_transpose_inds(mv.orientation, o)
+        j = [idx[p] for p in perm]
+        for ax in range(3):
+            if o[ax] != tuple(mv.orientation[p] for p in perm)[ax]:
+                j[ax] = r.shape[ax] - 1 - j[ax]
+        assert np.allclose(r.affine @ np.array(j + [1.0]), world)
+        assert r.volume[int(j[0]), int(j[1]), int(j[2]), 0] == vol[1, 2, 3, 0]
+    with pytest.raises(ValueError):
+        mv.reformat(("LR", "RL", "IS"))
+    assert stdo.orientation_from_affine(stdo.to_affine(("SI", "AP", "LR"), (1, 2, 3))) == ("SI", "AP", "LR")
+
+
+def test_medical_volume_numpy_protocol_and_slicing():
+    mv = MedicalVolume(np.arange(24.0).reshape(2, 3, 4), np.eye(4))
+    assert isinstance(mv + 1, MedicalVolume) and np.array_equal((mv + 1).volume, mv.volume + 1)
+    assert (mv > 3).dtype == bool and np.exp(mv).shape == mv.shape
+    assert np.around(mv / 7, 2).volume[1, 1, 1] == np.around(mv.volume / 7, 2)[1, 1, 1]
+    s = mv[:, 1:3, ::2]
+    assert s.shape == (2, 2, 2) and np.allclose(s.affine[:3, 3], [0, 1, 0]) and s.affine[2, 2] == 2
+    with pytest.raises(IndexError):
+        mv[0]
+    with pytest.raises(ValueError):
+        mv + MedicalVolume(np.zeros((2, 3, 4)), np.diag([2.0, 1, 1, 1]))
+    p = MedicalVolume(np.zeros((2, 3, 4, 2)), np.eye(4), headers=np.empty((1, 1, 4, 1), dtype=object))
+    assert p[..., 1].shape == (2, 3, 4) and p[..., 1].headers().shape == (1, 1, 4)
+    st = np.stack([mv, mv * 2], axis=-1)
+    assert st.shape == (2, 3, 4, 2)
+    assert mv.is_identical(mv.clone()) and mv.is_same_dimensions(mv[...])
+    with pytest.raises(ValueError):
+        MedicalVolume(np.zeros((2, 2, 2)), np.eye(4), headers=np.empty((3, 1, 1), dtype=object))
+
+
+def test_format_p0_semantics():
+    """reference _format_p0 (fitting.py:1106-1161)."""
+    names = ["a", "b"]
+    assert F._format_p0(None, names, 5) == [1.0, 1.0]
+    assert F._format_p0(2.0, names, 5) == [2.0, 2.0]
+    assert F._format_p0((None, 3), names, 5) == [1.0, 3.0]
+    assert F._format_p0({"b": 50.0}, names, 5) == [1.0, 50.0]
+    out = F._format_p0([np.ones(5), 50], names, 5)
+    assert isinstance(out[0], np.ndarray) and out[1] == 50.0
+    out = F._format_p0(np.ones((5, 2)), names, 5)
+    assert all(isinstance(v, np.ndarray) and v.shape == (5,) for v in out)
+    with pytest.raises(ValueError):
+        F._format_p0((1, 2, 3), names, 5)
+    with pytest.raises(ValueError):
+        F._format_p0({"c": 1}, names, 5)
+    with pytest.raises(ValueError):
+        F._format_p0([np.ones(4), 1], names, 5)
+
+
+def test_model_recognition():
+    assert F._model_of(monoexponential) == "monoexponential"
+    assert F._model_of(lambda x, a, b: a * np.exp(b * x)) == "monoexponential"
+    assert F._model_of(lambda t, s0, r: s0 * np.exp(t * r)) == "monoexponential"
+    for bad in (lambda x, a, b: a * np.exp(-b * x), lambda x, a: a * x, F.biexponential,
+                lambda x, a, b: a + b * x):
+        with pytest.raises(NotImplementedError):
+            F._model_of(bad)
+
+
+def test_constructor_validation_matches_reference():
+    with pytest.raises(ValueError):
+        MonoExponentialFit(tc0="a value")
+    with pytest.raises(ValueError):
+        MonoExponentialFit(bounds=(0, 1, 2))
+    with pytest.raises(ValueError):
+        CurveFitter(monoexponential, out_bounds=[(0, 0.5, 1.0)])
+    with pytest.raises(ValueError):
+        CurveFitter(monoexponential, out_bounds=[(1.2, 0)])
+    with pytest.raises(TypeError):
+        CurveFitter(monoexponential, out_ufuncs=[None, 5])
+    with pytest.raises(ValueError):
+        CurveFitter(monoexponential, r2_threshold="nope")
+    assert CurveFitter(monoexponential).r2_threshold == 0.9  # "preferences" -> fitting/r2.threshold
+    f = CurveFitter(monoexponential, out_ufuncs=(None, F._inv_abs), out_bounds=((-np.inf, np.inf), (0, 100)),
+                    nan_to_num=0.0)
+    post = f._fusable_post()
+    assert post["inv_abs_b"] and post["bounds"] == ((-np.inf, np.inf), (0.0, 100.0))
+    assert CurveFitter(monoexponential, out_ufuncs=lambda v: v)._fusable_post() is None
+    y = [MedicalVolume(np.ones((2, 2, 2)), np.eye(4)) for _ in range(4)]
+    with pytest.raises(TypeError):
+        MonoExponentialFit().fit([1, 2, 3, 4], [v.A for v in y])
+    with pytest.raises(ValueError):
+        MonoExponentialFit().fit([1, 2, 3], y)
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference absent (GPU box)")
+def test_medical_volume_shim_vs_reference():
+    dosma = ref_harness.load_reference()
+    rng = np.random.default_rng(3)
+    vol = rng.random((3, 4, 5))
+    aff = np.array([[0, 0, 0.8, 5.0], [-0.6, 0, 0, 7.0], [0, -1.5, 0, -3.0], [0, 0, 0, 1.0]])
+    ours, ref = MedicalVolume(vol, aff), dosma.MedicalVolume(vol, aff)
+    assert ours.orientation == ref.orientation
+    for o in ORIENTS:
+        a, b = ours.reformat(o), ref.reformat(o)
+        assert a.orientation == b.orientation == o
+        assert np.array_equal(a.volume, b.volume) and np.allclose(a.affine, b.affine)
+    a, b = ours[1:, ::2, 1:4], ref[1:, ::2, 1:4]
+    assert np.array_equal(a.volume, b.volume) and np.allclose(a.affine, b.affine)

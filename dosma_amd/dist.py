@@ -1,0 +1,137 @@
+"""Multi-GPU driver: batches of volumes sharded on the batch axis, one process per GPU.
+
+The reference has no multi-GPU or distributed path at all (grep for nccl / mpi /
+torch.distributed -> 0 hits; its only parallelism is ``multiprocessing.Pool`` over voxels,
+dosma/core/fitting.py:860-868).  The path shards embarrassingly: voxels, slices and
+volumes are independent, so volume ``v`` of a batch goes to rank ``v mod world`` and NO collective sits
+on the data path.  RCCL (``torch.distributed`` backend "nccl" on ROCm) / gloo is used only for
+(a) the barrier + max-reduction that brackets timing, (b) an all-gather of a few per-rank scalars
+(voxel counts, elapsed time, per-volume summary statistics), (c) optionally a one-time broadcast of
+model weights.  Launch with ``python -m torch.distributed.run --nproc-per-node N ...``.
+"""
+import os
+from typing import Callable, Dict, List, Sequence
+
+import numpy as np
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str = None):
+    """Initialise the process group (no-op for a single process).  Returns (rank, local_rank, world).
+
+    backend: "nccl" (= RCCL over xGMI on ROCm) when a GPU is visible, else "gloo".
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def partition(n_items: int, world: int, rank: int) -> List[int]:
+    """Indices of the batch items owned by ``rank``: item v -> rank v mod world."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    return list(range(rank, n_items, world))
+
+
+def _device_for_collectives():
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_max(value: float) -> float:
+    """Max over ranks (used for the elapsed time of a timed region)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_device_for_collectives())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allgather_scalars(values: Sequence[float]) -> np.ndarray:
+    """All-gather a short, fixed-length vector of float64 per rank -> array (world, len(values))."""
+    import torch
+    import torch.distributed as dist
+
+    v = np.asarray(values, dtype=np.float64).reshape(-1)
+    if not dist.is_initialized():
+        return v[None, :].copy()
+    dev = _device_for_collectives()
+    mine = torch.tensor(v, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return np.stack([o.cpu().numpy() for o in out], axis=0)
+
+
+def sharded_map(n_items: int, fn: Callable[[int], Dict[str, float]]):
+    """Run ``fn(v)`` for every batch item this rank owns; gather every item's scalar summary everywhere.
+
+    ``fn`` does the per-volume work on this rank's GPU (e.g. ``MonoExponentialFit.fit`` + ``generate_mask``)
+    and returns a dict of scalars (same keys for every item), e.g. voxel counts and mean tc.
+    Returns (local: {v: fn(v)}, summary: {key: ndarray[n_items]}) -- the summary is identical on all ranks.
+    """
+    rank, _, world = env_world()
+    mine = partition(n_items, world, rank)
+    local = {v: fn(v) for v in mine}
+    keys = sorted(next(iter(local.values())).keys()) if local else []
+    # every rank must contribute the same vector length: pad to the max items per rank
+    per_rank = (n_items + world - 1) // world
+    nk = int(allreduce_max(float(len(keys))))
+    if not keys:
+        keys = [f"_{i}" for i in range(nk)]
+    buf = np.full((per_rank, 1 + nk), np.nan)
+    for slot, v in enumerate(mine):
+        buf[slot, 0] = v
+        buf[slot, 1:] = [local[v][k] for k in keys]
+    gathered = allgather_scalars(buf.reshape(-1)).reshape(world, per_rank, 1 + nk)
+    summary = {k: np.full(n_items, np.nan) for k in keys}
+    for r in range(world):
+        for slot in range(per_rank):
+            idx = gathered[r, slot, 0]
+            if not np.isnan(idx):
+                for j, k in enumerate(keys):
+                    summary[k][int(idx)] = gathered[r, slot, 1 + j]
+    return local, summary
+
+
+def broadcast_array(arr: np.ndarray, src: int = 0) -> np.ndarray:
+    """One-time broadcast of a (weights) array from ``src`` to every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return arr
+    dev = _device_for_collectives()
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()

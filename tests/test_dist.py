@@ -1,0 +1,88 @@
+"""The N > 1 path on CPU: two gloo processes (world_size 2), 127.0.0.1 rendezvous.
+
+The per-volume work is stubbed with the oracle (there is no GPU here); what is under test is the
+sharding (volume v -> rank v mod world), the scalar all-gather, the max-reduction of the timing, the
+weight broadcast -- i.e. everything bench.py / a multi-GPU driver relies on besides the kernels."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+from dosma_amd import dist as qd
+from oracle import fit_oracle as fo
+
+rank, local_rank, world = qd.init("gloo")
+assert world == 2
+n_vol = 5
+x = np.arange(1, 5) * 10.0
+
+def work(v):
+    rng = np.random.default_rng(100 + v)
+    y = rng.uniform(300, 1500, 64) * np.exp(-x[:, None] / rng.uniform(15, 80, 64))
+    tc, r2, _ = fo.monoexp_fit_arrays(x, y, decimal_precision=3)
+    return {"voxels": float(y.shape[1]), "mean_tc": float(tc.mean()), "rank": float(rank)}
+
+local, summary = qd.sharded_map(n_vol, work)
+assert sorted(local) == qd.partition(n_vol, world, rank)
+tmax = qd.allreduce_max(1.0 + rank)
+w = qd.broadcast_array(np.arange(6.0) * (1 if rank == 0 else -1))
+g = qd.allgather_scalars([rank, 10 * rank])
+qd.barrier()
+print("RESULT " + json.dumps({"rank": rank, "owned": sorted(local), "tmax": tmax, "w": w.tolist(),
+                              "g": g.tolist(), "summary": {k: v.tolist() for k, v in summary.items()}}))
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(out)
+    import json
+
+    res = [json.loads(next(l for l in o.splitlines() if l.startswith("RESULT "))[7:]) for o in outs]
+    res.sort(key=lambda r: r["rank"])
+    assert res[0]["owned"] == [0, 2, 4] and res[1]["owned"] == [1, 3]
+    assert res[0]["tmax"] == res[1]["tmax"] == 2.0
+    assert res[0]["w"] == res[1]["w"] == list(np.arange(6.0))
+    assert res[0]["g"] == res[1]["g"] == [[0.0, 0.0], [1.0, 10.0]]
+    # the gathered summary is complete and identical on both ranks
+    assert res[0]["summary"] == res[1]["summary"]
+    assert res[0]["summary"]["rank"] == [0.0, 1.0, 0.0, 1.0, 0.0]
+    assert res[0]["summary"]["voxels"] == [64.0] * 5
+    assert all(15 < t < 80 for t in res[0]["summary"]["mean_tc"])
+
+
+def test_partition_covers_everything_once():
+    from dosma_amd.dist import partition
+
+    for n in (0, 1, 7, 64):
+        for world in (1, 2, 3, 8):
+            seen = sorted(i for r in range(world) for i in partition(n, world, r))
+            assert seen == list(range(n))

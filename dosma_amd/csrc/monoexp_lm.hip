@@ -56,48 +56,98 @@ __device__ __forceinline__ double norm2(double a, double b) {
     return m * sqrt(ra * ra + rb * rb);
 }
 
-// Givens rotation of MINPACK qrsolv
-__device__ __forceinline__ void givens(double rkk, double sdk, double &c, double &s) {
-    if (fabs(rkk) < fabs(sdk)) {
-        const double cotan = rkk / sdk;
-        s = 0.5 / sqrt(0.25 + 0.25 * cotan * cotan);
-        c = s * cotan;
+// ---- fp64 reciprocal / square root without the IEEE division expansion ------------------------------
+// An fp64 `a / b` compiles to ~11 VALU instructions (v_div_scale x2, v_rcp, 5 fma, v_div_fmas,
+// v_div_fixup) and sqrt() to ~12; one LM iteration of the straightforward restatement spends ~50 of
+// them.  The solver state is bounded away from the exponent range limits, so the scale / fixup steps
+// are only needed on a guarded slow path.  Results are within 1-2 ulp of IEEE (parity is 1e-4, not bitwise).
+__device__ __forceinline__ double frcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    // 0, inf, NaN and (sub)normal extremes: IEEE division
+    const double ab = fabs(b);
+    return (ab > 1e-290 && ab < 1e290) ? r : 1.0 / b;
+}
+
+// s = sqrt(x), rs = 1/sqrt(x) by Goldschmidt iteration from v_rsq_f64 (9 instructions for both)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
+    if (x > 1e-290 && x < 1e290) {
+        const double r = __builtin_amdgcn_rsq(x);
+        double g = x * r;
+        double h = 0.5 * r;
+        double e = fma(-h, g, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        e = fma(-h, g, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        s = g;
+        rs = h + h;
     } else {
-        const double tn = sdk / rkk;
-        c = 0.5 / sqrt(0.25 + 0.25 * tn * tn);
-        s = c * tn;
+        s = sqrt(x);
+        rs = 1.0 / s;
     }
+}
+
+// ||(a, b)|| and its reciprocal; overflow-safe like MINPACK's enorm on the slow path
+__device__ __forceinline__ void norm2r(double a, double b, double &n, double &rn) {
+    const double q = a * a + b * b;
+    if (q > 1e-280 && q < 1e280) {
+        sqrt_rsqrt(q, n, rn);
+    } else {
+        n = norm2(a, b);
+        rn = 1.0 / n;
+    }
+}
+
+// Givens rotation of MINPACK qrsolv that annihilates sdk against rkk: (c, s) = (rkk, sdk) / h,
+// h = hypot(rkk, sdk).  MINPACK's two-branch tangent/cotangent form differs only by a common sign of
+// (c, s), which cancels in the solution; returns h (the new diagonal) and 1/h.
+__device__ __forceinline__ void givens(double rkk, double sdk, double &c, double &s, double &h,
+                                       double &rh) {
+    norm2r(rkk, sdk, h, rh);
+    c = rkk * rh;
+    s = sdk * rh;
 }
 
 // qrsolv for n = 2.  R = [r11 r12; 0 r22] (pivoted columns l0, l1), dg = sqrt(par)*diag by ORIGINAL
 // parameter index, qtb = Q^T f.  Returns x by original index and the triangular factor S
-// (sd0, sd1 diagonal, s10 off-diagonal) that lmpar's Newton correction needs.
-__device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, int l0, double dg0,
-                                        double dg1, double qtb0, double qtb1, double &x0, double &x1,
-                                        double &sd0, double &sd1, double &s10) {
+// (reciprocal diagonal rsd0, rsd1 and off-diagonal s10) that lmpar's Newton correction needs.
+__device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, double ir11, double ir22,
+                                        int l0, double dg0, double dg1, double qtb0, double qtb1,
+                                        double &x0, double &x1, double &rsd0, double &rsd1,
+                                        double &s10) {
     const double dl0 = l0 ? dg1 : dg0;
     const double dl1 = l0 ? dg0 : dg1;
-    double rr00 = r11, rr11 = r22, wa0 = qtb0, wa1 = qtb1;
+    double rr11 = r22, wa0 = qtb0, wa1 = qtb1;
+    double sd0 = r11, sd1;
+    rsd0 = ir11;
+    rsd1 = ir22;
     s10 = r12;
     if (dl0 != 0.0) {
-        double c, s;
-        givens(rr00, dl0, c, s);
-        rr00 = c * rr00 + s * dl0;
-        double qtbpj = -s * wa0;
+        double c, s, h, rh;
+        givens(r11, dl0, c, s, h, rh);
+        sd0 = h;
+        rsd0 = rh;
+        const double qtbpj = -s * wa0;
         wa0 = c * wa0;
         const double sdi = -s * s10;
         s10 = c * s10;
         if (sdi != 0.0) {
-            givens(rr11, sdi, c, s);
-            rr11 = c * rr11 + s * sdi;
+            givens(rr11, sdi, c, s, h, rh);
+            rr11 = h;
+            rsd1 = rh;
             wa1 = c * wa1 + s * qtbpj;
         }
     }
-    sd0 = rr00;
     if (dl1 != 0.0) {
-        double c, s;
-        givens(rr11, dl1, c, s);
-        rr11 = c * rr11 + s * dl1;
+        double c, s, h, rh;
+        givens(rr11, dl1, c, s, h, rh);
+        rr11 = h;
+        rsd1 = rh;
         wa1 = c * wa1;
     }
     sd1 = rr11;
@@ -106,22 +156,27 @@ __device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, int 
         wa1 = 0.0;
     } else if (sd1 == 0.0) {
         wa1 = 0.0;
-        wa0 = wa0 / sd0;
+        wa0 = wa0 * rsd0;
     } else {
-        wa1 = wa1 / sd1;
-        wa0 = (wa0 - s10 * wa1) / sd0;
+        wa1 = wa1 * rsd1;
+        wa0 = (wa0 - s10 * wa1) * rsd0;
     }
     x0 = l0 ? wa1 : wa0;
     x1 = l0 ? wa0 : wa1;
 }
 
 // MINPACK lmpar for n = 2: step p (by original index) with ||diag*p|| ~ delta, and the LM parameter.
-__device__ __forceinline__ void lmpar2(double r11, double r12, double r22, int l0, double dg0,
-                                       double dg1, double qtb0, double qtb1, double delta,
-                                       double &par, double &x0, double &x1) {
+// ir11, ir22 = 1/r11, 1/r22 and idg0, idg1 = 1/diag are maintained by the caller (they change only at
+// a QR).  ((fp/delta)/temp)/temp is evaluated as fp / (delta * temp^2): no square root of temp^2.
+__device__ __forceinline__ void lmpar2(double r11, double r12, double r22, double ir11, double ir22,
+                                       int l0, double dg0, double dg1, double idg0, double idg1,
+                                       double qtb0, double qtb1, double delta, double &par, double &x0,
+                                       double &x1) {
     const double dwarf = DBL_MIN;
     const double dl0 = l0 ? dg1 : dg0;  // diag(ipvt(0))
     const double dl1 = l0 ? dg0 : dg1;  // diag(ipvt(1))
+    const double idl0 = l0 ? idg1 : idg0;
+    const double idl1 = l0 ? idg0 : idg1;
     // Gauss-Newton direction
     double w0 = qtb0, w1 = qtb1;
     int nsing = 2;
@@ -132,15 +187,16 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, int l
     } else if (r22 == 0.0) {
         nsing = 1;
         w1 = 0.0;
-        w0 = w0 / r11;
+        w0 = w0 * ir11;
     } else {
-        w1 = w1 / r22;
-        w0 = (w0 - r12 * w1) / r11;
+        w1 = w1 * ir22;
+        w0 = (w0 - r12 * w1) * ir11;
     }
     x0 = l0 ? w1 : w0;
     x1 = l0 ? w0 : w1;
     double wa20 = dg0 * x0, wa21 = dg1 * x1;
-    double dxnorm = norm2(wa20, wa21);
+    double dxnorm, idx;
+    norm2r(wa20, wa21, dxnorm, idx);
     double fp = dxnorm - delta;
     if (fp <= 0.1 * delta) {
         par = 0.0;
@@ -148,39 +204,37 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, int l
     }
     double parl = 0.0;
     if (nsing >= 2) {
-        double t0 = dl0 * ((l0 ? wa21 : wa20) / dxnorm);
-        double t1 = dl1 * ((l0 ? wa20 : wa21) / dxnorm);
-        t0 = t0 / r11;
-        t1 = (t1 - r12 * t0) / r22;
-        const double temp = norm2(t0, t1);
-        parl = ((fp / delta) / temp) / temp;
+        double t0 = dl0 * ((l0 ? wa21 : wa20) * idx);
+        double t1 = dl1 * ((l0 ? wa20 : wa21) * idx);
+        t0 = t0 * ir11;
+        t1 = (t1 - r12 * t0) * ir22;
+        parl = fp * frcp(delta * (t0 * t0 + t1 * t1));
     }
-    const double g0 = (r11 * qtb0) / dl0;
-    const double g1 = (r12 * qtb0 + r22 * qtb1) / dl1;
+    const double g0 = (r11 * qtb0) * idl0;
+    const double g1 = (r12 * qtb0 + r22 * qtb1) * idl1;
     const double gnorm = norm2(g0, g1);
-    double paru = gnorm / delta;
+    double paru = gnorm * frcp(delta);
     if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
     par = fmax(par, parl);
     par = fmin(par, paru);
-    if (par == 0.0) par = gnorm / dxnorm;
+    if (par == 0.0) par = gnorm * idx;
     for (int iter = 1;; ++iter) {
         if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
         const double sp = sqrt(par);
-        double sd0, sd1, s10;
-        qrsolv2(r11, r12, r22, l0, sp * dg0, sp * dg1, qtb0, qtb1, x0, x1, sd0, sd1, s10);
+        double rsd0, rsd1, s10;
+        qrsolv2(r11, r12, r22, ir11, ir22, l0, sp * dg0, sp * dg1, qtb0, qtb1, x0, x1, rsd0, rsd1, s10);
         wa20 = dg0 * x0;
         wa21 = dg1 * x1;
-        dxnorm = norm2(wa20, wa21);
+        norm2r(wa20, wa21, dxnorm, idx);
         const double fp_old = fp;
         fp = dxnorm - delta;
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || iter == 10)
             break;
-        double t0 = dl0 * ((l0 ? wa21 : wa20) / dxnorm);
-        double t1 = dl1 * ((l0 ? wa20 : wa21) / dxnorm);
-        t0 = t0 / sd0;
-        t1 = (t1 - s10 * t0) / sd1;
-        const double temp = norm2(t0, t1);
-        const double parc = ((fp / delta) / temp) / temp;
+        double t0 = dl0 * ((l0 ? wa21 : wa20) * idx);
+        double t1 = dl1 * ((l0 ? wa20 : wa21) * idx);
+        t0 = t0 * rsd0;
+        t1 = (t1 - s10 * t0) * rsd1;
+        const double parc = fp * frcp(delta * (t0 * t0 + t1 * t1));
         if (fp > 0.0) parl = fmax(parl, par);
         if (fp < 0.0) paru = fmin(paru, par);
         par = fmax(parl, par + parc);
@@ -295,6 +349,9 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
     double fnorm = 0, par = 0, delta = 0, xnorm = 0, gnorm = 0;
     double dg0 = 1, dg1 = 1;                  // diag (by parameter)
     double r11 = 0, r12 = 0, r22 = 0;         // R of the pivoted QR
+    double ir11 = 0, ir22 = 0;                // 1/r11, 1/r22
+    double idg0 = 1, idg1 = 1;                // 1/diag
+    double rfn = 0;                           // 1/fnorm
     double qtf0 = 0, qtf1 = 0;                // first two components of Q^T fvec
     double sstot = 0;
     int l0 = 0;                               // ipvt(0): 0 = columns in order, 1 = swapped
@@ -456,7 +513,8 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
             double p0 = 0, p1 = 0;   // step (by parameter)
             double pnorm = 0;
             if (state == ST_ITER) {
-                lmpar2(r11, r12, r22, l0, dg0, dg1, qtf0, qtf1, delta, par, p0, p1);
+                lmpar2(r11, r12, r22, ir11, ir22, l0, dg0, dg1, idg0, idg1, qtf0, qtf1, delta, par,
+                       p0, p1);
                 p0 = -p0;
                 p1 = -p1;
                 ta = pa + p0;
@@ -511,21 +569,22 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
             if (state == ST_ITER) {
                 double actred = -1.0;
                 if (0.1 * fnorm1 < fnorm) {
-                    const double t = fnorm1 / fnorm;
+                    const double t = fnorm1 * rfn;
                     actred = 1.0 - t * t;
                 }
-                // R * P^T p
+                // R * P^T p;  prered = (||R P^T p|| / fnorm)^2 + 2 (sqrt(par) pnorm / fnorm)^2
                 const double pl0 = l0 ? p1 : p0, pl1 = l0 ? p0 : p1;
                 const double w0 = r11 * pl0 + r12 * pl1, w1 = r22 * pl1;
-                const double temp1 = norm2(w0, w1) / fnorm;
-                const double temp2 = (sqrt(par) * pnorm) / fnorm;
-                const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-                const double dirder = -(temp1 * temp1 + temp2 * temp2);
+                const double t1sq = (w0 * w0 + w1 * w1) * rfn * rfn;
+                const double pr = pnorm * rfn;
+                const double t2sq = par * pr * pr;
+                const double prered = t1sq + t2sq / 0.5;
+                const double dirder = -(t1sq + t2sq);
                 double ratio = 0.0;
-                if (prered != 0.0) ratio = actred / prered;
+                if (prered != 0.0) ratio = actred * frcp(prered);
                 if (ratio <= 0.25) {
                     double temp = 0.5;
-                    if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                    if (actred < 0.0) temp = 0.5 * dirder * frcp(dirder + 0.5 * actred);
                     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
                     delta = temp * fmin(delta, pnorm / 0.1);
                     par = par / temp;
@@ -533,16 +592,13 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                     delta = pnorm / 0.5;
                     par = 0.5 * par;
                 }
-#ifdef QMRI_TRACE
-                printf("it nfev=%d trial=(%.17g,%.17g) p=(%.6g,%.6g) par=%.6g delta=%.6g fnorm=%.17g fnorm1=%.17g actred=%.6g prered=%.6g ratio=%.6g\n",
-                       nfev, ta, tb, p0, p1, par, delta, fnorm, fnorm1, actred, prered, ratio);
-#endif
                 accepted = ratio >= 1e-4;
                 if (accepted) {
                     pa = ta;
                     pb = tb;
                     xnorm = norm2(dg0 * pa, dg1 * pb);
                     fnorm = fnorm1;
+                    rfn = frcp(fnorm);
                     first = false;
                 }
                 const bool small = fabs(actred) <= A.ftol && prered <= A.ftol && 0.5 * ratio <= 1.0;
@@ -557,6 +613,7 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
             } else {
                 accepted = true;
                 fnorm = fnorm1;
+                rfn = frcp(fnorm);
                 par = 0.0;
                 first = true;
             }
@@ -578,7 +635,7 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                     if (ha == 0.0) ha = eps;
                     if (hb == 0.0) hb = eps;
                     const double a1 = pa + ha, b1 = pb + hb;
-                    const double rha = 1.0 / ha, rhb = 1.0 / hb;
+                    const double rha = frcp(ha), rhb = frcp(hb);
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
                         if (FULL || i < E) {
@@ -592,8 +649,10 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                             n2 += c2[i] * c2[i];
                         }
                 }
-                // (E-vector norms: exps of finite args squared can only overflow to inf, never NaN)
-                const double acn0 = sqrt(n1), acn1 = sqrt(n2);
+                // (E-vector norms: sums of squares of finite values can only overflow to inf, never NaN)
+                double acn0, acn1, iacn0, iacn1;
+                sqrt_rsqrt(n1, acn0, iacn0);
+                sqrt_rsqrt(n2, acn1, iacn1);
                 l0 = acn1 > acn0 ? 1 : 0;
                 // P = pivot column, Q = the other one (in place: ev <- P, c2 <- Q)
                 if (l0) {
@@ -606,19 +665,24 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                         }
                 }
                 double ajn = l0 ? acn1 : acn0;
+                double iajn = l0 ? iacn1 : iacn0;
                 if (ajn != 0.0) {
-                    if (ev[0] < 0.0) ajn = -ajn;
+                    if (ev[0] < 0.0) {
+                        ajn = -ajn;
+                        iajn = -iajn;
+                    }
                     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
                         if (FULL || i < E) {
-                            ev[i] = ev[i] / ajn;
+                            ev[i] = ev[i] * iajn;
                             if (i == 0) ev[0] += 1.0;
                             s1 += ev[i] * c2[i];
                             s2 += ev[i] * fv[i];
                         }
-                    const double t1 = s1 / ev[0];
-                    const double t2 = -s2 / ev[0];
+                    const double iv0 = frcp(ev[0]);  // ev[0] in [1, 2]
+                    const double t1 = s1 * iv0;
+                    const double t2 = -s2 * iv0;
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
                         if (FULL || i < E) {
@@ -627,20 +691,25 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                         }
                 }
                 r11 = -ajn;
+                ir11 = -iajn;
                 r12 = c2[0];
                 qtf0 = fv[0];
                 double m2 = 0.0;
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
                     if (FULL || i < E) m2 += c2[i] * c2[i];
-                double ajn2 = sqrt(m2);
+                double ajn2, iajn2;
+                sqrt_rsqrt(m2, ajn2, iajn2);
                 if (ajn2 != 0.0) {
-                    if (c2[1] < 0.0) ajn2 = -ajn2;
+                    if (c2[1] < 0.0) {
+                        ajn2 = -ajn2;
+                        iajn2 = -iajn2;
+                    }
                     double s = 0.0;
 #pragma unroll
                     for (int i = 1; i < EMAX; ++i)
                         if (FULL || i < E) {
-                            c2[i] = c2[i] / ajn2;
+                            c2[i] = c2[i] * iajn2;
                             if (i == 1) c2[1] += 1.0;
                             s += c2[i] * fv[i];
                         }
@@ -649,10 +718,13 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                     fv[1] -= s;
                 }
                 r22 = -ajn2;
+                ir22 = -iajn2;
                 qtf1 = fv[1];
                 if (state == ST_INIT) {
                     dg0 = acn0 == 0.0 ? 1.0 : acn0;
                     dg1 = acn1 == 0.0 ? 1.0 : acn1;
+                    idg0 = acn0 == 0.0 ? 1.0 : iacn0;
+                    idg1 = acn1 == 0.0 ? 1.0 : iacn1;
                     xnorm = norm2(dg0 * pa, dg1 * pb);
                     delta = A.factor * xnorm;
                     if (delta == 0.0) delta = A.factor;
@@ -661,18 +733,24 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
                 gnorm = 0.0;
                 if (fnorm != 0.0) {
                     const double al0 = l0 ? acn1 : acn0, al1 = l0 ? acn0 : acn1;
-                    if (al0 != 0.0) gnorm = fabs((r11 * (qtf0 / fnorm)) / al0);
-                    if (al1 != 0.0)
-                        gnorm = fmax(gnorm,
-                                     fabs((r12 * (qtf0 / fnorm) + r22 * (qtf1 / fnorm)) / al1));
+                    const double ial0 = l0 ? iacn1 : iacn0, ial1 = l0 ? iacn0 : iacn1;
+                    const double q0 = qtf0 * rfn, q1 = qtf1 * rfn;
+                    if (al0 != 0.0) gnorm = fabs((r11 * q0) * ial0);
+                    if (al1 != 0.0) gnorm = fmax(gnorm, fabs((r12 * q0 + r22 * q1) * ial1));
                 }
 #ifdef QMRI_TRACE
                 printf("qr x=(%.17g,%.17g) acn=(%.17g,%.17g) l0=%d R=(%.17g,%.17g,%.17g) qtf=(%.17g,%.17g) gnorm=%.6g\n",
                        pa, pb, acn0, acn1, l0, r11, r12, r22, qtf0, qtf1, gnorm);
 #endif
                 if (gnorm <= A.gtol) info = 4;
-                dg0 = fmax(dg0, acn0);
-                dg1 = fmax(dg1, acn1);
+                if (acn0 > dg0) {
+                    dg0 = acn0;
+                    idg0 = iacn0;
+                }
+                if (acn1 > dg1) {
+                    dg1 = acn1;
+                    idg1 = iacn1;
+                }
                 state = ST_ITER;
             }
 

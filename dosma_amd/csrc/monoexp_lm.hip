@@ -33,7 +33,13 @@
 namespace qmri {
 
 constexpr int kSub = 256;        // voxels per tile (per wave): 4 per lane -> 16-byte loads for f32
-constexpr int kRefillIdle = 16;  // refill the wave when at least this many lanes are idle
+#ifndef QMRI_REFILL
+#define QMRI_REFILL 16
+#endif
+#ifndef QMRI_MIN_WAVES
+#define QMRI_MIN_WAVES 1
+#endif
+constexpr int kRefillIdle = QMRI_REFILL;  // refill the wave when at least this many lanes are idle
 
 // Separately rounded product / difference (no FMA contraction): numpy evaluates the model as
 // a * exp(b * x) - y with one rounding per operation, and lmdif's forward-difference Jacobian is
@@ -332,13 +338,25 @@ __device__ __forceinline__ void stage_rows(const S *__restrict__ g, long long ld
 
 enum : int { ST_IDLE = 0, ST_INIT = 1, ST_ITER = 2 };
 
+// LDS bytes one wave owns: samples [E][kSub] of LT + SStot, a0, b0 (double) + 1-byte queue entries
+template <typename LT>
+__host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
+    return (size_t)E * kSub * sizeof(LT) + (size_t)kSub * (3 * sizeof(double) + 1);
+}
+
 template <int EMAX, bool FULL, typename LT>
-__global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
+__global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const FitKArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int E = FULL ? EMAX : A.E;
-    LT *tile = reinterpret_cast<LT *>(smem) + (size_t)wave * E * kSub;
+    // wave-private LDS slice: samples [E][kSub] | SStot [kSub] | a0 [kSub] | b0 [kSub] | queue [kSub]
+    unsigned char *slice = smem + (size_t)wave * lds_bytes_per_wave<LT>(E);
+    LT *tile = reinterpret_cast<LT *>(slice);
+    double *t_sst = reinterpret_cast<double *>(slice + (size_t)E * kSub * sizeof(LT));
+    double *t_a0 = t_sst + kSub;
+    double *t_b0 = t_a0 + kSub;
+    unsigned char *t_queue = reinterpret_cast<unsigned char *>(t_b0 + kSub);
     const double epsmch = DBL_EPSILON;
 
     // ---- per-lane LM state (fp64 registers) ----
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
     int nfev = 0;
     bool first = true;                        // MINPACK iter == 1
 
-    // ---- wave-uniform queue over the current tile ----
+    // ---- wave-uniform queue of the fit-able voxels of the current tile ----
     long long tile_base = 0;
     int qpos = 0, qend = 0;
     bool more = true;
@@ -368,140 +386,164 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
         {
             unsigned long long idle = __ballot(state == ST_IDLE);
             const int nidle = __popcll(idle);
-            if (nidle >= kRefillIdle || nidle == 64) {
-                while (idle) {
-                    if (qpos >= qend) {
-                        if (!more) break;
-                        unsigned int t = 0;
-                        if (lane == 0) t = atomicAdd(A.tile_counter, 1u);
-                        t = __builtin_amdgcn_readfirstlane(t);
-                        const long long start = (long long)t * kSub;
-                        if (start >= A.N) {
-                            more = false;
-                            break;
-                        }
-                        tile_base = start;
-                        const long long rem = A.N - start;
-                        qend = rem < kSub ? (int)rem : kSub;
-                        qpos = 0;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        switch (A.y_dtype) {
-                            case QMRI_F32:
-                                stage_rows(static_cast<const float *>(A.y) + start, A.ld, E, qend,
-                                           tile, lane, A.vec_ok);
-                                break;
-                            case QMRI_F64:
-                                stage_rows(static_cast<const double *>(A.y) + start, A.ld, E, qend,
-                                           tile, lane, A.vec_ok);
-                                break;
-                            case QMRI_I16:
-                                stage_rows(static_cast<const short *>(A.y) + start, A.ld, E, qend,
-                                           tile, lane, A.vec_ok);
-                                break;
-                            default:
-                                stage_rows(static_cast<const unsigned short *>(A.y) + start, A.ld, E,
-                                           qend, tile, lane, A.vec_ok);
-                                break;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+            if (nidle >= A.refill_idle || nidle == 64) {
+                // ---- queue empty: claim tiles until one has fit-able voxels (or the volume is done) ----
+                while (qpos >= qend && more) {
+                    unsigned int t = 0;
+                    if (lane == 0) t = atomicAdd(A.tile_counter, 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    const long long start = (long long)t * kSub;
+                    if (start >= A.N) {
+                        more = false;
+                        break;
                     }
-                    // rank of this lane among the idle lanes
-                    const int rank = __builtin_amdgcn_mbcnt_hi(
-                        (unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                    const int j = qpos + rank;
-                    if (state == ST_IDLE && j < qend) {
-                        const long long v = tile_base + j;
-                        bool selected = true;
-                        if (A.mask) selected = A.mask[v] != 0;
-                        if (!selected) {
-                            finish_voxel(A, v, 0, 0, 0, -1, 0, true);
-                        } else {
-                            bool allzero = true, finite = true, oob = false;
-                            double mean = 0.0;
-#pragma unroll
-                            for (int i = 0; i < EMAX; ++i)
-                                if (FULL || i < E) {
-                                    const LT s = tile[i * kSub + j];
-                                    yv[i] = s;
-                                    allzero = allzero && (s == LT(0));
-                                    finite = finite && isfinite(static_cast<double>(s));
-                                    if (A.use_y_bounds)
-                                        oob = oob || static_cast<double>(s) < A.y_lo ||
-                                              static_cast<double>(s) > A.y_hi;
-                                    mean += static_cast<double>(s);
-                                }
-                            if (!finite) {
-                                // reference: ValueError for the whole call (scipy check_finite)
-                                *A.nonfinite = 1;
-                                finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
-                            } else if (allzero || oob) {
-                                // skip rule, fitting.py:1064-1067
-                                finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                    tile_base = start;
+                    const long long rem = A.N - start;
+                    const int count = rem < kSub ? (int)rem : kSub;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    switch (A.y_dtype) {
+                        case QMRI_F32:
+                            stage_rows(static_cast<const float *>(A.y) + start, A.ld, E, count, tile,
+                                       lane, A.vec_ok);
+                            break;
+                        case QMRI_F64:
+                            stage_rows(static_cast<const double *>(A.y) + start, A.ld, E, count, tile,
+                                       lane, A.vec_ok);
+                            break;
+                        case QMRI_I16:
+                            stage_rows(static_cast<const short *>(A.y) + start, A.ld, E, count, tile,
+                                       lane, A.vec_ok);
+                            break;
+                        default:
+                            stage_rows(static_cast<const unsigned short *>(A.y) + start, A.ld, E, count,
+                                       tile, lane, A.vec_ok);
+                            break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- tile preparation with ALL lanes (4 voxels per lane, coalesced side traffic):
+                    // mask / skip / non-finite rules, SStot, initial guess, and the compacted queue of
+                    // voxels that really need the solver.  Skipped voxels are finished right here.
+                    int qn = 0;
+#pragma unroll 1
+                    for (int k = 0; k < kSub / 64; ++k) {
+                        const int j = k * 64 + lane;
+                        bool need_fit = false;
+                        if (j < count) {
+                            const long long v = start + j;
+                            bool selected = true;
+                            if (A.mask) selected = A.mask[v] != 0;
+                            if (!selected) {
+                                finish_voxel(A, v, 0, 0, 0, -1, 0, true);
                             } else {
-                                mean = mean / (double)E;
-                                double st = 0.0;
+                                bool allzero = true, finite = true, oob = false;
+                                double mean = 0.0;
+                                double sv[EMAX];
 #pragma unroll
                                 for (int i = 0; i < EMAX; ++i)
                                     if (FULL || i < E) {
-                                        const double d = static_cast<double>(yv[i]) - mean;
-                                        st += d * d;
+                                        const double q = static_cast<double>(tile[i * kSub + j]);
+                                        sv[i] = q;
+                                        allzero = allzero && (q == 0.0);
+                                        finite = finite && isfinite(q);
+                                        if (A.use_y_bounds) oob = oob || q < A.y_lo || q > A.y_hi;
+                                        mean += q;
                                     }
-                                sstot = st;
-                                vox = v;
-                                pa = A.a0;
-                                pb = A.b0;
-                                if (A.init == QMRI_INIT_PER_VOXEL) {
-                                    if (A.a0v) pa = A.a0v[v];
-                                    if (A.b0v) pb = A.b0v[v];
-                                } else if (A.init == QMRI_INIT_LOGLIN) {
-                                    // fitting.py:701-718: v + 1e-10*(v==0); log; degree-1 LS in x;
-                                    // r2 on the log data; r2 < 0 or NaN -> params 0 -> p0 = (1, 0)
-                                    double sl = 0.0;
-                                    double lg[EMAX];
+                                if (!finite) {
+                                    // reference: ValueError for the whole call (scipy check_finite)
+                                    *A.nonfinite = 1;
+                                    finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                                } else if (allzero || oob) {
+                                    // skip rule, fitting.py:1064-1067
+                                    finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                                } else {
+                                    need_fit = true;
+                                    mean = mean / (double)E;
+                                    double st = 0.0;
 #pragma unroll
                                     for (int i = 0; i < EMAX; ++i)
                                         if (FULL || i < E) {
-                                            double s = static_cast<double>(yv[i]);
-                                            if (s == 0.0) s = 1e-10;
-                                            lg[i] = log(s);
-                                            sl += lg[i];
+                                            const double d = sv[i] - mean;
+                                            st += d * d;
                                         }
-                                    const double lmean = sl / (double)E;
-                                    double sxy = 0.0, syy = 0.0;
+                                    t_sst[j] = st;
+                                    if (A.init == QMRI_INIT_PER_VOXEL) {
+                                        t_a0[j] = A.a0v ? A.a0v[v] : A.a0;
+                                        t_b0[j] = A.b0v ? A.b0v[v] : A.b0;
+                                    } else if (A.init == QMRI_INIT_LOGLIN) {
+                                        // fitting.py:701-718: v + 1e-10*(v==0); log; degree-1 LS in x;
+                                        // r2 on the log data; r2 < 0 or NaN -> params 0 -> p0 = (1, 0)
+                                        double sl = 0.0;
 #pragma unroll
-                                    for (int i = 0; i < EMAX; ++i)
-                                        if (FULL || i < E) {
-                                            const double dy = lg[i] - lmean;
-                                            sxy += (A.x[i] - A.xmean) * dy;
-                                            syy += dy * dy;
-                                        }
-                                    const double slope = sxy / A.sxx;
-                                    const double icpt = lmean - slope * A.xmean;
-                                    double ssr = 0.0;
+                                        for (int i = 0; i < EMAX; ++i)
+                                            if (FULL || i < E) {
+                                                double q = sv[i];
+                                                if (q == 0.0) q = 1e-10;
+                                                sv[i] = log(q);
+                                                sl += sv[i];
+                                            }
+                                        const double lmean = sl / (double)E;
+                                        double sxy = 0.0, syy = 0.0;
 #pragma unroll
-                                    for (int i = 0; i < EMAX; ++i)
-                                        if (FULL || i < E) {
-                                            const double r = (slope * A.x[i] + icpt) - lg[i];
-                                            ssr += r * r;
-                                        }
-                                    const double r2l = 1.0 - ssr / (syy + 1e-8);
-                                    if (r2l >= 0.0 && !isnan(slope) && !isnan(icpt)) {
-                                        pa = exp(icpt);
-                                        pb = slope;
-                                    } else {
-                                        pa = 1.0;
-                                        pb = 0.0;
+                                        for (int i = 0; i < EMAX; ++i)
+                                            if (FULL || i < E) {
+                                                const double dy = sv[i] - lmean;
+                                                sxy += (A.x[i] - A.xmean) * dy;
+                                                syy += dy * dy;
+                                            }
+                                        const double slope = sxy / A.sxx;
+                                        const double icpt = lmean - slope * A.xmean;
+                                        double ssr = 0.0;
+#pragma unroll
+                                        for (int i = 0; i < EMAX; ++i)
+                                            if (FULL || i < E) {
+                                                const double r = (slope * A.x[i] + icpt) - sv[i];
+                                                ssr += r * r;
+                                            }
+                                        const double r2l = 1.0 - ssr / (syy + 1e-8);
+                                        const bool good = r2l >= 0.0 && !isnan(slope) && !isnan(icpt);
+                                        t_a0[j] = good ? exp(icpt) : 1.0;
+                                        t_b0[j] = good ? slope : 0.0;
                                     }
                                 }
-                                state = ST_INIT;
                             }
                         }
+                        const unsigned long long fit = __ballot(need_fit);
+                        if (need_fit) {
+                            const int r = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(fit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fit, 0u));
+                            t_queue[qn + r] = (unsigned char)j;
+                        }
+                        qn += __popcll(fit);
                     }
-                    qpos = qpos + __popcll(idle);
+                    qpos = 0;
+                    qend = qn;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // ---- pull: idle lane number r takes queue entry qpos + r ----
+                if (qpos < qend) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                    const int q = qpos + rank;
+                    if (state == ST_IDLE && q < qend) {
+                        const int j = t_queue[q];
+#pragma unroll
+                        for (int i = 0; i < EMAX; ++i)
+                            if (FULL || i < E) yv[i] = tile[i * kSub + j];
+                        sstot = t_sst[j];
+                        vox = tile_base + j;
+                        pa = A.a0;
+                        pb = A.b0;
+                        if (A.init != QMRI_INIT_SCALAR) {
+                            pa = t_a0[j];
+                            pb = t_b0[j];
+                        }
+                        state = ST_INIT;
+                    }
+                    qpos = qpos + nidle;
                     if (qpos > qend) qpos = qend;
-                    idle = __ballot(state == ST_IDLE);
                 }
             }
         }
@@ -775,7 +817,7 @@ __global__ __launch_bounds__(256) void monoexp_lm_kernel(const FitKArgs A) {
 // tile is small enough (<= 80 KB per block), otherwise one block of up to 160 KB.
 template <typename LT>
 static int waves_per_block(int E) {
-    const size_t tile = (size_t)E * kSub * sizeof(LT);
+    const size_t tile = lds_bytes_per_wave<LT>(E);
     int w = (int)((80 * 1024) / tile);
     if (w < 1) w = (int)((160 * 1024) / tile);
     if (w > 4) w = 4;
@@ -786,7 +828,7 @@ template <int EMAX, bool FULL, typename LT>
 static hipError_t launch_one(const FitKArgs &k, int grid, hipStream_t stream) {
     const int wpb = waves_per_block<LT>(k.E);
     if (wpb < 1) return hipErrorInvalidValue;
-    const size_t lds = (size_t)wpb * k.E * kSub * sizeof(LT);
+    const size_t lds = (size_t)wpb * lds_bytes_per_wave<LT>(k.E);
     auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
     (void)hipGetLastError();  // do not inherit a stale error from an unrelated earlier call
     if (lds > 64 * 1024) {
@@ -802,7 +844,7 @@ template <int EMAX, bool FULL, typename LT>
 static int occupancy_one(int E) {
     int nb = 0;
     const int wpb = waves_per_block<LT>(E);
-    const size_t lds = (size_t)wpb * E * kSub * sizeof(LT);
+    const size_t lds = (size_t)wpb * lds_bytes_per_wave<LT>(E);
     auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn),

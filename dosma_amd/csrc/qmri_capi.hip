@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -107,6 +108,12 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     k.vec_ok = (reinterpret_cast<uintptr_t>(a->y) % (4 * es) == 0) && (a->ld % 4 == 0);
     k.init = a->init;
     k.use_y_bounds = a->use_y_bounds;
+    {
+        const char *env = std::getenv("QMRI_REFILL_IDLE");
+        k.refill_idle = env ? std::atoi(env) : 16;
+        if (k.refill_idle < 1) k.refill_idle = 1;
+        if (k.refill_idle > 64) k.refill_idle = 64;
+    }
     k.y_lo = a->y_lo;
     k.y_hi = a->y_hi;
     k.mask = a->mask;

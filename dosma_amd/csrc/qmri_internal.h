@@ -20,7 +20,7 @@ struct FitKArgs {
     int vec_ok;  // rows are 4-element aligned: 16-byte-per-lane staging loads are legal
     int init;
     int use_y_bounds;
-    int pad0;
+    int refill_idle;  // idle lanes at which a wave pulls new voxels
     double y_lo, y_hi;
     const unsigned char *mask;
     const double *a0v;

@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recipes", default="B,A", help="which recipes to time (A = headline, last)")
     args = ap.parse_args()
 
     from dosma_amd import _lib as L
@@ -153,7 +154,7 @@ def main():
         torch.cuda.synchronize(device)
 
     results = {}
-    for recipe in ("B", "A"):  # A last: it is the headline
+    for recipe in args.recipes.split(","):  # A last: it is the headline
         a = make_args(L, y, popt, r2, stream.cuda_stream, recipe)
         a.device = local_rank
         for _ in range(args.warmup):
@@ -223,10 +224,12 @@ def main():
             "runs": {
                 "A_defaults_fixed_p0": {"voxel_fits_per_s": n * world * args.steps / ra["elapsed"],
                                         "kernel_ms": ra["kernel_ms"]},
-                "B_polyfit_init": {"voxel_fits_per_s": n * world * args.steps / results["B"]["elapsed"],
-                                   "kernel_ms": results["B"]["kernel_ms"]},
             },
         }
+        if "B" in results:
+            out["runs"]["B_polyfit_init"] = {
+                "voxel_fits_per_s": n * world * args.steps / results["B"]["elapsed"],
+                "kernel_ms": results["B"]["kernel_ms"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(y)
         print(json.dumps(out))

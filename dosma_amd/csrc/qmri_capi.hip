@@ -110,7 +110,7 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     k.use_y_bounds = a->use_y_bounds;
     {
         const char *env = std::getenv("QMRI_REFILL_IDLE");
-        k.refill_idle = env ? std::atoi(env) : 16;
+        k.refill_idle = env ? std::atoi(env) : 8;
         if (k.refill_idle < 1) k.refill_idle = 1;
         if (k.refill_idle > 64) k.refill_idle = 64;
     }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): bench + rocprofv3 kernel stats + HBM PMC passes -> gpurun_out/<tag>/
+# usage: scripts/collect_profile.sh <tag>
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --recipes A > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --recipes A > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --recipes A > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS_F64 SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --recipes A > $OUT/pmc_sq.log 2>&1
+tail -c 600 $OUT/bench.json

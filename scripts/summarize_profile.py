@@ -1,0 +1,47 @@
+"""Turn a gpurun_out/<tag>/ directory (scripts/collect_profile.sh) into the committed summaries under
+profiles/: <tag>_kernel_stats.csv (rocprofv3 --stats), <tag>_bench.json, <tag>_counters.json
+(HBM traffic with the gfx950 FETCH_SIZE correction + SQ counters)."""
+import csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
+
+
+def last_dispatch(path, kernel="monoexp"):
+    rows = [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"]]
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    return {r["Counter_Name"]: float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last}, rows[0]
+
+
+fetch, _ = last_dispatch(glob.glob(os.path.join(src, "pmc_fetch", "*counter_collection.csv"))[0])
+write, _ = last_dispatch(glob.glob(os.path.join(src, "pmc_write", "*counter_collection.csv"))[0])
+sq, row = last_dispatch(glob.glob(os.path.join(src, "pmc_sq", "*counter_collection.csv"))[0])
+n = bench["config"]["voxels_per_gpu_per_step"]
+alg = bench["roofline"]["algorithmic_bytes_per_voxel"] * n
+rd = 2 * fetch["FETCH_SIZE"] * 1024   # MI355X_MICROARCH.md: FETCH_SIZE counts 1/2 of a wide coalesced read
+wr = write["WRITE_SIZE"] * 1024
+stats = [r for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")) if "monoexp" in r["Name"]][0]
+out = {
+    "tag": tag,
+    "kernel": stats["Name"],
+    "rocprof_avg_kernel_ms": float(stats["AverageNs"]) / 1e6,
+    "bench_hip_event_kernel_ms": bench["roofline"]["kernel_ms"],
+    "vgpr": row["VGPR_Count"], "accum_vgpr": row["Accum_VGPR_Count"], "lds_bytes_per_block": row["LDS_Block_Size"],
+    "FETCH_SIZE_raw_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_raw_KB": write["WRITE_SIZE"],
+    "correction": "FETCH_SIZE doubled (gfx950: reports 1/2 of the bytes of a wide coalesced streaming read, "
+                  "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (uncalibrated per the guide)",
+    "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+    "hbm_bytes_per_launch": rd + wr,
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": (rd + wr) / alg,
+    "sq": sq,
+    "lanes_active_per_valu_instr": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+}
+json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
+json.dump({"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_counters.json"},
+          open("profiles/r01_hbm_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -71,10 +71,24 @@ class QmriLinfitArgs(ctypes.Structure):
     ]
 
 
+class QmriUnet2dDesc(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_int32), ("base_features", ctypes.c_int32), ("n_classes", ctypes.c_int32),
+        ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("tensors", ctypes.POINTER(ctypes.c_void_p)), ("n_tensors", ctypes.c_int32),
+        ("reserved", ctypes.c_int32), ("bn_eps", ctypes.c_double),
+    ]
+
+
+PRECISION = {"bf16": 0, "bf16x3": 1}
+
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
     "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
+    "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
+    "qmri_conv2d_nhwc_host",
 )
 
 _lib = None
@@ -146,6 +160,21 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = [ctypes.POINTER(QmriLinfitArgs)]
             fn.restype = ctypes.c_int
+        lib.qmri_unet2d_create.argtypes = [ctypes.POINTER(QmriUnet2dDesc), ctypes.POINTER(ctypes.c_void_p)]
+        lib.qmri_unet2d_create.restype = ctypes.c_int
+        lib.qmri_unet2d_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        lib.qmri_unet2d_set_precision.restype = ctypes.c_int
+        lib.qmri_unet2d_forward.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+            ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        lib.qmri_unet2d_forward.restype = ctypes.c_int
+        lib.qmri_unet2d_destroy.argtypes = [ctypes.c_void_p]
+        lib.qmri_unet2d_destroy.restype = ctypes.c_int
+        lib.qmri_conv2d_nhwc_host.argtypes = [
+            ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+        lib.qmri_conv2d_nhwc_host.restype = ctypes.c_int
         _lib = lib
         return lib
 
@@ -298,3 +327,77 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
     a.device = int(device)
     check(lib.qmri_linfit_host(ctypes.byref(a)))
     return out
+
+
+def conv2d_nhwc_host(x, kernel, bias, *, scale=None, shift=None, relu=True, transposed=False,
+                     precision="bf16x3", device=0):
+    """One conv layer on the GPU from host arrays: x (B,H,W,Cin) f32; kernel in the Keras layout --
+    (3,3,Cin,Cout) for Conv2D, (3,3,Cout,Cin) for Conv2DTranspose(strides=2).  Returns NHWC f32."""
+    lib = load()
+    require_device()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    kernel = np.ascontiguousarray(kernel, dtype=np.float32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    B, H, W, Cin = x.shape
+    Cout = kernel.shape[2] if transposed else kernel.shape[3]
+    if kernel.shape != ((3, 3, Cout, Cin) if transposed else (3, 3, Cin, Cout)):
+        raise ValueError(f"kernel shape {kernel.shape} does not match the input channels {Cin}")
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+    y = np.empty((B, 2 * H, 2 * W, Cout) if transposed else (B, H, W, Cout), dtype=np.float32)
+    check(lib.qmri_conv2d_nhwc_host(_ptr(x), B, H, W, Cin, _ptr(kernel), _ptr(bias), _ptr(sc), _ptr(sh),
+                                    1 if relu else 0, Cout, 1 if transposed else 0, PRECISION[precision],
+                                    _ptr(y), int(device)))
+    return y
+
+
+class Unet2dEngine:
+    """Owns a native U-Net instance (weights packed on the GPU + activation buffers)."""
+
+    def __init__(self, tensors, H, W, *, depth=6, base_features=32, n_classes=4, max_batch=16,
+                 precision="bf16x3", device=0, bn_eps=1e-3):
+        lib = load()
+        require_device()
+        self._lib = lib
+        self._handle = ctypes.c_void_p()
+        keep = [np.ascontiguousarray(t, dtype=np.float32) for t in tensors]
+        arr = (ctypes.c_void_p * len(keep))(*[t.ctypes.data for t in keep])
+        d = QmriUnet2dDesc()
+        d.depth, d.base_features, d.n_classes = depth, base_features, n_classes
+        d.H, d.W, d.max_batch = int(H), int(W), int(max_batch)
+        d.precision, d.device = PRECISION[precision], int(device)
+        d.tensors = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        d.n_tensors = len(keep)
+        d.bn_eps = float(bn_eps)
+        check(lib.qmri_unet2d_create(ctypes.byref(d), ctypes.byref(self._handle)))
+        self.H, self.W, self.n_classes, self.max_batch = int(H), int(W), int(n_classes), int(max_batch)
+
+    def set_precision(self, precision):
+        check(self._lib.qmri_unet2d_set_precision(self._handle, PRECISION[precision]))
+
+    def forward_host(self, x, *, whiten=False, eps=0.0, want_logits=True, want_mask=True):
+        """x (S, H, W) float32 host array -> (logits (S,H,W,C) f32 | None, mask (S,H,W,C) u8 | None)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        S = x.shape[0]
+        if x.shape[1:] != (self.H, self.W):
+            raise ValueError(f"slices are {x.shape[1:]}, model was built for {(self.H, self.W)}")
+        logits = np.empty((S, self.H, self.W, self.n_classes), np.float32) if want_logits else None
+        mask = np.empty((S, self.H, self.W, self.n_classes), np.uint8) if want_mask else None
+        check(self._lib.qmri_unet2d_forward(self._handle, _ptr(x), S, 0, 1 if whiten else 0, float(eps),
+                                            _ptr(logits), _ptr(mask), 0, None))
+        return logits, mask
+
+    def forward_device(self, x_ptr, S, logits_ptr, mask_ptr, *, whiten=False, eps=0.0, stream=None):
+        check(self._lib.qmri_unet2d_forward(self._handle, x_ptr, int(S), 1, 1 if whiten else 0, float(eps),
+                                            logits_ptr, mask_ptr, 1, stream))
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.qmri_unet2d_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

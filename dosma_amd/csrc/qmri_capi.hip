@@ -191,6 +191,13 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
 
 }  // namespace
 
+namespace qmri {
+void set_last_error(const char *msg) {
+    std::strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+}  // namespace qmri
+
 extern "C" {
 
 int qmri_version(void) { return QMRI_VERSION; }

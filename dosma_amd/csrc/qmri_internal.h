@@ -62,6 +62,39 @@ struct LinfitKArgs {
 };
 hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
 
+// Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).
+struct ConvKArgs {
+    const float *x;      // NHWC fp32 input, pixel stride ldx (elements), channel offset xoff
+    long long ldx;
+    int xoff;
+    int B, H, W;         // input grid: GEMM rows = B*H*W
+    int Cin, Cout;
+    int ntaps;
+    int tap_dy[9], tap_dx[9];  // input pixel of tap t = (y + dy[t], x + dx[t]); zero outside the image
+    const __bf16 *w_hi;  // [Cout][ntaps*Cin] bf16 (K-major per output channel)
+    const __bf16 *w_lo;  // low parts (SPLIT3) or nullptr
+    const float *bias;   // [Cout] or nullptr
+    const float *scale;  // [Cout] or nullptr   y = scale * relu(acc + bias) + shift
+    const float *shift;
+    int relu;
+    float *y;            // NHWC fp32 output, pixel stride ldy, channel offset yoff
+    long long ldy;
+    int yoff;
+    int Ho, Wo;          // output image size
+    int sy, sx, py, px;  // output pixel = (y*sy + py, x*sx + px)
+};
+hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
+hipError_t conv3x3_c1_launch(const float *x, int B, int H, int W, const float *w, const float *bias,
+                             int Cout, float *y, long long ldy, int yoff, hipStream_t stream);
+hipError_t maxpool2_launch(const float *x, long long ldx, int xoff, int B, int H, int W, int C, float *y,
+                           hipStream_t stream);
+hipError_t head_launch(const float *x, long long npix, int Cin, const float *w, const float *bias, int NC,
+                       float *logits, unsigned char *mask, hipStream_t stream);
+hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
+                         hipStream_t stream);
+
+void set_last_error(const char *msg);  // thread-local message behind qmri_last_error()
+
 int monoexp_tile_voxels();
 const char *monoexp_variant_name(int E, int y_dtype);
 int monoexp_blocks_per_cu(const FitKArgs &k);

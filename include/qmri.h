@@ -167,6 +167,52 @@ typedef struct qmri_linfit_args {
 int qmri_linfit_device(const qmri_linfit_args *args); /* device pointers, asynchronous on args->stream */
 int qmri_linfit_host(const qmri_linfit_args *args);   /* host pointers, synchronous */
 
+/*
+ * ---- 2D U-Net segmentation (IWOAIOAIUnet2D / IWOAIOAIUnet2DNormalized) --------------------------------
+ * Replaces `model.predict(v, batch_size)` inside SegModel.generate_mask
+ *   (/root/reference/dosma/models/oaiunet2d.py:305; graph :197-289; whitening seg_model.py:114-127).
+ * Weights are handed over ONCE as host fp32 arrays in Keras layouts and Keras layer-creation order
+ * (what `load_weights` of the .h5 iterates over):
+ *   for level l = 0 .. depth-1 :  conv1.kernel (3,3,Cin,C) conv1.bias (C)  conv2.kernel (3,3,C,C) conv2.bias
+ *                                 bn.gamma bn.beta bn.moving_mean bn.moving_variance            (8 tensors)
+ *   for level l = depth-2 .. 0 :  deconv.kernel (3,3,C,Cup) deconv.bias  conv1.kernel (3,3,2C,C) conv1.bias
+ *                                 conv2.kernel conv2.bias  bn.gamma bn.beta bn.mean bn.var      (10 tensors)
+ *   head.kernel (1,1,C0,n_classes) head.bias                                                    (2 tensors)
+ */
+typedef struct qmri_unet2d_desc {
+    int32_t depth;          /* 6 */
+    int32_t base_features;  /* 32: level l has base_features << l channels */
+    int32_t n_classes;      /* 4 (fc, tc, pc, men) */
+    int32_t H, W;           /* slice size; multiples of 2^(depth-1) */
+    int32_t max_batch;      /* slices per pass through the network (the reference's batch_size) */
+    int32_t precision;      /* 0: bf16 MFMA (1 product);  1: split-bf16 x3 (~fp32 accuracy) */
+    int32_t device;
+    const float *const *tensors; /* HOST pointers, order above */
+    int32_t n_tensors;
+    int32_t reserved;
+    double bn_eps;          /* BatchNormalization epsilon: 1e-3 (oaiunet2d.py:228) */
+} qmri_unet2d_desc;
+
+int qmri_unet2d_create(const qmri_unet2d_desc *desc, void **handle);
+int qmri_unet2d_set_precision(void *handle, int32_t precision);
+/*
+ * x [S][H][W] fp32 (host or device), optional whole-volume whitening (x - mean)/(std + eps) first.
+ * Outputs (nullable): logits [S][H][W][n_classes] fp32 (pre-sigmoid), mask u8 = sigmoid > 0.5.
+ */
+int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_device, int32_t whiten,
+                        double whiten_eps, float *logits, uint8_t *mask, int32_t out_on_device,
+                        void *stream);
+int qmri_unet2d_destroy(void *handle);
+/*
+ * One layer on host NHWC fp32 arrays (operator-level entry; also what the unit tests drive):
+ *   transposed 0: Conv2D(Cout, 3x3, padding=same), kernel (3,3,Cin,Cout)       oaiunet2d.py:213-226
+ *   transposed 1: Conv2DTranspose(Cout, 3x3, strides=2, padding=same), kernel (3,3,Cout,Cin) :259-261
+ *   y = scale * relu?(conv + bias) + shift   (scale/shift nullable: the folded BatchNormalization)
+ */
+int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *kernel,
+                          const float *bias, const float *scale, const float *shift, int32_t relu,
+                          int32_t Cout, int32_t transposed, int32_t precision, float *y, int32_t device);
+
 /* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
  * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */
 void qmri_set_timing(int enable);

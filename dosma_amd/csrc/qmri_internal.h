@@ -70,8 +70,9 @@ struct ConvKArgs {
     int B, H, W;         // input grid: GEMM rows = B*H*W
     int Cin, Cout;
     int ntaps;
-    int tap_dy[9], tap_dx[9];  // input pixel of tap t = (y + dy[t], x + dx[t]); zero outside the image
-    const __bf16 *w_hi;  // [Cout][ntaps*Cin] bf16 (K-major per output channel)
+    unsigned long long taps;  // 4 bits per tap: (dy+1) | (dx+1) << 2, dy, dx in {-1, 0, 1}
+    int tiles_y, tiles_x;     // filled by conv_igemm_launch
+    const __bf16 *w_hi;  // [Cout][chunk][tap][32] bf16: K index = (chunk*ntaps + tap)*32 + c (K-major per cout)
     const __bf16 *w_lo;  // low parts (SPLIT3) or nullptr
     const float *bias;   // [Cout] or nullptr
     const float *scale;  // [Cout] or nullptr   y = scale * relu(acc + bias) + shift

@@ -102,7 +102,8 @@ struct ConvLayer {
     }
 };
 
-// Conv2D 3x3 SAME: Keras kernel (kh, kw, Cin, Cout) -> W[co][(kh*3+kw)*Cin + ci], taps dy = kh-1, dx = kw-1
+// Conv2D 3x3 SAME: Keras kernel (kh, kw, Cin, Cout) -> W[co][(chunk*9 + tap)*32 + c] with ci = chunk*32 + c,
+// tap = kh*3 + kw, dy = kh-1, dx = kw-1 (chunk-major K so that all 9 taps reuse one LDS-resident halo)
 void pack_conv3x3(const float *k, int Cin, int Cout, ConvLayer &L, std::vector<float> &wk) {
     L.Cin = Cin;
     L.Cout = Cout;
@@ -115,7 +116,8 @@ void pack_conv3x3(const float *k, int Cin, int Cout, ConvLayer &L, std::vector<f
             L.dx[t] = kw - 1;
             for (int ci = 0; ci < Cin; ++ci)
                 for (int co = 0; co < Cout; ++co)
-                    wk[(size_t)co * 9 * Cin + (size_t)t * Cin + ci] = k[(((size_t)kh * 3 + kw) * Cin + ci) * Cout + co];
+                    wk[(size_t)co * 9 * Cin + ((size_t)(ci / 32) * 9 + t) * 32 + ci % 32] =
+                        k[(((size_t)kh * 3 + kw) * Cin + ci) * Cout + co];
         }
 }
 
@@ -137,7 +139,8 @@ void pack_deconv_phase(const float *k, int Cin, int Cout, int py, int px, ConvLa
             L.dx[t] = kw == 2 ? -1 : 0;
             for (int co = 0; co < Cout; ++co)
                 for (int ci = 0; ci < Cin; ++ci)
-                    wk[(size_t)co * L.ntaps * Cin + (size_t)t * Cin + ci] = k[(((size_t)kh * 3 + kw) * Cout + co) * Cin + ci];
+                    wk[(size_t)co * L.ntaps * Cin + ((size_t)(ci / 32) * L.ntaps + t) * 32 + ci % 32] =
+                        k[(((size_t)kh * 3 + kw) * Cout + co) * Cin + ci];
         }
 }
 
@@ -154,10 +157,9 @@ qmri::ConvKArgs conv_args(const ConvLayer &L, const float *x, long long ldx, int
     k.Cin = L.Cin;
     k.Cout = L.Cout;
     k.ntaps = L.ntaps;
-    for (int t = 0; t < L.ntaps; ++t) {
-        k.tap_dy[t] = L.dy[t];
-        k.tap_dx[t] = L.dx[t];
-    }
+    k.taps = 0;
+    for (int t = 0; t < L.ntaps; ++t)
+        k.taps |= (unsigned long long)((L.dy[t] + 1) | ((L.dx[t] + 1) << 2)) << (4 * t);
     k.w_hi = L.w_hi.as<__bf16>();
     k.w_lo = L.w_lo.as<__bf16>();
     k.bias = L.bias.as<float>();

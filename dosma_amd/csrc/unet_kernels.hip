@@ -29,26 +29,42 @@ namespace qmri {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kBM = 128;        // output pixels per block
 constexpr int kBK = 32;         // channels per K step (one tap x 32 input channels)
 constexpr int kLdsRow = 40;     // bf16 elements per LDS row: 32 + 8 pad -> 80 B stride, conflict-free b128 reads
+constexpr int kTW = 16;         // output tile width (pixels)
 
+// Tile geometry.  A block owns TH x 16 output pixels x BN output channels and loops over 32-channel
+// chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
+// LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
+// fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
 template <int BN>
 struct TileCfg {
+    static constexpr int TH = BN == 128 ? 8 : 16;
+    static constexpr int BM = TH * kTW;
     static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
     static constexpr int WAVES_M = 4 / WAVES_N;
-    static constexpr int TM = kBM / WAVES_M / 32;
+    static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
+    static constexpr int HALO_PIX = (TH + 2) * (kTW + 2);
+    static constexpr int HALO_PAIRS = (HALO_PIX * 4 + 255) / 256;  // (pixel, 8-channel group) per thread
+    static constexpr int B_PAIRS = (BN * 4 + 255) / 256;
 };
 
 __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo,
                                            bool want_lo) {
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = static_cast<__bf16>(v[i]);
-        hi[i] = h;
-        if (want_lo) lo[i] = static_cast<__bf16>(v[i] - static_cast<float>(h));
+    hi[0] = static_cast<__bf16>(a.x); hi[1] = static_cast<__bf16>(a.y);
+    hi[2] = static_cast<__bf16>(a.z); hi[3] = static_cast<__bf16>(a.w);
+    hi[4] = static_cast<__bf16>(b.x); hi[5] = static_cast<__bf16>(b.y);
+    hi[6] = static_cast<__bf16>(b.z); hi[7] = static_cast<__bf16>(b.w);
+    if (want_lo) {
+        lo[0] = static_cast<__bf16>(a.x - static_cast<float>(hi[0]));
+        lo[1] = static_cast<__bf16>(a.y - static_cast<float>(hi[1]));
+        lo[2] = static_cast<__bf16>(a.z - static_cast<float>(hi[2]));
+        lo[3] = static_cast<__bf16>(a.w - static_cast<float>(hi[3]));
+        lo[4] = static_cast<__bf16>(b.x - static_cast<float>(hi[4]));
+        lo[5] = static_cast<__bf16>(b.y - static_cast<float>(hi[5]));
+        lo[6] = static_cast<__bf16>(b.z - static_cast<float>(hi[6]));
+        lo[7] = static_cast<__bf16>(b.w - static_cast<float>(hi[7]));
     }
 }
 
@@ -56,109 +72,102 @@ template <int BN, bool SPLIT3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     using C = TileCfg<BN>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
-    constexpr int A_BYTES = kBM * kLdsRow * 2;
-    constexpr int B_BYTES = BN * kLdsRow * 2;
-    constexpr int BUF_BYTES = NPLANES * (A_BYTES + B_BYTES);
+    constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
+    constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *rowpix = reinterpret_cast<int *>(smem + 2 * BUF_BYTES);  // [kBM] output pixel index (-1 = none)
+    unsigned char *halo_base = smem;                                  // [2][NPLANES][HALO_BYTES]
+    unsigned char *w_base = smem + 2 * NPLANES * HALO_BYTES;          // [2][NPLANES][W_BYTES]
+    int *rowpix = reinterpret_cast<int *>(w_base + 2 * NPLANES * W_BYTES);  // [BM] output pixel or -1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / C::WAVES_N;
     const int wn = wave % C::WAVES_N;
-    const long long M = (long long)A.B * A.H * A.W;
-    const long long m0 = (long long)blockIdx.x * kBM;
     const int n0 = blockIdx.y * BN;
-    const int K = A.ntaps * A.Cin;
 
-    // ---- per-thread gather coordinates for the A (activation) tile: 2 (row, 8-channel group) pairs ----
-    int a_row[2], a_grp[2], a_y[2], a_x[2];
-    long long a_base[2];
-    bool a_ok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int idx = tid + r * 256;
-        a_row[r] = idx >> 2;
-        a_grp[r] = idx & 3;
-        const long long m = m0 + a_row[r];
-        a_ok[r] = m < M;
-        const long long mm = a_ok[r] ? m : 0;
-        const int xw = (int)(mm % A.W);
-        const long long t = mm / A.W;
-        const int yh = (int)(t % A.H);
-        a_y[r] = yh;
-        a_x[r] = xw;
-        a_base[r] = mm;  // pixel index of the un-shifted position
-    }
-    if (tid < kBM) {
-        const long long m = m0 + tid;
+    // block -> (image, tile row, tile column)
+    const int tiles_per_img = A.tiles_y * A.tiles_x;
+    const int b = blockIdx.x / tiles_per_img;
+    const int trem = blockIdx.x - b * tiles_per_img;
+    const int ty = trem / A.tiles_x;
+    const int tx = trem - ty * A.tiles_x;
+    const int y0 = ty * C::TH, x0 = tx * kTW;
+    const long long img_base = (long long)b * A.H * A.W;
+
+    for (int r = tid; r < C::BM; r += 256) {
+        const int ly = r / kTW, lx = r % kTW;
+        const int yy = y0 + ly, xx = x0 + lx;
         int pix = -1;
-        if (m < M) {
-            const int xw = (int)(m % A.W);
-            const long long t = m / A.W;
-            const int yh = (int)(t % A.H);
-            const int b = (int)(t / A.H);
-            pix = (b * A.Ho + (yh * A.sy + A.py)) * A.Wo + (xw * A.sx + A.px);
-        }
-        rowpix[tid] = pix;
+        if (yy < A.H && xx < A.W) pix = (b * A.Ho + (yy * A.sy + A.py)) * A.Wo + (xx * A.sx + A.px);
+        rowpix[r] = pix;
     }
 
-    constexpr int B_PAIRS = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;  // (row, group) pairs per thread for B
-    float4 ra[2][2];
-    bf16x8 rb_hi[B_PAIRS], rb_lo[B_PAIRS];
+    // ---- per-thread halo gather coordinates (constant over the K loop) ----
+    long long h_src[C::HALO_PAIRS];  // element offset of the pixel's channel 0 (+ 8-channel group), or -1
+    int h_dst[C::HALO_PAIRS];        // byte offset inside a halo plane
+#pragma unroll
+    for (int r = 0; r < C::HALO_PAIRS; ++r) {
+        const int idx = tid + r * 256;
+        const int hp = idx >> 2, grp = idx & 3;
+        const int hy = hp / (kTW + 2), hx = hp - hy * (kTW + 2);
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const bool ok = hp < C::HALO_PIX && yy >= 0 && yy < A.H && xx >= 0 && xx < A.W;
+        h_src[r] = ok ? (img_base + (long long)yy * A.W + xx) * A.ldx + A.xoff + grp * 8 : -1;
+        h_dst[r] = hp < C::HALO_PIX ? (hp * kLdsRow + grp * 8) * 2 : -1;
+    }
 
-    auto load_tile = [&](int step) {
-        const int k0 = step * kBK;
-        const int tap = k0 / A.Cin;
-        const int c0 = k0 - tap * A.Cin;
-        const int dy = A.tap_dy[tap], dx = A.tap_dx[tap];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int yy = a_y[r] + dy, xx = a_x[r] + dx;
-            const bool ok = a_ok[r] && yy >= 0 && yy < A.H && xx >= 0 && xx < A.W;
-            if (ok) {
-                const float *p = A.x + (a_base[r] + (long long)dy * A.W + dx) * A.ldx + A.xoff + c0 +
-                                 a_grp[r] * 8;
-                ra[r][0] = *reinterpret_cast<const float4 *>(p);
-                ra[r][1] = *reinterpret_cast<const float4 *>(p + 4);
-            } else {
-                ra[r][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                ra[r][1] = ra[r][0];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < B_PAIRS; ++r) {
-            const int idx = tid + r * 256;
-            if (idx < BN * 4) {
-                const int row = idx >> 2, grp = idx & 3;
-                const long long off = (long long)(n0 + row) * K + k0 + grp * 8;
-                rb_hi[r] = *reinterpret_cast<const bf16x8 *>(A.w_hi + off);
-                if (SPLIT3) rb_lo[r] = *reinterpret_cast<const bf16x8 *>(A.w_lo + off);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char *base = smem + buf * BUF_BYTES;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            bf16x8 hi, lo;
-            split_bf16(ra[r][0], ra[r][1], hi, lo, SPLIT3);
-            const int off = (a_row[r] * kLdsRow + a_grp[r] * 8) * 2;
-            *reinterpret_cast<bf16x8 *>(base + off) = hi;
-            if (SPLIT3) *reinterpret_cast<bf16x8 *>(base + A_BYTES + off) = lo;
-        }
-        unsigned char *bb = base + NPLANES * A_BYTES;
-#pragma unroll
-        for (int r = 0; r < B_PAIRS; ++r) {
-            const int idx = tid + r * 256;
-            if (idx < BN * 4) {
-                const int off = ((idx >> 2) * kLdsRow + (idx & 3) * 8) * 2;
-                *reinterpret_cast<bf16x8 *>(bb + off) = rb_hi[r];
-                if (SPLIT3) *reinterpret_cast<bf16x8 *>(bb + B_BYTES + off) = rb_lo[r];
-            }
-        }
-    };
+    float4 rh0[C::HALO_PAIRS], rh1[C::HALO_PAIRS];
+    bf16x8 rb_hi[C::B_PAIRS], rb_lo[C::B_PAIRS];
+    const int ntaps = A.ntaps;
+    const int K = ntaps * A.Cin;
+
+    // (macros, not lambdas: by-reference captures of the staging arrays made the compiler keep them in
+    //  scratch memory; the loads are unconditional from a clamped address + select for the same reason)
+#define QMRI_LOAD_HALO(c0_)                                                                        \
+    _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                    \
+        const bool ok_ = h_src[r] >= 0;                                                            \
+        const float *p_ = A.x + (ok_ ? h_src[r] : 0) + (c0_);                                      \
+        const float4 v0_ = *reinterpret_cast<const float4 *>(p_);                                  \
+        const float4 v1_ = *reinterpret_cast<const float4 *>(p_ + 4);                              \
+        rh0[r] = ok_ ? v0_ : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+        rh1[r] = ok_ ? v1_ : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+    }
+#define QMRI_STORE_HALO(buf_)                                                                      \
+    {                                                                                              \
+        unsigned char *base_ = halo_base + (buf_) * NPLANES * HALO_BYTES;                          \
+        _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                \
+            if (h_dst[r] >= 0) {                                                                   \
+                bf16x8 hi_, lo_;                                                                   \
+                split_bf16(rh0[r], rh1[r], hi_, lo_, SPLIT3);                                      \
+                *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = hi_;                               \
+                if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + HALO_BYTES + h_dst[r]) = lo_;      \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    // weights of K step `step` (= chunk * ntaps + tap): [BN][32] slice of W[co][step*32 + c]
+#define QMRI_LOAD_W(step_)                                                                         \
+    _Pragma("unroll") for (int r = 0; r < C::B_PAIRS; ++r) {                                       \
+        const int idx_ = tid + r * 256;                                                            \
+        if (idx_ < BN * 4) {                                                                       \
+            const long long off_ =                                                                 \
+                (long long)(n0 + (idx_ >> 2)) * K + (long long)(step_) * kBK + (idx_ & 3) * 8;     \
+            rb_hi[r] = *reinterpret_cast<const bf16x8 *>(A.w_hi + off_);                           \
+            if (SPLIT3) rb_lo[r] = *reinterpret_cast<const bf16x8 *>(A.w_lo + off_);               \
+        }                                                                                          \
+    }
+#define QMRI_STORE_W(buf_)                                                                         \
+    {                                                                                              \
+        unsigned char *base_ = w_base + (buf_) * NPLANES * W_BYTES;                                \
+        _Pragma("unroll") for (int r = 0; r < C::B_PAIRS; ++r) {                                   \
+            const int idx_ = tid + r * 256;                                                        \
+            if (idx_ < BN * 4) {                                                                   \
+                const int off_ = ((idx_ >> 2) * kLdsRow + (idx_ & 3) * 8) * 2;                     \
+                *reinterpret_cast<bf16x8 *>(base_ + off_) = rb_hi[r];                              \
+                if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + W_BYTES + off_) = rb_lo[r];        \
+            }                                                                                      \
+        }                                                                                          \
+    }
 
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
@@ -168,43 +177,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int steps = K / kBK;
-    load_tile(0);
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        store_tile(buf);
-        __syncthreads();
-        if (s + 1 < steps) load_tile(s + 1);  // global loads in flight under the MFMAs below
-        const unsigned char *base = smem + buf * BUF_BYTES;
-        const unsigned char *bb = base + NPLANES * A_BYTES;
+    // per-lane halo row of each MFMA row-tile (un-shifted): pixel (ly + 1, lx + 1)
+    int a_row0[C::TM];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
-            bf16x8 a_hi[C::TM], a_lo[C::TM], b_hi[C::TN], b_lo[C::TN];
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) {
-                const int row = (wm * C::TM + i) * 32 + (lane & 31);
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(base + row * kLdsRow * 2 + koff);
-                if (SPLIT3)
-                    a_lo[i] = *reinterpret_cast<const bf16x8 *>(base + A_BYTES + row * kLdsRow * 2 + koff);
+    for (int i = 0; i < C::TM; ++i) {
+        const int r = (wm * C::TM + i) * 32 + (lane & 31);
+        a_row0[i] = ((r / kTW) + 1) * (kTW + 2) + (r % kTW) + 1;
+    }
+
+    const int chunks = A.Cin / kBK;
+    const int steps = chunks * ntaps;
+    QMRI_LOAD_HALO(0)
+    QMRI_LOAD_W(0)
+    int step = 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int hbuf = ch & 1;
+        QMRI_STORE_HALO(hbuf)
+        if (ch + 1 < chunks) {
+            QMRI_LOAD_HALO((ch + 1) * kBK)
+        }  // next chunk's halo in flight under 9 taps of MFMA
+        const unsigned char *hb = halo_base + hbuf * NPLANES * HALO_BYTES;
+        for (int t = 0; t < ntaps; ++t, ++step) {
+            const int wbuf = step & 1;
+            QMRI_STORE_W(wbuf)
+            __syncthreads();
+            if (step + 1 < steps) {
+                QMRI_LOAD_W(step + 1)
             }
+            const unsigned char *wb = w_base + wbuf * NPLANES * W_BYTES;
+            const int code = (int)((A.taps >> (4 * t)) & 0xF);  // (dy+1) | (dx+1) << 2
+            const int shift = ((code & 3) - 1) * (kTW + 2) + ((code >> 2) - 1);
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) {
-                const int col = (wn * C::TN + j) * 32 + (lane & 31);
-                b_hi[j] = *reinterpret_cast<const bf16x8 *>(bb + col * kLdsRow * 2 + koff);
-                if (SPLIT3)
-                    b_lo[j] = *reinterpret_cast<const bf16x8 *>(bb + B_BYTES + col * kLdsRow * 2 + koff);
-            }
+            for (int kk = 0; kk < 2; ++kk) {
+                const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
+                bf16x8 a_hi[C::TM], a_lo[C::TM], b_hi[C::TN], b_lo[C::TN];
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i)
+                for (int i = 0; i < C::TM; ++i) {
+                    const int off = (a_row0[i] + shift) * kLdsRow * 2 + koff;
+                    a_hi[i] = *reinterpret_cast<const bf16x8 *>(hb + off);
+                    if (SPLIT3) a_lo[i] = *reinterpret_cast<const bf16x8 *>(hb + HALO_BYTES + off);
+                }
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) {
-                    if (SPLIT3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    const int col = (wn * C::TN + j) * 32 + (lane & 31);
+                    b_hi[j] = *reinterpret_cast<const bf16x8 *>(wb + col * kLdsRow * 2 + koff);
+                    if (SPLIT3) b_lo[j] = *reinterpret_cast<const bf16x8 *>(wb + W_BYTES + col * kLdsRow * 2 + koff);
                 }
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) {
+                        if (SPLIT3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     }
 
@@ -234,17 +263,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     }
 }
 
-hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream) {
-    const long long M = (long long)k.B * k.H * k.W;
+#undef QMRI_LOAD_HALO
+#undef QMRI_STORE_HALO
+#undef QMRI_LOAD_W
+#undef QMRI_STORE_W
+
+template <int BN>
+static size_t conv_lds_bytes(int split3) {
+    using C = TileCfg<BN>;
+    const int planes = split3 ? 2 : 1;
+    return 2 * (size_t)planes * (C::HALO_PIX + BN) * kLdsRow * 2 + C::BM * sizeof(int);
+}
+
+hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
+    ConvKArgs k = k0;
     const int bn = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(k.Cout / bn));
-    const int planes = split3 ? 2 : 1;
-    const size_t lds = 2 * (size_t)planes * (kBM + bn) * kLdsRow * 2 + kBM * sizeof(int);
+    const int th = bn == 128 ? 8 : 16;
+    k.tiles_y = (k.H + th - 1) / th;
+    k.tiles_x = (k.W + kTW - 1) / kTW;
+    dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
 #define QMRI_CONV_CASE(BN_, S3_)                                                                    \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, S3_>;                                                      \
+        const size_t lds = conv_lds_bytes<BN_>(S3_);                                                \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

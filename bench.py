@@ -113,6 +113,61 @@ def cpu_baseline(y_dev, cores_cap=None):
     }
 
 
+UNET_HW = 384
+UNET_SLICES = 160
+UNET_GFLOP_PER_SLICE = 70.79   # 35.39 GMAC per 384x384 slice
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def bench_unet(L, torch, dist, device, local_rank, world, args, barrier):
+    """UNet2D slices/s (BASELINE.json configs[3]: IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv).
+
+    A step = one whole volume (160 sagittal slices incl. whole-volume whitening) per GPU through the
+    network, input resident in HBM, logits + masks written to HBM.  Random He-initialised weights of
+    the reference architecture (the trained .h5 is not distributed; throughput does not depend on
+    the values) and random-normal input (not zeros: DVFS, cdna_hip_programming.md rule 25)."""
+    from dosma_amd.models import weights as W
+
+    eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), UNET_HW, UNET_HW,
+                         max_batch=args.unet_batch, precision="bf16", device=local_rank)
+    gen = torch.Generator(device=device).manual_seed(7 + local_rank)
+    x = torch.randn((UNET_SLICES, UNET_HW, UNET_HW), device=device, generator=gen) * 150 + 300
+    logits = torch.empty((UNET_SLICES, UNET_HW, UNET_HW, 4), device=device)
+    mask = torch.empty((UNET_SLICES, UNET_HW, UNET_HW, 4), device=device, dtype=torch.uint8)
+    stream = torch.cuda.current_stream(device)
+    steps = max(2, args.steps // 4)
+    res = {}
+    for prec in ("bf16x3", "bf16"):
+        eng.set_precision(prec)
+        for _ in range(max(1, args.warmup // 2)):
+            eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
+                               stream=stream.cuda_stream)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
+                               stream=stream.cuda_stream)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t[0].item()
+        res[prec] = UNET_SLICES * world * steps / el
+    eng.close()
+    tf = res["bf16"] / world * UNET_GFLOP_PER_SLICE / 1e3
+    return {
+        "metric": "UNet2D slices/sec (IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv)",
+        "value": res["bf16"], "unit": "slices/s", "steps": steps, "batch": args.unet_batch,
+        "precision": "bf16 operands, fp32 accumulate, fp32 activations in HBM",
+        "slices_per_s_bf16x3": res["bf16x3"],
+        "data": "synthetic (random He weights of the reference architecture, random-normal input)",
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / MFMA_BF16_PEAK_TFLOPS, "gflop_per_slice": UNET_GFLOP_PER_SLICE,
+                     "traffic": None},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +175,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recipes", default="B,A", help="which recipes to time (A = headline, last)")
+    ap.add_argument("--no-unet", action="store_true", help="skip the UNet2D slices/s leg")
+    ap.add_argument("--unet-batch", type=int, default=32)
     args = ap.parse_args()
 
     from dosma_amd import _lib as L
@@ -177,6 +234,10 @@ def main():
         results[recipe] = dict(elapsed=elapsed, kernel_ms=kernel_ms,
                                kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
 
+    unet = None
+    if not args.no_unet:
+        unet = bench_unet(L, torch, dist, device, local_rank, world, args, barrier)
+
     if rank == 0:
         ra = results["A"]
         total_voxels = n * world * args.steps
@@ -188,7 +249,7 @@ def main():
             with open(prof) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
-            "metric": "voxel-fits/sec (8-echo monoexp, 512x512x160)",
+            "metric": "voxel-fits/sec (8-echo monoexp, 512x512x160) [+ UNet2D slices/sec under \"unet2d\"]",
             "value": value,
             "unit": "voxel-fits/s",
             "n_gpus": world,
@@ -226,6 +287,8 @@ def main():
                                         "kernel_ms": ra["kernel_ms"]},
             },
         }
+        if unet is not None:
+            out["unet2d"] = unet
         if "B" in results:
             out["runs"]["B_polyfit_init"] = {
                 "voxel_fits_per_s": n * world * args.steps / results["B"]["elapsed"],

@@ -1,0 +1,107 @@
+"""Segmentation-model base class on the HIP U-Net engine.
+
+Mirror of the reference's ``dosma/models/seg_model.py`` (``SegModel`` :14-79, ``KerasSegModel`` :82-106,
+``whiten_volume`` :114-127) for the inference path: same constructor ``(input_shape, weights_path,
+force_weights=False)``, same ``generate_mask(volume)`` / ``__call__`` contract, ``batch_size`` from
+``preferences.segmentation_batch_size``.  ``build_model`` creates a native engine
+(``libqmri_hip.so``: ``qmri_unet2d_*``) instead of a Keras model; there is no TensorFlow/CPU path.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from dosma_amd.defaults import preferences
+from dosma_amd.med_volume import MedicalVolume
+
+__all__ = ["SegModel", "HipSegModel", "whiten_volume"]
+
+__VOLUME_DIMENSIONS__ = 3
+
+
+class SegModel(ABC):
+    """
+    Args:
+        input_shape (Tuple[int]): ``(height, width, channels)`` of one slice.
+        weights_path (str | dict): ``.npz`` (or Keras ``.h5`` when h5py is installed) weights file, or a
+            dict of arrays in Keras layouts (``dosma_amd.models.weights``).
+        force_weights (bool, optional): load weights without checking the file name.
+    """
+
+    ALIASES = [""]
+
+    def __init__(self, input_shape, weights_path, force_weights=False):
+        self.batch_size = preferences.segmentation_batch_size
+        self.seg_model = self.build_model(input_shape, weights_path)
+
+    @abstractmethod
+    def build_model(self, input_shape, weights_path):
+        pass
+
+    @abstractmethod
+    def generate_mask(self, volume: MedicalVolume):
+        """Segment the volume; returns uint8 {0,1} MedicalVolume(s) of ``volume.shape``."""
+        pass
+
+    def __call__(self, *args, **kwargs):
+        return self.generate_mask(*args, **kwargs)
+
+    def __preprocess_volume__(self, volume: np.ndarray):
+        return volume
+
+    def __postprocess_volume__(self, volume: np.ndarray):
+        return volume
+
+
+class HipSegModel(SegModel):
+    """Counterpart of the reference's ``KerasSegModel``: builds the native engine and loads weights."""
+
+    #: "bf16x3" (split-bf16, ~fp32 accuracy: logits within 1e-3 of an fp32 run) or "bf16" (single MFMA)
+    precision = "bf16x3"
+    device = 0
+
+    def build_model(self, input_shape, weights_path=None):
+        from dosma_amd import _lib
+        from dosma_amd.models import weights as W
+
+        if type(input_shape) is not tuple or len(input_shape) != 3 or input_shape[2] != 1:
+            raise ValueError("input_size must be a tuple of size (height, width, 1)")
+        if weights_path is None:
+            raise ValueError("weights are required")
+        if isinstance(weights_path, dict):
+            w = weights_path
+        elif str(weights_path).endswith(".npz"):
+            w = W.load_npz(weights_path)
+        else:
+            w = W.load_keras_h5(weights_path)
+        n_classes = self._n_classes()
+        W.validate(w, n_classes=n_classes)
+        return _lib.Unet2dEngine(W.to_abi_order(w), input_shape[0], input_shape[1], n_classes=n_classes,
+                                 max_batch=max(int(self.batch_size), 1), precision=self.precision,
+                                 device=self.device)
+
+    def _n_classes(self):
+        return 4
+
+    def _predict(self, vol_hws: np.ndarray, whiten: bool, eps: float, want_logits=False):
+        """``model.predict`` of the reference: (H, W, S) volume -> (S, H, W, C) mask (and logits)."""
+        eng = self.seg_model
+        if int(self.batch_size) != eng.max_batch:  # the CLI sets model.batch_size after construction
+            raise ValueError("batch_size was changed after the engine was built; rebuild the model")
+        v = np.ascontiguousarray(np.transpose(vol_hws, (2, 0, 1)), dtype=np.float32)
+        logits, mask = eng.forward_host(v, whiten=whiten, eps=eps, want_logits=want_logits)
+        return logits, mask
+
+    def __del__(self):
+        eng = getattr(self, "seg_model", None)
+        if eng is not None:
+            eng.close()
+
+
+def whiten_volume(x: np.ndarray, eps: float = 0.0):
+    """``(x - mean) / (std + eps)`` over all pixels (reference seg_model.py:114-127).
+
+    Host (numpy) version for callers that want the array; ``generate_mask`` whitens on the GPU."""
+    x = np.asarray(x)
+    if len(x.shape) != __VOLUME_DIMENSIONS__:
+        raise ValueError(f"Input has {x.ndim} dimensions. Expected {__VOLUME_DIMENSIONS__}")
+    return (x - np.mean(x)) / (np.std(x) + eps)

@@ -51,6 +51,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         "         offsetof(qmri_monoexp_args, info), offsetof(qmri_monoexp_args, stream));\n"
         '  printf("%zu %zu %zu\\n", offsetof(qmri_linfit_args, x), offsetof(qmri_linfit_args, popt),\n'
         "         offsetof(qmri_linfit_args, stream));\n"
+        '  printf("%zu %zu %zu\\n", sizeof(qmri_unet2d_desc), offsetof(qmri_unet2d_desc, tensors),\n'
+        "         offsetof(qmri_unet2d_desc, bn_eps));\n"
         "  return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -59,7 +61,9 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
     A, P, Lf = _lib.QmriMonoexpArgs, _lib.QmriPost, _lib.QmriLinfitArgs
     want = [ctypes.sizeof(P), ctypes.sizeof(A), ctypes.sizeof(Lf),
             A.x.offset, A.a0.offset, A.post.offset, A.popt.offset, A.info.offset, A.stream.offset,
-            Lf.x.offset, Lf.popt.offset, Lf.stream.offset]
+            Lf.x.offset, Lf.popt.offset, Lf.stream.offset,
+            ctypes.sizeof(_lib.QmriUnet2dDesc), _lib.QmriUnet2dDesc.tensors.offset,
+            _lib.QmriUnet2dDesc.bn_eps.offset]
     assert got == want
 
 

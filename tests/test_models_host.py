@@ -1,0 +1,75 @@
+"""Host logic of the segmentation path that needs no GPU: weights container, registry, validation,
+whitening helper, and the torch restatement's layer semantics (pinned against naive definitions)."""
+import numpy as np
+import pytest
+
+from dosma_amd.models import SUPPORTED_MODELS, weights as W, whiten_volume
+from dosma_amd.models.oaiunet2d import IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, OAIUnet2D
+from oracle import unet_oracle as uo
+
+
+def test_aliases_nonempty_and_disjoint():
+    """reference tests/models/test_util.py:6-34."""
+    models = [OAIUnet2D, IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized]
+    aliases = [set(m.ALIASES) for m in models]
+    assert all(a and "" not in a for a in aliases)
+    for i in range(len(aliases)):
+        for j in range(i + 1, len(aliases)):
+            assert not (aliases[i] & aliases[j])
+    assert SUPPORTED_MODELS == ["oai-unet2d", "iwoai-2019-t6", "iwoai-2019-t6-normalized"]
+
+
+def test_weights_container(tmp_path):
+    w = W.random_weights(seed=1, nf=(32, 64), n_classes=4)
+    assert len(W.tensor_names(depth=2)) == 2 * 8 + 10 + 2
+    W.validate(w, nf=(32, 64))
+    assert w["up0_deconv_kernel"].shape == (3, 3, 32, 64) and w["up0_conv1_kernel"].shape == (3, 3, 64, 32)
+    W.save_npz(tmp_path / "w.npz", w)
+    w2 = W.load_npz(tmp_path / "w.npz")
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    bad = dict(w)
+    bad["down1_conv2_kernel"] = bad["down1_conv2_kernel"][..., :3]
+    with pytest.raises(ValueError):
+        W.validate(bad, nf=(32, 64))
+    del bad["head_bias"]
+    with pytest.raises(ValueError):
+        W.validate(bad, nf=(32, 64))
+    full = W.random_weights(seed=0)
+    assert sum(v.size for v in full.values()) == 34_597_892  # 34.6 M parameters
+    assert [n for n in W.tensor_names()] == [n for n in W.tensor_names(6)] and len(W.tensor_names()) == 100
+
+
+def test_whiten_volume_matches_reference_formula():
+    x = np.random.default_rng(0).uniform(0, 500, (5, 6, 7)).astype(np.float32)
+    y = whiten_volume(x)
+    assert abs(float(y.mean())) < 1e-5 and abs(float(y.std()) - 1) < 1e-5
+    assert np.array_equal(whiten_volume(x, eps=1e-8), (x - np.mean(x)) / (np.std(x) + 1e-8))
+    with pytest.raises(ValueError):
+        whiten_volume(x[0])
+
+
+def test_restatement_layer_semantics():
+    """Conv2DTranspose alignment vs the scatter definition, and BN-after-ReLU / concat order through a
+    2-level network evaluated by hand."""
+    rng = np.random.default_rng(2)
+    nf = (32, 64)
+    w = uo.make_weights(seed=5, nf=nf)
+    x = rng.standard_normal((1, 4, 4)).astype(np.float32)
+    logits, feats = uo.forward(w, x, nf=nf, return_features=True, dtype="float64")
+    assert logits.shape == (1, 4, 4, 4)
+    d1 = feats["down1"]  # (1, 2, 2, 64) post-BN
+    up = uo.deconv_naive(d1, w["up0_deconv_kernel"], w["up0_deconv_bias"])
+    assert np.allclose(up, feats["up0_deconv"], atol=1e-10)
+    # first block by hand at one pixel: conv -> relu -> conv -> relu -> BN
+    k1, b1 = w["down0_conv1_kernel"].astype(np.float64), w["down0_conv1_bias"].astype(np.float64)
+    xp = np.pad(x[0].astype(np.float64), 1)
+    c1 = np.zeros((4, 4, 32))
+    for i in range(4):
+        for j in range(4):
+            c1[i, j] = np.maximum(np.einsum("hw,hwc->c", xp[i:i + 3, j:j + 3], k1[:, :, 0, :]) + b1, 0)
+    k2, b2 = w["down0_conv2_kernel"].astype(np.float64), w["down0_conv2_bias"].astype(np.float64)
+    c1p = np.pad(c1, ((1, 1), (1, 1), (0, 0)))
+    c2 = np.maximum(np.einsum("hwc,hwco->o", c1p[1:4, 2:5], k2) + b2, 0)  # pixel (1, 2)
+    g, bt, mu, var = (w[f"down0_bn_{n}"].astype(np.float64) for n in ("gamma", "beta", "mean", "var"))
+    want = g * (c2 - mu) / np.sqrt(var + 1e-3) + bt
+    assert np.allclose(feats["down0"][0, 1, 2], want, atol=1e-10)

@@ -123,3 +123,61 @@ def test_whitening_and_batching_are_consistent(small_net):
         a.forward_host(vol[:, :16, :])
     with pytest.raises(NotImplementedError):
         L.Unet2dEngine(tensors, 48, 48)  # not divisible by 32 -> reference's 3x3 pooling branch
+
+
+# ----------------------------------------------------------------------------- drop-in model classes
+def test_generate_mask_drop_in(small_net, tmp_path):
+    """The reference's generate_mask contract (oaiunet2d.py:291-320): dict fc/tc/pc/men of uint8 {0,1}
+    MedicalVolumes with the input's shape, orientation and affine -- for any input orientation."""
+    from dosma_amd import MedicalVolume
+    from dosma_amd.models import (IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, OAIUnet2D, get_model,
+                                  model_from_config)
+    from dosma_amd.models import weights as W
+
+    w, _ = small_net
+    rng = np.random.default_rng(9)
+    H, Wd, S = 64, 32, 6
+    sag = (rng.standard_normal((H, Wd, S)) * 80 + 200).astype(np.float32)  # (SI, AP, LR)
+    aff = np.array([[0, 0, 1.5, -40.0], [0, -0.4, 0, 60.0], [-0.4, 0, 0, 70.0], [0, 0, 0, 1.0]])
+    mv = MedicalVolume(sag, aff)
+    assert mv.orientation == ("SI", "AP", "LR")
+    model = IWOAIOAIUnet2DNormalized((H, Wd, 1), w, force_weights=True)
+    out = model.generate_mask(mv)
+    assert list(out) == ["fc", "tc", "pc", "men"]
+    xw = uo.whiten_volume(sag.astype(np.float64)).astype(np.float32)
+    ref = uo.forward(w, np.transpose(xw, (2, 0, 1)), dtype="float64") > 0  # (S, H, W, 4)
+    for i, k in enumerate(out):
+        m = out[k]
+        assert isinstance(m, MedicalVolume) and m.dtype == np.uint8 and m.shape == mv.shape
+        assert np.allclose(m.affine, mv.affine) and set(np.unique(m.volume)) <= {0, 1}
+        assert (m.volume == np.transpose(ref[..., i], (1, 2, 0))).mean() > 0.9999
+    # same data presented in another orientation -> same masks in that orientation
+    mv_ax = mv.reformat(("AP", "LR", "SI"))
+    out_ax = model(mv_ax)
+    for k in out:
+        assert out_ax[k].orientation == mv_ax.orientation
+        assert np.array_equal(out_ax[k].reformat(mv.orientation).volume, out[k].volume)
+    # un-normalised variant, registry, config wrapper, weights round trip through .npz
+    path = tmp_path / "iwoai-2019-unet2d_fc-tc-pc-men_weights.npz"
+    W.save_npz(path, w)
+    m2 = get_model("iwoai-2019-t6", (H, Wd, 1), str(path))
+    assert isinstance(m2, IWOAIOAIUnet2D)
+    o2 = m2.generate_mask(mv)
+    ref2 = uo.forward(w, np.transpose(sag, (2, 0, 1)), dtype="float64") > 0
+    assert (o2["tc"].volume == np.transpose(ref2[..., 1], (1, 2, 0))).mean() > 0.9999
+    with pytest.raises(ValueError):
+        IWOAIOAIUnet2D((H, Wd, 1), str(tmp_path / "other.npz"))
+    with pytest.raises(ValueError):
+        IWOAIOAIUnet2D((H, Wd), w, force_weights=True)
+    with pytest.raises(LookupError):
+        get_model("nope", (H, Wd, 1), w)
+    cfg = {"DOSMA_MODEL": "iwoai-2019-t6-normalized", "CATEGORIES": ["a", "b", "c", "d"], "WEIGHTS_FILE": w}
+    m3 = model_from_config(cfg, input_shape=(H, Wd, 1))
+    assert list(m3.generate_mask(mv)) == ["a", "b", "c", "d"]
+    # single-class OAIUnet2D: one MedicalVolume, whiten(eps=1e-8)
+    w1 = dict(w)
+    w1["head_kernel"], w1["head_bias"] = w["head_kernel"][..., :1].copy(), w["head_bias"][:1].copy()
+    m4 = OAIUnet2D((H, Wd, 1), w1)
+    o4 = m4.generate_mask(mv)
+    assert isinstance(o4, MedicalVolume) and o4.shape == mv.shape
+    assert (o4.volume == out["fc"].volume).mean() > 0.999

@@ -64,7 +64,7 @@ hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
 
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).
 struct ConvKArgs {
-    const float *x;      // NHWC fp32 input, pixel stride ldx (elements), channel offset xoff
+    const void *x;       // NHWC input (fp32, or bf16 in plain-bf16 mode), pixel stride ldx (elements), channel offset xoff
     long long ldx;
     int xoff;
     int B, H, W;         // input grid: GEMM rows = B*H*W
@@ -78,7 +78,7 @@ struct ConvKArgs {
     const float *scale;  // [Cout] or nullptr   y = scale * relu(acc + bias) + shift
     const float *shift;
     int relu;
-    float *y;            // NHWC fp32 output, pixel stride ldy, channel offset yoff
+    void *y;             // NHWC output (same element type as x), pixel stride ldy, channel offset yoff
     long long ldy;
     int yoff;
     int Ho, Wo;          // output image size
@@ -86,11 +86,12 @@ struct ConvKArgs {
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
 hipError_t conv3x3_c1_launch(const float *x, int B, int H, int W, const float *w, const float *bias,
-                             int Cout, float *y, long long ldy, int yoff, hipStream_t stream);
-hipError_t maxpool2_launch(const float *x, long long ldx, int xoff, int B, int H, int W, int C, float *y,
-                           hipStream_t stream);
-hipError_t head_launch(const float *x, long long npix, int Cin, const float *w, const float *bias, int NC,
-                       float *logits, unsigned char *mask, hipStream_t stream);
+                             int Cout, void *y, long long ldy, int yoff, int act_bf16, hipStream_t stream);
+hipError_t maxpool2_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y,
+                           int act_bf16, hipStream_t stream);
+hipError_t head_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC,
+                       float *logits, unsigned char *mask, int act_bf16, hipStream_t stream);
+hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStream_t stream);
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
                          hipStream_t stream);
 

@@ -144,8 +144,8 @@ void pack_deconv_phase(const float *k, int Cin, int Cout, int py, int px, ConvLa
         }
 }
 
-qmri::ConvKArgs conv_args(const ConvLayer &L, const float *x, long long ldx, int xoff, int B, int H, int W,
-                          float *y, long long ldy, int yoff, int Ho, int Wo, int sy, int sx, int py, int px) {
+qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int xoff, int B, int H, int W,
+                          void *y, long long ldy, int yoff, int Ho, int Wo, int sy, int sx, int py, int px) {
     qmri::ConvKArgs k;
     std::memset(&k, 0, sizeof(k));
     k.x = x;
@@ -340,53 +340,59 @@ int qmri_unet2d_set_precision(void *handle, int32_t precision) {
     return QMRI_OK;
 }
 
-// one batch of `Bt` slices already in U->in (device) -> logits / mask device pointers for that batch
+// one batch of `Bt` slices already in U->in (device) -> logits / mask device pointers for that batch.
+// Activation buffers are allocated for fp32 and reinterpreted as bf16 in the plain-bf16 mode.
 static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hipStream_t st) {
     const int D = U->depth;
     const int s3 = U->split3;
+    const int ab = s3 ? 0 : 1;  // activations stored as bf16?
+    const size_t es = ab ? 2 : 4;
+    auto at = [&](const DevBuf &b, long long elem_off) -> void * {
+        return static_cast<unsigned char *>(b.p) + (size_t)elem_off * es;
+    };
+    (void)at;
     // ---- contracting path ----
     for (int l = 0; l < D; ++l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
-        float *t1 = U->tmp[l]->as<float>();
+        void *t1 = U->tmp[l]->p;
         if (l == 0) {
             U_TRY(qmri::conv3x3_c1_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(),
-                                          C, t1, C, 0, st));
+                                          C, t1, C, 0, ab, st));
         } else {
-            auto k = conv_args(*U->down1[l], U->pool[l]->as<float>(), U->nf[l - 1], 0, Bt, H, W, t1, C, 0, H, W,
-                               1, 1, 0, 0);
+            auto k = conv_args(*U->down1[l], U->pool[l]->p, U->nf[l - 1], 0, Bt, H, W, t1, C, 0, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         }
         if (l < D - 1) {
             // block output (post-BN) goes to the 2nd half of this level's concat buffer = the skip
-            float *cat = U->cat[l]->as<float>();
+            void *cat = U->cat[l]->p;
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, cat, 2 * C, C, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
-            U_TRY(qmri::maxpool2_launch(cat, 2 * C, C, Bt, H, W, C, U->pool[l + 1]->as<float>(), st));
+            U_TRY(qmri::maxpool2_launch(cat, 2 * C, C, Bt, H, W, C, U->pool[l + 1]->p, ab, st));
         } else {
-            auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.as<float>(), C, 0, H, W, 1, 1, 0, 0);
+            auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         }
     }
     // ---- expanding path ----
-    const float *src = U->bottom.as<float>();
+    const void *src = U->bottom.p;
     for (int l = D - 2; l >= 0; --l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
-        float *cat = U->cat[l]->as<float>();
+        void *cat = U->cat[l]->p;
         for (int ph = 0; ph < 4; ++ph) {
             auto k = conv_args(*U->updec[(size_t)l * 4 + ph], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W,
                                2, 2, ph >> 1, ph & 1);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         }
-        float *t1 = U->tmp[l]->as<float>();
+        void *t1 = U->tmp[l]->p;
         auto k1 = conv_args(*U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, H, W, 1, 1, 0, 0);
         U_TRY(qmri::conv_igemm_launch(k1, s3, st));
-        float *out = U->upout[l]->as<float>();
+        void *out = U->upout[l]->p;
         auto k2 = conv_args(*U->up2[l], t1, C, 0, Bt, H, W, out, C, 0, H, W, 1, 1, 0, 0);
         U_TRY(qmri::conv_igemm_launch(k2, s3, st));
         src = out;
     }
     U_TRY(qmri::head_launch(src, (long long)Bt * U->H * U->W, U->nf[0], U->head_w.as<float>(),
-                            U->head_b.as<float>(), U->ncls, logits, mask, st));
+                            U->head_b.as<float>(), U->ncls, logits, mask, ab, st));
     return QMRI_OK;
 }
 
@@ -463,10 +469,17 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
     if (Cin % 32 || Cout % 32) return ufail(QMRI_ERR_UNSUPPORTED, "Cin and Cout must be multiples of 32");
     U_TRY(hipSetDevice(device));
     const int Ho = transposed ? 2 * H : H, Wo = transposed ? 2 * W : W;
-    DevBuf dx, dy;
-    U_TRY(dx.alloc((size_t)B * H * W * Cin * 4));
-    U_TRY(dy.alloc((size_t)B * Ho * Wo * Cout * 4));
-    U_TRY(hipMemcpy(dx.p, x, (size_t)B * H * W * Cin * 4, hipMemcpyHostToDevice));
+    const int ab = precision == 0;  // plain bf16 mode: bf16 activations on the device
+    const long long nx = (long long)B * H * W * Cin, ny = (long long)B * Ho * Wo * Cout;
+    DevBuf dx, dy, dxb, dyb;
+    U_TRY(dx.alloc((size_t)nx * 4));
+    U_TRY(dy.alloc((size_t)ny * 4));
+    U_TRY(hipMemcpy(dx.p, x, (size_t)nx * 4, hipMemcpyHostToDevice));
+    if (ab) {
+        U_TRY(dxb.alloc((size_t)nx * 2));
+        U_TRY(dyb.alloc((size_t)ny * 2));
+        U_TRY(qmri::cast_launch(dx.p, nx, dxb.p, 1, nullptr));
+    }
     std::vector<float> wk, sc, sh;
     if (scale && shift) {
         sc.assign(scale, scale + Cout);
@@ -481,9 +494,13 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         else
             pack_conv3x3(kernel, Cin, Cout, L, wk);
         U_TRY(L.upload(wk, bias, sc.empty() ? nullptr : &sc, sc.empty() ? nullptr : &sh));
-        auto k = conv_args(L, dx.as<float>(), Cin, 0, B, H, W, dy.as<float>(), Cout, 0, Ho, Wo, transposed ? 2 : 1,
-                           transposed ? 2 : 1, ph >> 1, ph & 1);
+        auto k = conv_args(L, ab ? dxb.p : dx.p, Cin, 0, B, H, W, ab ? dyb.p : dy.p, Cout, 0, Ho, Wo,
+                           transposed ? 2 : 1, transposed ? 2 : 1, ph >> 1, ph & 1);
         U_TRY(qmri::conv_igemm_launch(k, precision != 0, nullptr));
+        U_TRY(hipDeviceSynchronize());
+    }
+    if (ab) {
+        U_TRY(qmri::cast_launch(dyb.p, ny, dy.p, 0, nullptr));
         U_TRY(hipDeviceSynchronize());
     }
     U_TRY(hipMemcpy(y, dy.p, (size_t)B * Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));

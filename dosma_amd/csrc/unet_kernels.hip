@@ -68,8 +68,10 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, bool SPLIT3>
+template <int BN, bool SPLIT3, typename AT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
+    constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
+    static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     using C = TileCfg<BN>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         h_dst[r] = hp < C::HALO_PIX ? (hp * kLdsRow + grp * 8) * 2 : -1;
     }
 
-    float4 rh0[C::HALO_PAIRS], rh1[C::HALO_PAIRS];
+    float4 rh0[C::HALO_PAIRS], rh1[C::HALO_PAIRS];  // fp32 activations: 8 channels = 2 x float4
+    bf16x8 rhb[C::HALO_PAIRS];                       // bf16 activations: 8 channels = 16 bytes
     bf16x8 rb_hi[C::B_PAIRS], rb_lo[C::B_PAIRS];
     const int ntaps = A.ntaps;
     const int K = ntaps * A.Cin;
@@ -127,21 +130,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #define QMRI_LOAD_HALO(c0_)                                                                        \
     _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                    \
         const bool ok_ = h_src[r] >= 0;                                                            \
-        const float *p_ = A.x + (ok_ ? h_src[r] : 0) + (c0_);                                      \
-        const float4 v0_ = *reinterpret_cast<const float4 *>(p_);                                  \
-        const float4 v1_ = *reinterpret_cast<const float4 *>(p_ + 4);                              \
-        rh0[r] = ok_ ? v0_ : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
-        rh1[r] = ok_ ? v1_ : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+        const AT *p_ = static_cast<const AT *>(A.x) + (ok_ ? h_src[r] : 0) + (c0_);                \
+        if constexpr (ACT_BF16) {                                                                  \
+            const bf16x8 v_ = *reinterpret_cast<const bf16x8 *>(p_);                               \
+            bf16x8 z_;                                                                             \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) z_[q] = static_cast<__bf16>(0.f);        \
+            rhb[r] = ok_ ? v_ : z_;                                                                \
+        } else {                                                                                   \
+            const float4 v0_ = *reinterpret_cast<const float4 *>(p_);                              \
+            const float4 v1_ = *reinterpret_cast<const float4 *>(p_ + 4);                          \
+            rh0[r] = ok_ ? v0_ : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+            rh1[r] = ok_ ? v1_ : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+        }                                                                                          \
     }
 #define QMRI_STORE_HALO(buf_)                                                                      \
     {                                                                                              \
         unsigned char *base_ = halo_base + (buf_) * NPLANES * HALO_BYTES;                          \
         _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                \
             if (h_dst[r] >= 0) {                                                                   \
-                bf16x8 hi_, lo_;                                                                   \
-                split_bf16(rh0[r], rh1[r], hi_, lo_, SPLIT3);                                      \
-                *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = hi_;                               \
-                if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + HALO_BYTES + h_dst[r]) = lo_;      \
+                if constexpr (ACT_BF16) {                                                          \
+                    *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = rhb[r];                        \
+                } else {                                                                           \
+                    bf16x8 hi_, lo_;                                                               \
+                    split_bf16(rh0[r], rh1[r], hi_, lo_, SPLIT3);                                  \
+                    *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = hi_;                           \
+                    if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + HALO_BYTES + h_dst[r]) = lo_;  \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
     }
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
                     float v = acc[i][j][e] + bias;
                     if (A.relu) v = fmaxf(v, 0.f);
                     v = v * scale + shift;
-                    A.y[(long long)pix * A.ldy + A.yoff + n] = v;
+                    static_cast<AT *>(A.y)[(long long)pix * A.ldy + A.yoff + n] = static_cast<AT>(v);
                 }
             }
         }
@@ -276,6 +290,7 @@ static size_t conv_lds_bytes(int split3) {
 }
 
 hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
+    // precision 0 (plain bf16): bf16 activations in HBM;  precision 1 (split-bf16 x3): fp32 activations
     ConvKArgs k = k0;
     const int bn = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
@@ -284,9 +299,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     k.tiles_x = (k.W + kTW - 1) / kTW;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
-#define QMRI_CONV_CASE(BN_, S3_)                                                                    \
+#define QMRI_CONV_CASE(BN_, S3_, AT_)                                                                    \
     do {                                                                                            \
-        auto fn = conv_igemm_kernel<BN_, S3_>;                                                      \
+        auto fn = conv_igemm_kernel<BN_, S3_, AT_>;                                                    \
         const size_t lds = conv_lds_bytes<BN_>(S3_);                                                \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
@@ -296,23 +311,50 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);                                    \
     } while (0)
     if (bn == 128) {
-        if (split3) QMRI_CONV_CASE(128, true); else QMRI_CONV_CASE(128, false);
+        if (split3) QMRI_CONV_CASE(128, true, float); else QMRI_CONV_CASE(128, false, __bf16);
     } else if (bn == 64) {
-        if (split3) QMRI_CONV_CASE(64, true); else QMRI_CONV_CASE(64, false);
+        if (split3) QMRI_CONV_CASE(64, true, float); else QMRI_CONV_CASE(64, false, __bf16);
     } else {
-        if (split3) QMRI_CONV_CASE(32, true); else QMRI_CONV_CASE(32, false);
+        if (split3) QMRI_CONV_CASE(32, true, float); else QMRI_CONV_CASE(32, false, __bf16);
     }
 #undef QMRI_CONV_CASE
     return hipGetLastError();
 }
 
+// ---- activation load/store helpers (AT = float or __bf16) ------------------------------------------
+template <typename AT>
+__device__ __forceinline__ void load4(const AT *p, float (&v)[4]) {
+    if constexpr (sizeof(AT) == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        const bf16x4 q = *reinterpret_cast<const bf16x4 *>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = static_cast<float>(q[i]);
+    }
+}
+template <typename AT>
+__device__ __forceinline__ void store4(AT *p, const float (&v)[4]) {
+    if constexpr (sizeof(AT) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = static_cast<__bf16>(v[i]);
+        *reinterpret_cast<bf16x4 *>(p) = q;
+    }
+}
+
 // ---- first layer: Conv2D(C, 3x3, SAME) on ONE input channel + bias + ReLU (fp32 VALU) ---------------
-// x [B][H][W] fp32; w [9][Cout] fp32 (tap-major); y NHWC with pixel stride ldy / channel offset yoff.
+// x [B][H][W] fp32; w [9][Cout] fp32 (tap-major); y NHWC (AT) with pixel stride ldy / channel offset yoff.
 // One thread = one pixel x 8 output channels.
+template <typename AT>
 __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float *__restrict__ x, int B, int H, int W,
                                                          const float *__restrict__ w,
                                                          const float *__restrict__ bias, int Cout,
-                                                         float *__restrict__ y, long long ldy, int yoff) {
+                                                         AT *__restrict__ y, long long ldy, int yoff) {
     const int groups = Cout / 8;
     const long long total = (long long)B * H * W * groups;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -338,28 +380,33 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float *__restrict
                     for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
                 }
             }
-        float4 o0 = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-        float4 o1 = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
-        float *dst = y + pix * ldy + yoff + g * 8;
-        *reinterpret_cast<float4 *>(dst) = o0;
-        *reinterpret_cast<float4 *>(dst + 4) = o1;
+        const float o0[4] = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+        const float o1[4] = {fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f)};
+        AT *dst = y + pix * ldy + yoff + g * 8;
+        store4(dst, o0);
+        store4(dst + 4, o1);
     }
 }
 
 hipError_t conv3x3_c1_launch(const float *x, int B, int H, int W, const float *w, const float *bias,
-                             int Cout, float *y, long long ldy, int yoff, hipStream_t stream) {
+                             int Cout, void *y, long long ldy, int yoff, int act_bf16, hipStream_t stream) {
     const long long total = (long long)B * H * W * (Cout / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 65535 * 4) blocks = 65535 * 4;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, B, H, W, w, bias,
-                       Cout, y, ldy, yoff);
+    if (act_bf16)
+        hipLaunchKernelGGL(conv3x3_c1_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, x, B, H, W,
+                           w, bias, Cout, static_cast<__bf16 *>(y), ldy, yoff);
+    else
+        hipLaunchKernelGGL(conv3x3_c1_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, x, B, H, W,
+                           w, bias, Cout, static_cast<float *>(y), ldy, yoff);
     return hipGetLastError();
 }
 
-// ---- MaxPooling2D(2x2): NHWC fp32, input with pixel stride / channel offset, output compact ---------
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ x, long long ldx, int xoff,
-                                                       int B, int H, int W, int C, float *__restrict__ y) {
+// ---- MaxPooling2D(2x2): NHWC, input with pixel stride / channel offset, output compact ---------------
+template <typename AT>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const AT *__restrict__ x, long long ldx, int xoff,
+                                                       int B, int H, int W, int C, AT *__restrict__ y) {
     const int Ho = H / 2, Wo = W / 2, cg = C / 4;
     const long long total = (long long)B * Ho * Wo * cg;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -370,68 +417,113 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__
         const long long t = p / Wo;
         const int yo = (int)(t % Ho);
         const long long b = t / Ho;
-        const float *src = x + ((b * H + 2 * yo) * W + 2 * xo) * ldx + xoff + c;
-        const float4 v00 = *reinterpret_cast<const float4 *>(src);
-        const float4 v01 = *reinterpret_cast<const float4 *>(src + ldx);
-        const float4 v10 = *reinterpret_cast<const float4 *>(src + (long long)W * ldx);
-        const float4 v11 = *reinterpret_cast<const float4 *>(src + (long long)W * ldx + ldx);
-        float4 o;
-        o.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
-        o.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
-        o.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
-        o.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-        *reinterpret_cast<float4 *>(y + p * C + c) = o;
+        const AT *src = x + ((b * H + 2 * yo) * W + 2 * xo) * ldx + xoff + c;
+        float v00[4], v01[4], v10[4], v11[4], o[4];
+        load4(src, v00);
+        load4(src + ldx, v01);
+        load4(src + (long long)W * ldx, v10);
+        load4(src + (long long)W * ldx + ldx, v11);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaxf(v00[i], v01[i]), fmaxf(v10[i], v11[i]));
+        store4(y + p * C + c, o);
     }
 }
 
-hipError_t maxpool2_launch(const float *x, long long ldx, int xoff, int B, int H, int W, int C, float *y,
-                           hipStream_t stream) {
+hipError_t maxpool2_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y,
+                           int act_bf16, hipStream_t stream) {
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 65535 * 4) blocks = 65535 * 4;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, xoff, B, H, W,
-                       C, y);
+    if (act_bf16)
+        hipLaunchKernelGGL(maxpool2_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           static_cast<const __bf16 *>(x), ldx, xoff, B, H, W, C, static_cast<__bf16 *>(y));
+    else
+        hipLaunchKernelGGL(maxpool2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           static_cast<const float *>(x), ldx, xoff, B, H, W, C, static_cast<float *>(y));
     return hipGetLastError();
 }
 
 // ---- head: Conv2D(n_classes <= 4, 1x1) -> logits fp32 [pix][NC] and mask u8 [pix][NC] = logit > 0 -----
-__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, long long npix, int Cin,
+// Cin/4 lanes cooperate on one pixel (each reads 4 consecutive channels -> a pixel's channels are one
+// contiguous, coalesced segment), partial dot products are reduced with wave shuffles.
+template <typename AT, int LPP /*lanes per pixel = Cin/4: 8 for Cin = 32*/>
+__global__ __launch_bounds__(256) void head_kernel(const AT *__restrict__ x, long long npix, int Cin,
                                                    const float *__restrict__ w /*[Cin][NC]*/,
                                                    const float *__restrict__ bias, int NC,
                                                    float *__restrict__ logits,
                                                    unsigned char *__restrict__ mask) {
-    __shared__ float sw[256 * 4 + 4];
-    for (int i = threadIdx.x; i < Cin * NC; i += blockDim.x) sw[i] = w[i];
-    if (threadIdx.x < NC) sw[Cin * NC + threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
-         p += (long long)gridDim.x * blockDim.x) {
-        float acc[4];
-        for (int c = 0; c < 4; ++c) acc[c] = c < NC ? sw[Cin * NC + c] : 0.f;
-        const float *src = x + p * Cin;
-        for (int k = 0; k < Cin; k += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(src + k);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
+    const int sub = threadIdx.x % LPP;
+    float wr[4][4];  // this lane's 4 channels x up to 4 classes
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                for (int c = 0; c < NC; ++c) acc[c] = fmaf(vv[q], sw[(k + q) * NC + c], acc[c]);
-        }
-        for (int c = 0; c < NC; ++c) {
-            if (logits) logits[p * NC + c] = acc[c];
-            if (mask) mask[p * NC + c] = acc[c] > 0.f ? 1 : 0;  // sigmoid(z) > 0.5  <=>  z > 0
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wr[q][c] = c < NC ? w[(sub * 4 + q) * NC + c] : 0.f;
+    const long long ppb = 256 / LPP;  // pixels per block iteration
+    for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / LPP; p < npix; p += (long long)gridDim.x * ppb) {
+        float v[4];
+        load4(x + p * Cin + sub * 4, v);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[q], wr[q][c], acc[c]);
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+        if (sub < NC) {
+            const float z = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + bias[sub];
+            if (logits) logits[p * NC + sub] = z;
+            if (mask) mask[p * NC + sub] = z > 0.f ? 1 : 0;  // sigmoid(z) > 0.5  <=>  z > 0
         }
     }
 }
 
-hipError_t head_launch(const float *x, long long npix, int Cin, const float *w, const float *bias, int NC,
-                       float *logits, unsigned char *mask, hipStream_t stream) {
-    if (NC > 4 || Cin > 256 || Cin % 4) return hipErrorInvalidValue;
-    long long blocks = (npix + 255) / 256;
-    if (blocks > 65535 * 4) blocks = 65535 * 4;
+hipError_t head_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC,
+                       float *logits, unsigned char *mask, int act_bf16, hipStream_t stream) {
+    if (NC > 4 || (Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256)) return hipErrorInvalidValue;
+    long long blocks = (npix * (Cin / 4) + 255) / 256;
+    if (blocks > 65535 * 8) blocks = 65535 * 8;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, npix, Cin, w, bias, NC,
-                       logits, mask);
+#define QMRI_HEAD(LPP_)                                                                                \
+    do {                                                                                               \
+        if (act_bf16)                                                                                  \
+            hipLaunchKernelGGL((head_kernel<__bf16, LPP_>), dim3((unsigned)blocks), dim3(256), 0, stream, \
+                               static_cast<const __bf16 *>(x), npix, Cin, w, bias, NC, logits, mask);   \
+        else                                                                                           \
+            hipLaunchKernelGGL((head_kernel<float, LPP_>), dim3((unsigned)blocks), dim3(256), 0, stream,  \
+                               static_cast<const float *>(x), npix, Cin, w, bias, NC, logits, mask);    \
+    } while (0)
+    if (Cin == 32) QMRI_HEAD(8);
+    else if (Cin == 64) QMRI_HEAD(16);
+    else if (Cin == 128) QMRI_HEAD(32);
+    else QMRI_HEAD(64);
+#undef QMRI_HEAD
+    return hipGetLastError();
+}
+
+// ---- dtype casts (operator-level host entry in bf16 mode) ------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float *__restrict__ x, long long n, __bf16 *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        y[i] = static_cast<__bf16>(x[i]);
+}
+__global__ void cast_bf16_f32_kernel(const __bf16 *__restrict__ x, long long n, float *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        y[i] = static_cast<float>(x[i]);
+}
+hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    if (to_bf16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           static_cast<const float *>(x), n, static_cast<__bf16 *>(y));
+    else
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           static_cast<const __bf16 *>(x), n, static_cast<float *>(y));
     return hipGetLastError();
 }
 

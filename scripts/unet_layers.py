@@ -1,0 +1,34 @@
+"""Summarise a rocprofv3 kernel trace of scripts/prof_unet.py: per-layer time and TFLOP/s of the last forward batch."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+k = [r for r in rows if 'qmri::' in r['Kernel_Name'] and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
+# one forward batch = 1 c1 + 26 igemm convs... find last head kernel and go back to the previous head
+heads = [i for i, r in enumerate(k) if 'head_kernel' in r['Kernel_Name']]
+seg = k[heads[-2] + 1: heads[-1] + 1]
+nf = [32, 64, 128, 256, 512, 1024]
+# expected op list for flops
+ops = []
+H = 384
+for l in range(6):
+    h = H >> l
+    cin = 1 if l == 0 else nf[l - 1]
+    ops.append((f"down{l}.conv1", h * h * 9 * cin * nf[l]))
+    ops.append((f"down{l}.conv2", h * h * 9 * nf[l] * nf[l]))
+    if l < 5: ops.append((f"pool{l}", 0))
+for l in range(4, -1, -1):
+    h = H >> l
+    hin = h // 2
+    for ph, nt in enumerate((4, 2, 2, 1)):
+        ops.append((f"up{l}.deconv.p{ph}", hin * hin * nt * nf[l + 1] * nf[l]))
+    ops.append((f"up{l}.conv1", h * h * 9 * 2 * nf[l] * nf[l]))
+    ops.append((f"up{l}.conv2", h * h * 9 * nf[l] * nf[l]))
+ops.append(("head", H * H * 32 * 4))
+assert len(ops) == len(seg), (len(ops), len(seg))
+tot = 0
+for (name, macs), r in zip(ops, seg):
+    us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    tot += us
+    tf = 2 * macs * B / us / 1e6 if macs else 0
+    print(f"{name:18s} {us:8.0f} us  {tf:7.1f} TF  grid {r['Grid_Size_X']:>9}x{r['Grid_Size_Y']} lds {r['LDS_Block_Size']} vgpr {r['VGPR_Count']}+{r['Accum_VGPR_Count']}")
+print("total us", tot, "-> slices/s", B / tot * 1e6)

@@ -83,6 +83,14 @@ struct ConvKArgs {
     int yoff;
     int Ho, Wo;          // output image size
     int sy, sx, py, px;  // output pixel = (y*sy + py, x*sx + px)
+    // fused consumers of the finished tile (all nullable)
+    void *pool_y;        // MaxPooling2D(2x2) of the output, compact NHWC with pool_ld channels per pixel
+    int pool_ld;
+    int head_nc;         // 1x1 head: classes
+    const float *head_w; // [Cout][head_nc]
+    const float *head_b; // [head_nc]
+    float *logits;       // [pixels][head_nc]
+    unsigned char *mask; // [pixels][head_nc]  (logit > 0)
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
 hipError_t conv3x3_c1_launch(const float *x, int B, int H, int W, const float *w, const float *bias,

@@ -366,8 +366,9 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
             // block output (post-BN) goes to the 2nd half of this level's concat buffer = the skip
             void *cat = U->cat[l]->p;
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, cat, 2 * C, C, H, W, 1, 1, 0, 0);
+            k.pool_y = U->pool[l + 1]->p;  // MaxPooling2D fused into the producing epilogue
+            k.pool_ld = C;
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
-            U_TRY(qmri::maxpool2_launch(cat, 2 * C, C, Bt, H, W, C, U->pool[l + 1]->p, ab, st));
         } else {
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
@@ -388,11 +389,21 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
         U_TRY(qmri::conv_igemm_launch(k1, s3, st));
         void *out = U->upout[l]->p;
         auto k2 = conv_args(*U->up2[l], t1, C, 0, Bt, H, W, out, C, 0, H, W, 1, 1, 0, 0);
+        const bool fuse_head = l == 0 && C == 32;  // the whole channel run of a pixel is in one tile
+        if (fuse_head) {
+            k2.y = nullptr;  // the last feature map is only consumed by the head: never written to HBM
+            k2.head_w = U->head_w.as<float>();
+            k2.head_b = U->head_b.as<float>();
+            k2.head_nc = U->ncls;
+            k2.logits = logits;
+            k2.mask = mask;
+        }
         U_TRY(qmri::conv_igemm_launch(k2, s3, st));
         src = out;
+        if (l == 0 && !fuse_head)
+            U_TRY(qmri::head_launch(src, (long long)Bt * U->H * U->W, U->nf[0], U->head_w.as<float>(),
+                                    U->head_b.as<float>(), U->ncls, logits, mask, ab, st));
     }
-    U_TRY(qmri::head_launch(src, (long long)Bt * U->H * U->W, U->nf[0], U->head_w.as<float>(),
-                            U->head_b.as<float>(), U->ncls, logits, mask, ab, st));
     return QMRI_OK;
 }
 

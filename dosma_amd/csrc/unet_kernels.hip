@@ -37,9 +37,11 @@ constexpr int kTW = 16;         // output tile width (pixels)
 // chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
 // LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
 // fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
-template <int BN>
+template <int BN, bool WALL>
 struct TileCfg {
-    static constexpr int TH = BN == 128 ? 8 : 16;
+    // WALL (small BN): the weights of ALL taps of a chunk are staged at once -> 2 barriers per chunk
+    // instead of one per tap (at BN <= 64 a tap is only 2-4 MFMAs per wave, less than a barrier costs)
+    static constexpr int TH = (BN == 128 || WALL) ? 8 : 16;
     static constexpr int BM = TH * kTW;
     static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
     static constexpr int WAVES_M = 4 / WAVES_N;
@@ -48,6 +50,7 @@ struct TileCfg {
     static constexpr int HALO_PIX = (TH + 2) * (kTW + 2);
     static constexpr int HALO_PAIRS = (HALO_PIX * 4 + 255) / 256;  // (pixel, 8-channel group) per thread
     static constexpr int B_PAIRS = (BN * 4 + 255) / 256;
+    static constexpr int WALL_PAIRS = (9 * BN * 4 + 255) / 256;
 };
 
 __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo,
@@ -72,14 +75,15 @@ template <int BN, bool SPLIT3, typename AT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
-    using C = TileCfg<BN>;
+    constexpr bool WALL = BN <= 64 && !SPLIT3;
+    using C = TileCfg<BN, WALL>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *halo_base = smem;                                  // [2][NPLANES][HALO_BYTES]
     unsigned char *w_base = smem + 2 * NPLANES * HALO_BYTES;          // [2][NPLANES][W_BYTES]
-    int *rowpix = reinterpret_cast<int *>(w_base + 2 * NPLANES * W_BYTES);  // [BM] output pixel or -1
+    int *rowpix = reinterpret_cast<int *>(w_base + (WALL ? 9 : 2 * NPLANES) * W_BYTES);  // [BM] output pixel or -1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 
     float4 rh0[C::HALO_PAIRS], rh1[C::HALO_PAIRS];  // fp32 activations: 8 channels = 2 x float4
     bf16x8 rhb[C::HALO_PAIRS];                       // bf16 activations: 8 channels = 16 bytes
-    bf16x8 rb_hi[C::B_PAIRS], rb_lo[C::B_PAIRS];
+    bf16x8 rb_hi[WALL ? C::WALL_PAIRS : C::B_PAIRS], rb_lo[C::B_PAIRS];
     const int ntaps = A.ntaps;
     const int K = ntaps * A.Cin;
 
@@ -183,6 +187,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         }                                                                                          \
     }
 
+    // WALL: all taps of chunk `ch_`: tap-major [ntaps][BN][32]
+#define QMRI_LOAD_WALL(ch_)                                                                        \
+    _Pragma("unroll") for (int r = 0; r < C::WALL_PAIRS; ++r) {                                    \
+        const int idx_ = tid + r * 256;                                                            \
+        if (idx_ < ntaps * BN * 4) {                                                               \
+            const int tap_ = idx_ / (BN * 4), rem_ = idx_ - tap_ * (BN * 4);                       \
+            const long long off_ = (long long)(n0 + (rem_ >> 2)) * K +                             \
+                                   (long long)((ch_) * ntaps + tap_) * kBK + (rem_ & 3) * 8;       \
+            rb_hi[r] = *reinterpret_cast<const bf16x8 *>(A.w_hi + off_);                           \
+        }                                                                                          \
+    }
+#define QMRI_STORE_WALL()                                                                          \
+    _Pragma("unroll") for (int r = 0; r < C::WALL_PAIRS; ++r) {                                    \
+        const int idx_ = tid + r * 256;                                                            \
+        if (idx_ < ntaps * BN * 4) {                                                               \
+            const int off_ = ((idx_ >> 2) * kLdsRow + (idx_ & 3) * 8) * 2;                         \
+            *reinterpret_cast<bf16x8 *>(w_base + off_) = rb_hi[r];                                 \
+        }                                                                                          \
+    }
+
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
     for (int i = 0; i < C::TM; ++i)
@@ -202,23 +226,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     const int chunks = A.Cin / kBK;
     const int steps = chunks * ntaps;
     QMRI_LOAD_HALO(0)
-    QMRI_LOAD_W(0)
+    if constexpr (WALL) {
+        QMRI_LOAD_WALL(0)
+    } else {
+        QMRI_LOAD_W(0)
+    }
     int step = 0;
     for (int ch = 0; ch < chunks; ++ch) {
         const int hbuf = ch & 1;
         QMRI_STORE_HALO(hbuf)
-        if (ch + 1 < chunks) {
-            QMRI_LOAD_HALO((ch + 1) * kBK)
-        }  // next chunk's halo in flight under 9 taps of MFMA
+        if constexpr (WALL) {
+            __syncthreads();  // every wave is done reading the previous chunk's weights
+            QMRI_STORE_WALL()
+            __syncthreads();
+            if (ch + 1 < chunks) {
+                QMRI_LOAD_HALO((ch + 1) * kBK)
+                QMRI_LOAD_WALL(ch + 1)
+            }
+        } else {
+            if (ch + 1 < chunks) {
+                QMRI_LOAD_HALO((ch + 1) * kBK)
+            }  // next chunk's halo in flight under 9 taps of MFMA
+        }
         const unsigned char *hb = halo_base + hbuf * NPLANES * HALO_BYTES;
         for (int t = 0; t < ntaps; ++t, ++step) {
-            const int wbuf = step & 1;
-            QMRI_STORE_W(wbuf)
-            __syncthreads();
-            if (step + 1 < steps) {
-                QMRI_LOAD_W(step + 1)
+            const unsigned char *wb;
+            if constexpr (WALL) {
+                wb = w_base + t * W_BYTES;
+            } else {
+                const int wbuf = step & 1;
+                QMRI_STORE_W(wbuf)
+                __syncthreads();
+                if (step + 1 < steps) {
+                    QMRI_LOAD_W(step + 1)
+                }
+                wb = w_base + wbuf * NPLANES * W_BYTES;
             }
-            const unsigned char *wb = w_base + wbuf * NPLANES * W_BYTES;
             const int code = (int)((A.taps >> (4 * t)) & 0xF);  // (dy+1) | (dx+1) << 2
             const int shift = ((code & 3) - 1) * (kTW + 2) + ((code >> 2) - 1);
 #pragma unroll
@@ -251,11 +294,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         }
     }
 
-    // ---- epilogue: y = scale * relu(acc + bias) + shift, written NHWC (32 consecutive channels per
-    // half-wave -> 128-byte segments) ----
+    // ---- epilogue: y = scale * relu(acc + bias) + shift.  The tile is transposed through LDS so that the
+    // global stores are 16 bytes per lane over each pixel's contiguous channel run (a lane of the MFMA
+    // C layout owns one channel of 16 different pixels: storing from there would be 2-4 B per lane).
+    // Optional fused consumers of the finished tile, all from LDS:
+    //   * MaxPooling2D(2x2) of the tile (oaiunet2d.py:234-243) -> A.pool_y (the next level's input);
+    //   * the 1x1 classification head + sigmoid threshold (oaiunet2d.py:285, 306) -> logits / mask.
+    __syncthreads();  // every wave is done reading the halo / weight buffers: reuse them as the out tile
+    AT *otile = reinterpret_cast<AT *>(smem);                       // [BM][BN]
+    float *hw = reinterpret_cast<float *>(smem + C::BM * BN * sizeof(AT));  // head weights [BN][NC] + bias
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + (wn * C::TN + j) * 32 + (lane & 31);
+        const int col = (wn * C::TN + j) * 32 + (lane & 31);
+        const int n = n0 + col;
         const float bias = A.bias ? A.bias[n] : 0.f;
         const float scale = A.scale ? A.scale[n] : 1.f;
         const float shift = A.shift ? A.shift[n] : 0.f;
@@ -265,13 +316,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + (e & 3) + 8 * (e >> 2);
-                const int pix = rowpix[row];
-                if (pix >= 0) {
-                    float v = acc[i][j][e] + bias;
-                    if (A.relu) v = fmaxf(v, 0.f);
-                    v = v * scale + shift;
-                    static_cast<AT *>(A.y)[(long long)pix * A.ldy + A.yoff + n] = static_cast<AT>(v);
+                float v = acc[i][j][e] + bias;
+                if (A.relu) v = fmaxf(v, 0.f);
+                v = v * scale + shift;
+                otile[row * BN + col] = static_cast<AT>(v);
+            }
+        }
+    }
+    if (A.head_w) {
+        for (int i = tid; i < BN * A.head_nc + A.head_nc; i += 256)
+            hw[i] = i < BN * A.head_nc ? A.head_w[i] : A.head_b[i - BN * A.head_nc];
+    }
+    __syncthreads();
+    constexpr int CH = BN * (int)sizeof(AT) / 16;  // 16-byte chunks per pixel row of the tile
+    if (A.y) {
+        for (int idx = tid; idx < C::BM * CH; idx += 256) {
+            const int row = idx / CH, c = idx - row * CH;
+            const int pix = rowpix[row];
+            if (pix >= 0) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(otile) +
+                                                                 (size_t)row * BN * sizeof(AT) + c * 16);
+                unsigned char *dst = static_cast<unsigned char *>(A.y) +
+                                     ((long long)pix * A.ldy + A.yoff + n0) * (long long)sizeof(AT) + c * 16;
+                *reinterpret_cast<uint4 *>(dst) = v;
+            }
+        }
+    }
+    if (A.pool_y) {
+        constexpr int VPC = 16 / (int)sizeof(AT);  // values per 16-byte chunk
+        const int Hp = A.H >> 1, Wp = A.W >> 1;
+        for (int idx = tid; idx < (C::BM / 4) * CH; idx += 256) {
+            const int q = idx / CH, c = idx - q * CH;
+            const int qy = q / (kTW / 2), qx = q - qy * (kTW / 2);
+            const int yy = (y0 >> 1) + qy, xx = (x0 >> 1) + qx;
+            if (yy < Hp && xx < Wp) {
+                const int r00 = (2 * qy) * kTW + 2 * qx;
+                const AT *p0 = otile + (size_t)r00 * BN + c * VPC;
+                AT o[VPC];
+#pragma unroll
+                for (int k = 0; k < VPC; ++k) {
+                    const float m = fmaxf(fmaxf(static_cast<float>(p0[k]), static_cast<float>(p0[BN + k])),
+                                          fmaxf(static_cast<float>(p0[kTW * BN + k]),
+                                                static_cast<float>(p0[(kTW + 1) * BN + k])));
+                    o[k] = static_cast<AT>(m);
                 }
+                AT *dst = static_cast<AT *>(A.pool_y) +
+                          ((long long)(b * Hp + yy) * Wp + xx) * A.pool_ld + n0 + c * VPC;
+                *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
+            }
+        }
+    }
+    if (A.head_w) {
+        const int NC = A.head_nc;
+        for (int row = tid; row < C::BM; row += 256) {
+            const int pix = rowpix[row];
+            if (pix < 0) continue;
+            float z[4] = {hw[BN * NC + 0], NC > 1 ? hw[BN * NC + 1] : 0.f, NC > 2 ? hw[BN * NC + 2] : 0.f,
+                          NC > 3 ? hw[BN * NC + 3] : 0.f};
+            for (int k = 0; k < BN; ++k) {
+                const float v = static_cast<float>(otile[row * BN + k]);
+                for (int c = 0; c < NC; ++c) z[c] = fmaf(v, hw[k * NC + c], z[c]);
+            }
+            for (int c = 0; c < NC; ++c) {
+                if (A.logits) A.logits[(long long)pix * NC + c] = z[c];
+                if (A.mask) A.mask[(long long)pix * NC + c] = z[c] > 0.f ? 1 : 0;
             }
         }
     }
@@ -281,12 +389,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #undef QMRI_STORE_HALO
 #undef QMRI_LOAD_W
 #undef QMRI_STORE_W
+#undef QMRI_LOAD_WALL
+#undef QMRI_STORE_WALL
 
-template <int BN>
-static size_t conv_lds_bytes(int split3) {
-    using C = TileCfg<BN>;
-    const int planes = split3 ? 2 : 1;
-    return 2 * (size_t)planes * (C::HALO_PIX + BN) * kLdsRow * 2 + C::BM * sizeof(int);
+template <int BN, bool S3>
+static size_t conv_lds_bytes() {
+    constexpr bool WALL = BN <= 64 && !S3;
+    using C = TileCfg<BN, WALL>;
+    const int planes = S3 ? 2 : 1;
+    const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
+    const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
+    return halo + w + C::BM * sizeof(int);
 }
 
 hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
@@ -294,7 +407,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     ConvKArgs k = k0;
     const int bn = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
-    const int th = bn == 128 ? 8 : 16;
+    if (k.head_w && (k.Cout != bn || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
+    if (k.pool_y && (k.sy != 1 || k.sx != 1 || (k.H & 1) || (k.W & 1))) return hipErrorInvalidValue;
+    const int th = (bn == 128 || !split3) ? 8 : 16;  // must match TileCfg<BN, WALL>::TH
     k.tiles_y = (k.H + th - 1) / th;
     k.tiles_x = (k.W + kTW - 1) / kTW;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
@@ -302,7 +417,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
 #define QMRI_CONV_CASE(BN_, S3_, AT_)                                                                    \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, S3_, AT_>;                                                    \
-        const size_t lds = conv_lds_bytes<BN_>(S3_);                                                \
+        const size_t lds = conv_lds_bytes<BN_, S3_>();                                              \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-k = [r for r in rows if 'qmri::' in r['Kernel_Name'] and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
+k = [r for r in rows if ('qmri::' in r['Kernel_Name'] or '_ZN4qmri' in r['Kernel_Name']) and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
 # one forward batch = 1 c1 + 26 igemm convs... find last head kernel and go back to the previous head
 heads = [i for i, r in enumerate(k) if 'head_kernel' in r['Kernel_Name']]
 seg = k[heads[-2] + 1: heads[-1] + 1]

@@ -367,19 +367,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         }
     }
     if (A.head_w) {
+        // BN/4 lanes per pixel, 4 channels each (a pixel's channels are one contiguous LDS run ->
+        // conflict-free), partial dot products combined with wave shuffles.
+        constexpr int LPP = BN / 4;
         const int NC = A.head_nc;
-        for (int row = tid; row < C::BM; row += 256) {
-            const int pix = rowpix[row];
-            if (pix < 0) continue;
-            float z[4] = {hw[BN * NC + 0], NC > 1 ? hw[BN * NC + 1] : 0.f, NC > 2 ? hw[BN * NC + 2] : 0.f,
-                          NC > 3 ? hw[BN * NC + 3] : 0.f};
-            for (int k = 0; k < BN; ++k) {
-                const float v = static_cast<float>(otile[row * BN + k]);
-                for (int c = 0; c < NC; ++c) z[c] = fmaf(v, hw[k * NC + c], z[c]);
+        const int sub = tid % LPP;
+        float wr[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wr[q][c] = c < NC ? hw[(sub * 4 + q) * NC + c] : 0.f;
+        for (int row = tid / LPP; row < C::BM; row += 256 / LPP) {
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = static_cast<float>(otile[row * BN + sub * 4 + q]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[c] = fmaf(v, wr[q][c], z[c]);
             }
-            for (int c = 0; c < NC; ++c) {
-                if (A.logits) A.logits[(long long)pix * NC + c] = z[c];
-                if (A.mask) A.mask[(long long)pix * NC + c] = z[c] > 0.f ? 1 : 0;
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], o, 64);
+            const int pix = rowpix[row];
+            if (pix >= 0 && sub < NC) {
+                const float zz = (sub == 0 ? z[0] : sub == 1 ? z[1] : sub == 2 ? z[2] : z[3]) + hw[BN * NC + sub];
+                if (A.logits) A.logits[(long long)pix * NC + sub] = zz;
+                if (A.mask) A.mask[(long long)pix * NC + sub] = zz > 0.f ? 1 : 0;
             }
         }
     }

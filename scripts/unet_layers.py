@@ -4,8 +4,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 k = [r for r in rows if ('qmri::' in r['Kernel_Name'] or '_ZN4qmri' in r['Kernel_Name']) and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
 # one forward batch = 1 c1 + 26 igemm convs... find last head kernel and go back to the previous head
-heads = [i for i, r in enumerate(k) if 'head_kernel' in r['Kernel_Name']]
-seg = k[heads[-2] + 1: heads[-1] + 1]
+n_ops = 2 * 6 + 5 * 6
+seg = k[-n_ops:]
 nf = [32, 64, 128, 256, 512, 1024]
 # expected op list for flops
 ops = []
@@ -15,7 +15,6 @@ for l in range(6):
     cin = 1 if l == 0 else nf[l - 1]
     ops.append((f"down{l}.conv1", h * h * 9 * cin * nf[l]))
     ops.append((f"down{l}.conv2", h * h * 9 * nf[l] * nf[l]))
-    if l < 5: ops.append((f"pool{l}", 0))
 for l in range(4, -1, -1):
     h = H >> l
     hin = h // 2
@@ -23,7 +22,6 @@ for l in range(4, -1, -1):
         ops.append((f"up{l}.deconv.p{ph}", hin * hin * nt * nf[l + 1] * nf[l]))
     ops.append((f"up{l}.conv1", h * h * 9 * 2 * nf[l] * nf[l]))
     ops.append((f"up{l}.conv2", h * h * 9 * nf[l] * nf[l]))
-ops.append(("head", H * H * 32 * 4))
 assert len(ops) == len(seg), (len(ops), len(seg))
 tot = 0
 for (name, macs), r in zip(ops, seg):

@@ -45,3 +45,28 @@ json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_counters.json"},
           open("profiles/r01_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# ---- UNet2D leg ----
+import collections, subprocess
+ut = os.path.join(src, "unet_stats", "u_kernel_trace.csv")
+if os.path.exists(ut):
+    shutil.copy(os.path.join(src, "unet_stats", "u_kernel_stats.csv"), f"profiles/{tag}_unet_kernel_stats.csv")
+    layers = subprocess.check_output([sys.executable, "scripts/unet_layers.py", ut]).decode()
+    open(f"profiles/{tag}_unet_layers.txt", "w").write(
+        "# rocprofv3 --kernel-trace of scripts/prof_unet.py (bf16, 384x384, batch 32): last forward batch\n" + layers)
+    rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
+            if "conv_igemm" in r["Kernel_Name"]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-42:]
+    agg = collections.Counter()
+    for r in rows:
+        if int(r["Dispatch_Id"]) in ids:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    gui = agg["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
+    u = {"tag": tag, "workload": "UNet2D forward, 32 slices of 384x384, plain bf16 mode, 42 conv_igemm dispatches",
+         "counters": dict(agg),
+         "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4),
+         "mfma_gflop_issued": agg["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / 1e9,
+         "mfma_gflop_algorithmic": 70.79 * 32,
+         "unet2d_bench": bench.get("unet2d")}
+    json.dump(u, open(f"profiles/{tag}_unet_counters.json", "w"), indent=1)
+    print(json.dumps({k: u[k] for k in ("MfmaUtil", "mfma_gflop_issued", "mfma_gflop_algorithmic")}))

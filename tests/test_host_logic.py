@@ -131,3 +131,38 @@ def test_medical_volume_shim_vs_reference():
         assert np.array_equal(a.volume, b.volume) and np.allclose(a.affine, b.affine)
     a, b = ours[1:, ::2, 1:4], ref[1:, ::2, 1:4]
     assert np.array_equal(a.volume, b.volume) and np.allclose(a.affine, b.affine)
+
+
+def test_quantitative_values_to_metrics():
+    """reference tests/core/test_quant_vals.py:52-174: exact counts / means per label, bounds `closed=`."""
+    from dosma_amd.quant_vals import QuantitativeValue, QuantitativeValueType, T1Rho, T2, T2Star
+
+    vol = np.zeros((4, 4, 2))
+    vol[:2] = 10.0
+    vol[2:] = 30.0
+    vol[0, 0, 0] = np.nan
+    vol[3, 3, 1] = 100.0
+    qv = T2(MedicalVolume(vol, np.eye(4)))
+    assert qv.qv_type == QuantitativeValueType.T2 and QuantitativeValue.get_qv("t2").NAME == "t2"
+    assert isinstance(QuantitativeValue.get_qv(1), T1Rho) and isinstance(QuantitativeValue.get_qv("t2_star"), T2Star)
+    with pytest.raises(ValueError):
+        QuantitativeValue.get_qv("nope")
+    with pytest.raises(TypeError):
+        T2(vol)
+    df = qv.to_metrics()
+    assert list(df["Category"]) == ["total"] and df["# Voxels"][0] == 31
+    labels = np.zeros((4, 4, 2), dtype=np.uint8)
+    labels[:2] = 1
+    labels[2:] = 2
+    df = qv.to_metrics(MedicalVolume(labels, np.eye(4)), labels={1: "a", 2: "b"})
+    assert list(df["Category"]) == ["a", "b", "total"]
+    assert list(df["# Voxels"]) == [15, 16, 31] and df["Mean"][0] == 10.0
+    df = qv.to_metrics(MedicalVolume(labels, np.eye(4)), bounds=(10, 30), closed="right")
+    assert list(df["# Voxels"]) == [0, 15, 15]  # 10 excluded (open on the left), 100 excluded
+    df = qv.to_metrics(MedicalVolume(labels, np.eye(4)), bounds=(10, 30), closed="both",
+                       fns={"max": lambda v: np.max(v) if v.size else np.nan})
+    assert list(df["# Voxels"]) == [15, 15, 30] and df["max"][1] == 30.0
+    qv.add_additional_volume("r2", MedicalVolume(np.ones((4, 4, 2)), np.eye(4)))
+    assert "r2" in qv.additional_volumes
+    with pytest.raises(TypeError):
+        qv.add_additional_volume("r2", np.ones(3))

@@ -73,6 +73,7 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, ntaps = 0;
     int dy[9] = {0}, dx[9] = {0};
     int relu = 0;
+    int deconv = 0;
     DevBuf w_hi, w_lo, bias, scale, shift;
     bool has_affine = false;
 
@@ -144,6 +145,28 @@ void pack_deconv_phase(const float *k, int Cin, int Cout, int py, int px, ConvLa
         }
 }
 
+// Conv2DTranspose 3x3 stride 2 SAME, all four phases fused: 9 taps in the order
+//   phase (py,px) = (0,0): (kh,kw) = (0,0) (0,2) (2,0) (2,2);  (0,1): (0,1) (2,1);  (1,0): (1,0) (1,2);  (1,1): (1,1)
+// with dy = (kh == 2 ? -1 : 0), dx = (kw == 2 ? -1 : 0).  Keras kernel (kh, kw, Cout, Cin).
+void pack_deconv_fused(const float *k, int Cin, int Cout, ConvLayer &L, std::vector<float> &wk) {
+    static const int KH[9] = {0, 0, 2, 2, 0, 2, 1, 1, 1};
+    static const int KW[9] = {0, 2, 0, 2, 1, 1, 0, 2, 1};
+    L.Cin = Cin;
+    L.Cout = Cout;
+    L.ntaps = 9;
+    L.deconv = 1;
+    wk.assign((size_t)Cout * 9 * Cin, 0.f);
+    for (int t = 0; t < 9; ++t) {
+        const int kh = KH[t], kw = KW[t];
+        L.dy[t] = kh == 2 ? -1 : 0;
+        L.dx[t] = kw == 2 ? -1 : 0;
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci)
+                wk[(size_t)co * 9 * Cin + ((size_t)(ci / 32) * 9 + t) * 32 + ci % 32] =
+                    k[(((size_t)kh * 3 + kw) * Cout + co) * Cin + ci];
+    }
+}
+
 qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int xoff, int B, int H, int W,
                           void *y, long long ldy, int yoff, int Ho, int Wo, int sy, int sx, int py, int px) {
     qmri::ConvKArgs k;
@@ -157,6 +180,7 @@ qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int 
     k.Cin = L.Cin;
     k.Cout = L.Cout;
     k.ntaps = L.ntaps;
+    k.deconv = L.deconv;
     k.taps = 0;
     for (int t = 0; t < L.ntaps; ++t)
         k.taps |= (unsigned long long)((L.dy[t] + 1) | ((L.dx[t] + 1) << 2)) << (4 * t);
@@ -183,7 +207,7 @@ struct Unet {
     std::vector<int> nf;
     DevBuf c1_w, c1_b;  // first layer fp32: [9][nf0], [nf0]
     std::vector<std::unique_ptr<ConvLayer>> down1, down2, up1, up2;  // index by level
-    std::vector<std::unique_ptr<ConvLayer>> updec;                   // [level*4 + phase]
+    std::vector<std::unique_ptr<ConvLayer>> updec;                   // [level]: fused 4-phase transposed conv
     DevBuf head_w, head_b;
     // activations (fp32 NHWC), index by level
     DevBuf in;
@@ -251,7 +275,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->down2.resize(d->depth);
     U->up1.resize(d->depth);
     U->up2.resize(d->depth);
-    U->updec.resize((size_t)d->depth * 4);
+    U->updec.resize((size_t)d->depth);
     std::vector<float> wk, sc, sh;
     for (int l = 0; l < d->depth; ++l) {
         const int C = U->nf[l];
@@ -280,11 +304,11 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         const int C = U->nf[l], Cup = U->nf[l + 1];
         const float *kd = T[ti], *bd = T[ti + 1], *k1 = T[ti + 2], *b1 = T[ti + 3], *k2 = T[ti + 4], *b2 = T[ti + 5];
         ti += 6;
-        for (int ph = 0; ph < 4; ++ph) {
-            auto &L = U->updec[(size_t)l * 4 + ph];
+        {
+            auto &L = U->updec[(size_t)l];
             L.reset(new ConvLayer);
             L->relu = 0;
-            pack_deconv_phase(kd, Cup, C, ph >> 1, ph & 1, *L, wk);
+            pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
         }
         U->up1[l].reset(new ConvLayer);
@@ -379,9 +403,8 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     for (int l = D - 2; l >= 0; --l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
         void *cat = U->cat[l]->p;
-        for (int ph = 0; ph < 4; ++ph) {
-            auto k = conv_args(*U->updec[(size_t)l * 4 + ph], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W,
-                               2, 2, ph >> 1, ph & 1);
+        {
+            auto k = conv_args(*U->updec[(size_t)l], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         }
         void *t1 = U->tmp[l]->p;
@@ -496,17 +519,16 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         sc.assign(scale, scale + Cout);
         sh.assign(shift, shift + Cout);
     }
-    const int nph = transposed ? 4 : 1;
-    for (int ph = 0; ph < nph; ++ph) {
+    {
         ConvLayer L;
         L.relu = relu;
         if (transposed)
-            pack_deconv_phase(kernel, Cin, Cout, ph >> 1, ph & 1, L, wk);
+            pack_deconv_fused(kernel, Cin, Cout, L, wk);
         else
             pack_conv3x3(kernel, Cin, Cout, L, wk);
         U_TRY(L.upload(wk, bias, sc.empty() ? nullptr : &sc, sc.empty() ? nullptr : &sh));
         auto k = conv_args(L, ab ? dxb.p : dx.p, Cin, 0, B, H, W, ab ? dyb.p : dy.p, Cout, 0, Ho, Wo,
-                           transposed ? 2 : 1, transposed ? 2 : 1, ph >> 1, ph & 1);
+                           transposed ? 2 : 1, transposed ? 2 : 1, 0, 0);
         U_TRY(qmri::conv_igemm_launch(k, precision != 0, nullptr));
         U_TRY(hipDeviceSynchronize());
     }

@@ -71,8 +71,13 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, bool SPLIT3, typename AT>
+template <int BN, bool SPLIT3, typename AT, bool DECONV>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
+    // DECONV: all four output phases of Conv2DTranspose(3x3, stride 2, SAME) in one pass: the 9 taps are
+    // ordered [phase (0,0): 4][phase (0,1): 2][phase (1,0): 2][phase (1,1): 1], each tap accumulates into
+    // its phase's accumulator, and the epilogue writes four interleaved output tiles.  The input halo is
+    // fetched once instead of four times and the launch count drops 4x.
+    constexpr int NPH = DECONV ? 4 : 1;
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
@@ -207,13 +212,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         }                                                                                          \
     }
 
-    f32x16 acc[C::TM][C::TN];
+    f32x16 acc[NPH][C::TM][C::TN];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j)
+        for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ph][i][j][e] = 0.f;
 
     // per-lane halo row of each MFMA row-tile (un-shifted): pixel (ly + 1, lx + 1)
     int a_row0[C::TM];
@@ -249,50 +256,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
             }  // next chunk's halo in flight under 9 taps of MFMA
         }
         const unsigned char *hb = halo_base + hbuf * NPLANES * HALO_BYTES;
-        for (int t = 0; t < ntaps; ++t, ++step) {
-            const unsigned char *wb;
-            if constexpr (WALL) {
-                wb = w_base + t * W_BYTES;
-            } else {
-                const int wbuf = step & 1;
-                QMRI_STORE_W(wbuf)
-                __syncthreads();
-                if (step + 1 < steps) {
-                    QMRI_LOAD_W(step + 1)
+#define QMRI_TAP_BODY(t_, ph_)                                                                          \
+        {                                                                                               \
+            const unsigned char *wb;                                                                    \
+            if constexpr (WALL) {                                                                       \
+                wb = w_base + (t_) * W_BYTES;                                                           \
+            } else {                                                                                    \
+                const int wbuf = step & 1;                                                              \
+                QMRI_STORE_W(wbuf)                                                                      \
+                __syncthreads();                                                                        \
+                if (step + 1 < steps) {                                                                 \
+                    QMRI_LOAD_W(step + 1)                                                               \
+                }                                                                                       \
+                wb = w_base + wbuf * NPLANES * W_BYTES;                                                 \
+            }                                                                                           \
+            const int code = (int)((A.taps >> (4 * (t_))) & 0xF); /* (dy+1) | (dx+1) << 2 */            \
+            const int shift = ((code & 3) - 1) * (kTW + 2) + ((code >> 2) - 1);                         \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
+                const int koff = (kk * 16 + (lane >> 5) * 8) * 2;                                       \
+                bf16x8 a_hi[C::TM], a_lo[C::TM], b_hi[C::TN], b_lo[C::TN];                              \
+                _Pragma("unroll") for (int i = 0; i < C::TM; ++i) {                                     \
+                    const int off = (a_row0[i] + shift) * kLdsRow * 2 + koff;                           \
+                    a_hi[i] = *reinterpret_cast<const bf16x8 *>(hb + off);                              \
+                    if (SPLIT3) a_lo[i] = *reinterpret_cast<const bf16x8 *>(hb + HALO_BYTES + off);     \
+                }                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < C::TN; ++j) {                                     \
+                    const int col = (wn * C::TN + j) * 32 + (lane & 31);                                \
+                    b_hi[j] = *reinterpret_cast<const bf16x8 *>(wb + col * kLdsRow * 2 + koff);         \
+                    if (SPLIT3)                                                                         \
+                        b_lo[j] = *reinterpret_cast<const bf16x8 *>(wb + W_BYTES + col * kLdsRow * 2 + koff); \
+                }                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < C::TM; ++i)                                       \
+                _Pragma("unroll") for (int j = 0; j < C::TN; ++j) {                                     \
+                    if (SPLIT3) {                                                                       \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[ph_][i][j], 0, 0, 0); \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[ph_][i][j], 0, 0, 0); \
+                    }                                                                                   \
+                    acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[ph_][i][j], 0, 0, 0); \
+                }                                                                                       \
+            }                                                                                           \
+            ++step;                                                                                     \
+        }
+        if constexpr (DECONV) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                constexpr int kPhaseOfTap[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+                switch (kPhaseOfTap[t]) {  // t is a compile-time constant after unrolling
+                    case 0: QMRI_TAP_BODY(t, 0) break;
+                    case 1: QMRI_TAP_BODY(t, NPH > 1 ? 1 : 0) break;
+                    case 2: QMRI_TAP_BODY(t, NPH > 2 ? 2 : 0) break;
+                    default: QMRI_TAP_BODY(t, NPH > 3 ? 3 : 0) break;
                 }
-                wb = w_base + wbuf * NPLANES * W_BYTES;
             }
-            const int code = (int)((A.taps >> (4 * t)) & 0xF);  // (dy+1) | (dx+1) << 2
-            const int shift = ((code & 3) - 1) * (kTW + 2) + ((code >> 2) - 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int koff = (kk * 16 + (lane >> 5) * 8) * 2;
-                bf16x8 a_hi[C::TM], a_lo[C::TM], b_hi[C::TN], b_lo[C::TN];
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i) {
-                    const int off = (a_row0[i] + shift) * kLdsRow * 2 + koff;
-                    a_hi[i] = *reinterpret_cast<const bf16x8 *>(hb + off);
-                    if (SPLIT3) a_lo[i] = *reinterpret_cast<const bf16x8 *>(hb + HALO_BYTES + off);
-                }
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) {
-                    const int col = (wn * C::TN + j) * 32 + (lane & 31);
-                    b_hi[j] = *reinterpret_cast<const bf16x8 *>(wb + col * kLdsRow * 2 + koff);
-                    if (SPLIT3) b_lo[j] = *reinterpret_cast<const bf16x8 *>(wb + W_BYTES + col * kLdsRow * 2 + koff);
-                }
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) {
-                        if (SPLIT3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-                    }
-            }
+        } else {
+            for (int t = 0; t < ntaps; ++t) QMRI_TAP_BODY(t, 0)
         }
     }
+#undef QMRI_TAP_BODY
 
     // ---- epilogue: y = scale * relu(acc + bias) + shift.  The tile is transposed through LDS so that the
     // global stores are 16 bytes per lane over each pixel's contiguous channel run (a lane of the MFMA
@@ -300,9 +320,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     // Optional fused consumers of the finished tile, all from LDS:
     //   * MaxPooling2D(2x2) of the tile (oaiunet2d.py:234-243) -> A.pool_y (the next level's input);
     //   * the 1x1 classification head + sigmoid threshold (oaiunet2d.py:285, 306) -> logits / mask.
-    __syncthreads();  // every wave is done reading the halo / weight buffers: reuse them as the out tile
     AT *otile = reinterpret_cast<AT *>(smem);                       // [BM][BN]
+    constexpr int CH = BN * (int)sizeof(AT) / 16;  // 16-byte chunks per pixel row of the tile
     float *hw = reinterpret_cast<float *>(smem + C::BM * BN * sizeof(AT));  // head weights [BN][NC] + bias
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+    // DECONV: phase ph = 2*py + px goes to output pixel (2y + py, 2x + px) = rowpix (phase 0) + py*Wo + px
+    const int ph_off = DECONV ? (ph >> 1) * A.Wo + (ph & 1) : 0;
+    __syncthreads();  // every wave is done reading the halo / weight buffers (or the previous phase's tile)
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
         const int col = (wn * C::TN + j) * 32 + (lane & 31);
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] + bias;
+                float v = acc[ph][i][j][e] + bias;
                 if (A.relu) v = fmaxf(v, 0.f);
                 v = v * scale + shift;
                 otile[row * BN + col] = static_cast<AT>(v);
@@ -328,7 +353,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
             hw[i] = i < BN * A.head_nc ? A.head_w[i] : A.head_b[i - BN * A.head_nc];
     }
     __syncthreads();
-    constexpr int CH = BN * (int)sizeof(AT) / 16;  // 16-byte chunks per pixel row of the tile
     if (A.y) {
         for (int idx = tid; idx < C::BM * CH; idx += 256) {
             const int row = idx / CH, c = idx - row * CH;
@@ -337,11 +361,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(otile) +
                                                                  (size_t)row * BN * sizeof(AT) + c * 16);
                 unsigned char *dst = static_cast<unsigned char *>(A.y) +
-                                     ((long long)pix * A.ldy + A.yoff + n0) * (long long)sizeof(AT) + c * 16;
+                                     ((long long)(pix + ph_off) * A.ldy + A.yoff + n0) * (long long)sizeof(AT) +
+                                     c * 16;
                 *reinterpret_cast<uint4 *>(dst) = v;
             }
         }
     }
+    }  // phases
     if (A.pool_y) {
         constexpr int VPC = 16 / (int)sizeof(AT);  // values per 16-byte chunk
         const int Hp = A.H >> 1, Wp = A.W >> 1;
@@ -419,7 +445,9 @@ static size_t conv_lds_bytes() {
 hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
     // precision 0 (plain bf16): bf16 activations in HBM;  precision 1 (split-bf16 x3): fp32 activations
     ConvKArgs k = k0;
-    const int bn = k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
+    // the fused transposed convolution keeps 4 accumulator sets: cap the channel tile at 64
+    const int bn = (k.Cout % 128 == 0 && !k.deconv) ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
+    if (k.deconv && (k.ntaps != 9 || k.sy != 2 || k.sx != 2 || k.pool_y || k.head_w)) return hipErrorInvalidValue;
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
     if (k.head_w && (k.Cout != bn || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
     if (k.pool_y && (k.sy != 1 || k.sx != 1 || (k.H & 1) || (k.W & 1))) return hipErrorInvalidValue;
@@ -428,9 +456,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     k.tiles_x = (k.W + kTW - 1) / kTW;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
-#define QMRI_CONV_CASE(BN_, S3_, AT_)                                                                    \
+#define QMRI_CONV_CASE(BN_, S3_, AT_, DC_)                                                                    \
     do {                                                                                            \
-        auto fn = conv_igemm_kernel<BN_, S3_, AT_>;                                                    \
+        auto fn = conv_igemm_kernel<BN_, S3_, AT_, DC_>;                                                  \
         const size_t lds = conv_lds_bytes<BN_, S3_>();                                              \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
@@ -439,12 +467,18 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         }                                                                                           \
         hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);                                    \
     } while (0)
-    if (bn == 128) {
-        if (split3) QMRI_CONV_CASE(128, true, float); else QMRI_CONV_CASE(128, false, __bf16);
+    if (k.deconv) {
+        if (bn == 64) {
+            if (split3) QMRI_CONV_CASE(64, true, float, true); else QMRI_CONV_CASE(64, false, __bf16, true);
+        } else {
+            if (split3) QMRI_CONV_CASE(32, true, float, true); else QMRI_CONV_CASE(32, false, __bf16, true);
+        }
+    } else if (bn == 128) {
+        if (split3) QMRI_CONV_CASE(128, true, float, false); else QMRI_CONV_CASE(128, false, __bf16, false);
     } else if (bn == 64) {
-        if (split3) QMRI_CONV_CASE(64, true, float); else QMRI_CONV_CASE(64, false, __bf16);
+        if (split3) QMRI_CONV_CASE(64, true, float, false); else QMRI_CONV_CASE(64, false, __bf16, false);
     } else {
-        if (split3) QMRI_CONV_CASE(32, true, float); else QMRI_CONV_CASE(32, false, __bf16);
+        if (split3) QMRI_CONV_CASE(32, true, float, false); else QMRI_CONV_CASE(32, false, __bf16, false);
     }
 #undef QMRI_CONV_CASE
     return hipGetLastError();

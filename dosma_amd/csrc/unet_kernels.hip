@@ -22,6 +22,8 @@
 //   whiten kernels     K13: (x - mean) / (std + eps) over the whole volume, fp64 reductions
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "qmri_internal.h"
 
 namespace qmri {
@@ -37,11 +39,11 @@ constexpr int kTW = 16;         // output tile width (pixels)
 // chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
 // LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
 // fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
-template <int BN, bool WALL>
+template <int BN, int TH_, bool WALL>
 struct TileCfg {
     // WALL (small BN): the weights of ALL taps of a chunk are staged at once -> 2 barriers per chunk
     // instead of one per tap (at BN <= 64 a tap is only 2-4 MFMAs per wave, less than a barrier costs)
-    static constexpr int TH = (BN == 128 || WALL) ? 8 : 16;
+    static constexpr int TH = TH_;
     static constexpr int BM = TH * kTW;
     static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
     static constexpr int WAVES_M = 4 / WAVES_N;
@@ -71,7 +73,7 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, bool SPLIT3, typename AT, bool DECONV>
+template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     // DECONV: all four output phases of Conv2DTranspose(3x3, stride 2, SAME) in one pass: the 9 taps are
     // ordered [phase (0,0): 4][phase (0,1): 2][phase (1,0): 2][phase (1,1): 1], each tap accumulates into
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
-    using C = TileCfg<BN, WALL>;
+    using C = TileCfg<BN, TH, WALL>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
@@ -432,34 +434,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #undef QMRI_LOAD_WALL
 #undef QMRI_STORE_WALL
 
-template <int BN, bool S3>
+template <int BN, int TH, bool S3>
 static size_t conv_lds_bytes() {
     constexpr bool WALL = BN <= 64 && !S3;
-    using C = TileCfg<BN, WALL>;
+    using C = TileCfg<BN, TH, WALL>;
     const int planes = S3 ? 2 : 1;
     const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
     return halo + w + C::BM * sizeof(int);
 }
 
+// rows of the output tile in plain-bf16 mode when the image height is a multiple of 16
+// (tunable per channel tile through QMRI_CONV_TH128 / _TH64 / _TH32 = 8 | 16 for experiments)
+static int conv_tile_rows(int bn) {
+    static int cfg[3] = {-1, -1, -1};
+    const int i = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+    if (cfg[i] < 0) {
+        const char *names[3] = {"QMRI_CONV_TH128", "QMRI_CONV_TH64", "QMRI_CONV_TH32"};
+        const int defaults[3] = {8, 8, 16};
+        const char *e = std::getenv(names[i]);
+        cfg[i] = e ? std::atoi(e) : defaults[i];
+        if (cfg[i] != 16) cfg[i] = 8;
+    }
+    return cfg[i];
+}
+
 hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
     // precision 0 (plain bf16): bf16 activations in HBM;  precision 1 (split-bf16 x3): fp32 activations
     ConvKArgs k = k0;
     // the fused transposed convolution keeps 4 accumulator sets: cap the channel tile at 64
-    const int bn = (k.Cout % 128 == 0 && !k.deconv) ? 128 : (k.Cout % 64 == 0 ? 64 : 32);
+    const int bn = k.deconv ? ((split3 && k.Cout % 64 == 0) ? 64 : 32)
+                            : (k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32));
     if (k.deconv && (k.ntaps != 9 || k.sy != 2 || k.sx != 2 || k.pool_y || k.head_w)) return hipErrorInvalidValue;
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
     if (k.head_w && (k.Cout != bn || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
     if (k.pool_y && (k.sy != 1 || k.sx != 1 || (k.H & 1) || (k.W & 1))) return hipErrorInvalidValue;
-    const int th = (bn == 128 || !split3) ? 8 : 16;  // must match TileCfg<BN, WALL>::TH
+    // tile height: 16 rows where the image height allows it and the accumulators fit, else 8
+    int th = 8;
+    if (!k.deconv) {
+        if (split3) th = bn == 128 ? 8 : 16;
+        else th = (k.H % 16 == 0) ? conv_tile_rows(bn) : 8;
+    }
     k.tiles_y = (k.H + th - 1) / th;
     k.tiles_x = (k.W + kTW - 1) / kTW;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
-#define QMRI_CONV_CASE(BN_, S3_, AT_, DC_)                                                                    \
+#define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_)                                                     \
     do {                                                                                            \
-        auto fn = conv_igemm_kernel<BN_, S3_, AT_, DC_>;                                                  \
-        const size_t lds = conv_lds_bytes<BN_, S3_>();                                              \
+        auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_>;                                       \
+        const size_t lds = conv_lds_bytes<BN_, TH_, S3_>();                                         \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -468,17 +491,19 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);                                    \
     } while (0)
     if (k.deconv) {
-        if (bn == 64) {
-            if (split3) QMRI_CONV_CASE(64, true, float, true); else QMRI_CONV_CASE(64, false, __bf16, true);
-        } else {
-            if (split3) QMRI_CONV_CASE(32, true, float, true); else QMRI_CONV_CASE(32, false, __bf16, true);
-        }
+        if (!split3) QMRI_CONV_CASE(32, 8, false, __bf16, true);
+        else if (bn == 64) QMRI_CONV_CASE(64, 8, true, float, true);
+        else QMRI_CONV_CASE(32, 8, true, float, true);
+    } else if (split3) {
+        if (bn == 128) QMRI_CONV_CASE(128, 8, true, float, false);
+        else if (bn == 64) QMRI_CONV_CASE(64, 16, true, float, false);
+        else QMRI_CONV_CASE(32, 16, true, float, false);
     } else if (bn == 128) {
-        if (split3) QMRI_CONV_CASE(128, true, float, false); else QMRI_CONV_CASE(128, false, __bf16, false);
+        if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {
-        if (split3) QMRI_CONV_CASE(64, true, float, false); else QMRI_CONV_CASE(64, false, __bf16, false);
+        if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);
     } else {
-        if (split3) QMRI_CONV_CASE(32, true, float, false); else QMRI_CONV_CASE(32, false, __bf16, false);
+        if (th == 16) QMRI_CONV_CASE(32, 16, false, __bf16, false); else QMRI_CONV_CASE(32, 8, false, __bf16, false);
     }
 #undef QMRI_CONV_CASE
     return hipGetLastError();

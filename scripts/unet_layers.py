@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 k = [r for r in rows if ('qmri::' in r['Kernel_Name'] or '_ZN4qmri' in r['Kernel_Name']) and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
 # one forward batch = 1 c1 + 26 igemm convs... find last head kernel and go back to the previous head
-n_ops = 2 * 6 + 5 * 6
+n_ops = 2 * 6 + 5 * 3
 seg = k[-n_ops:]
 nf = [32, 64, 128, 256, 512, 1024]
 # expected op list for flops
@@ -18,8 +18,7 @@ for l in range(6):
 for l in range(4, -1, -1):
     h = H >> l
     hin = h // 2
-    for ph, nt in enumerate((4, 2, 2, 1)):
-        ops.append((f"up{l}.deconv.p{ph}", hin * hin * nt * nf[l + 1] * nf[l]))
+    ops.append((f"up{l}.deconv", hin * hin * 9 * nf[l + 1] * nf[l]))
     ops.append((f"up{l}.conv1", h * h * 9 * 2 * nf[l] * nf[l]))
     ops.append((f"up{l}.conv2", h * h * 9 * nf[l] * nf[l]))
 assert len(ops) == len(seg), (len(ops), len(seg))

@@ -84,6 +84,10 @@ struct ConvKArgs {
     int yoff;
     int Ho, Wo;          // output image size
     int sy, sx, py, px;  // output pixel = (y*sy + py, x*sx + px)
+    // fused producer: the first layer Conv2D(32, 3x3)+ReLU on the 1-channel image [B][H][W] (nullable)
+    const float *c1_x;
+    const float *c1_w;   // [9][32] tap-major
+    const float *c1_b;   // [32]
     // fused consumers of the finished tile (all nullable)
     void *pool_y;        // MaxPooling2D(2x2) of the output, compact NHWC with pool_ld channels per pixel
     int pool_ld;

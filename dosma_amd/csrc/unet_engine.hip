@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -379,9 +380,14 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     for (int l = 0; l < D; ++l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
         void *t1 = U->tmp[l]->p;
+        // first layer computed inside conv2's halo stage: measured SLOWER (7.3k -> 6.6k slices/s: the VALU
+        // halo computation sits on the block's critical path), so it is off unless QMRI_FUSE_C1=1
+        static const bool want_fuse_c1 = std::getenv("QMRI_FUSE_C1") && std::atoi(std::getenv("QMRI_FUSE_C1")) != 0;
+        const bool fuse_c1 = want_fuse_c1 && l == 0 && C == 32 && D > 1;
         if (l == 0) {
-            U_TRY(qmri::conv3x3_c1_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(),
-                                          C, t1, C, 0, ab, st));
+            if (!fuse_c1)
+                U_TRY(qmri::conv3x3_c1_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(),
+                                              U->c1_b.as<float>(), C, t1, C, 0, ab, st));
         } else {
             auto k = conv_args(*U->down1[l], U->pool[l]->p, U->nf[l - 1], 0, Bt, H, W, t1, C, 0, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
@@ -392,6 +398,11 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, cat, 2 * C, C, H, W, 1, 1, 0, 0);
             k.pool_y = U->pool[l + 1]->p;  // MaxPooling2D fused into the producing epilogue
             k.pool_ld = C;
+            if (fuse_c1) {
+                k.c1_x = U->in.as<float>();
+                k.c1_w = U->c1_w.as<float>();
+                k.c1_b = U->c1_b.as<float>();
+            }
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         } else {
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, H, W, 1, 1, 0, 0);

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     unsigned char *halo_base = smem;                                  // [2][NPLANES][HALO_BYTES]
     unsigned char *w_base = smem + 2 * NPLANES * HALO_BYTES;          // [2][NPLANES][W_BYTES]
     int *rowpix = reinterpret_cast<int *>(w_base + (WALL ? 9 : 2 * NPLANES) * W_BYTES);  // [BM] output pixel or -1
+    float *c1w = reinterpret_cast<float *>(rowpix + C::BM);  // fused first layer: [9][32] weights + [32] bias
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,7 +235,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 
     const int chunks = A.Cin / kBK;
     const int steps = chunks * ntaps;
-    QMRI_LOAD_HALO(0)
+    if (A.c1_x) {
+        // Fused first layer (oaiunet2d.py:213-219 on the 1-channel input): the halo of THIS convolution's
+        // input is computed here -- relu(conv3x3(image) + bias), 32 channels -- straight into the staging
+        // registers, so the first feature map never goes to HBM.  Pixels outside the image are the zero
+        // padding of this convolution, not conv1 outputs.
+        for (int i = tid; i < 9 * 32 + 32; i += 256) c1w[i] = i < 288 ? A.c1_w[i] : A.c1_b[i - 288];
+        __syncthreads();
+        const int grp = tid & 3;
+        const float *img = A.c1_x + img_base;
+#pragma unroll
+        for (int r = 0; r < C::HALO_PAIRS; ++r) {
+            const int hp = (tid + r * 256) >> 2;
+            const int hy = hp / (kTW + 2), hx = hp - hy * (kTW + 2);
+            const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+            const bool inside = hp < C::HALO_PIX && yy >= 0 && yy < A.H && xx >= 0 && xx < A.W;
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = c1w[288 + grp * 8 + c];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int y2 = yy + kh - 1, x2 = xx + kw - 1;
+                    const bool ok = inside && y2 >= 0 && y2 < A.H && x2 >= 0 && x2 < A.W;
+                    const float v = ok ? img[(long long)y2 * A.W + x2] : 0.f;
+                    const float4 w0 = *reinterpret_cast<const float4 *>(c1w + (kh * 3 + kw) * 32 + grp * 8);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(c1w + (kh * 3 + kw) * 32 + grp * 8 + 4);
+                    o[0] = fmaf(v, w0.x, o[0]); o[1] = fmaf(v, w0.y, o[1]);
+                    o[2] = fmaf(v, w0.z, o[2]); o[3] = fmaf(v, w0.w, o[3]);
+                    o[4] = fmaf(v, w1.x, o[4]); o[5] = fmaf(v, w1.y, o[5]);
+                    o[6] = fmaf(v, w1.z, o[6]); o[7] = fmaf(v, w1.w, o[7]);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = inside ? fmaxf(o[c], 0.f) : 0.f;
+            if constexpr (ACT_BF16) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rhb[r][c] = static_cast<__bf16>(o[c]);
+            } else {
+                rh0[r] = make_float4(o[0], o[1], o[2], o[3]);
+                rh1[r] = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    } else {
+        QMRI_LOAD_HALO(0)
+    }
     if constexpr (WALL) {
         QMRI_LOAD_WALL(0)
     } else {
@@ -441,7 +486,7 @@ static size_t conv_lds_bytes() {
     const int planes = S3 ? 2 : 1;
     const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
-    return halo + w + C::BM * sizeof(int);
+    return halo + w + C::BM * sizeof(int) + (9 * 32 + 32) * sizeof(float);
 }
 
 // rows of the output tile in plain-bf16 mode when the image height is a multiple of 16
@@ -467,6 +512,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
                             : (k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32));
     if (k.deconv && (k.ntaps != 9 || k.sy != 2 || k.sx != 2 || k.pool_y || k.head_w)) return hipErrorInvalidValue;
     if (k.Cout % bn != 0 || k.Cin % kBK != 0) return hipErrorInvalidValue;
+    if (k.c1_x && (k.Cin != 32 || k.deconv)) return hipErrorInvalidValue;
     if (k.head_w && (k.Cout != bn || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
     if (k.pool_y && (k.sy != 1 || k.sx != 1 || (k.H & 1) || (k.W & 1))) return hipErrorInvalidValue;
     // tile height: 16 rows where the image height allows it and the accumulators fit, else 8

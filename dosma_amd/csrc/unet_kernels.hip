@@ -73,7 +73,7 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV>
+template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     // DECONV: all four output phases of Conv2DTranspose(3x3, stride 2, SAME) in one pass: the 9 taps are
     // ordered [phase (0,0): 4][phase (0,1): 2][phase (1,0): 2][phase (1,1): 1], each tap accumulates into
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 
     const int chunks = A.Cin / kBK;
     const int steps = chunks * ntaps;
-    if (A.c1_x) {
+    constexpr bool C1_CAPABLE = C1 && BN == 32 && !DECONV;  // a separate instantiation carries the fused first layer
+    bool did_c1 = false;
+    if constexpr (C1_CAPABLE) if (A.c1_x) {
+        did_c1 = true;
         // Fused first layer (oaiunet2d.py:213-219 on the 1-channel input): the halo of THIS convolution's
         // input is computed here -- relu(conv3x3(image) + bias), 32 channels -- straight into the staging
         // registers, so the first feature map never goes to HBM.  Pixels outside the image are the zero
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
                 rh1[r] = make_float4(o[4], o[5], o[6], o[7]);
             }
         }
-    } else {
+    }
+    if (!did_c1) {
         QMRI_LOAD_HALO(0)
     }
     if constexpr (WALL) {
@@ -486,7 +490,7 @@ static size_t conv_lds_bytes() {
     const int planes = S3 ? 2 : 1;
     const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
-    return halo + w + C::BM * sizeof(int) + (9 * 32 + 32) * sizeof(float);
+    return halo + w + C::BM * sizeof(int) + (BN == 32 ? (9 * 32 + 32) * sizeof(float) : 0);
 }
 
 // rows of the output tile in plain-bf16 mode when the image height is a multiple of 16
@@ -525,9 +529,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     k.tiles_x = (k.W + kTW - 1) / kTW;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
-#define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_)                                                     \
+#define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_, ...)                                                     \
     do {                                                                                            \
-        auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_>;                                       \
+        auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_, ##__VA_ARGS__>;                                  \
         const size_t lds = conv_lds_bytes<BN_, TH_, S3_>();                                         \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
@@ -543,13 +547,19 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     } else if (split3) {
         if (bn == 128) QMRI_CONV_CASE(128, 8, true, float, false);
         else if (bn == 64) QMRI_CONV_CASE(64, 16, true, float, false);
+        else if (k.c1_x) QMRI_CONV_CASE(32, 16, true, float, false, true);
         else QMRI_CONV_CASE(32, 16, true, float, false);
     } else if (bn == 128) {
         if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {
         if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);
     } else {
-        if (th == 16) QMRI_CONV_CASE(32, 16, false, __bf16, false); else QMRI_CONV_CASE(32, 8, false, __bf16, false);
+        if (k.c1_x) {
+            if (th == 16) QMRI_CONV_CASE(32, 16, false, __bf16, false, true);
+            else QMRI_CONV_CASE(32, 8, false, __bf16, false, true);
+        } else {
+            if (th == 16) QMRI_CONV_CASE(32, 16, false, __bf16, false); else QMRI_CONV_CASE(32, 8, false, __bf16, false);
+        }
     }
 #undef QMRI_CONV_CASE
     return hipGetLastError();

@@ -56,13 +56,13 @@ if os.path.exists(ut):
         "# rocprofv3 --kernel-trace of scripts/prof_unet.py (bf16, 384x384, batch 32): last forward batch\n" + layers)
     rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
             if "conv_igemm" in r["Kernel_Name"]]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-42:]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-27:]  # 12 + 15 conv_igemm dispatches per forward batch
     agg = collections.Counter()
     for r in rows:
         if int(r["Dispatch_Id"]) in ids:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
     gui = agg["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
-    u = {"tag": tag, "workload": "UNet2D forward, 32 slices of 384x384, plain bf16 mode, 42 conv_igemm dispatches",
+    u = {"tag": tag, "workload": "UNet2D forward, 32 slices of 384x384, plain bf16 mode, 27 conv_igemm dispatches (one forward batch)",
          "counters": dict(agg),
          "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4),
          "mfma_gflop_issued": agg["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / 1e9,

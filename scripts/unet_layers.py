@@ -4,7 +4,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 k = [r for r in rows if ('qmri::' in r['Kernel_Name'] or '_ZN4qmri' in r['Kernel_Name']) and 'whiten' not in r['Kernel_Name'] and 'sum' not in r['Kernel_Name'] and 'mean_from' not in r['Kernel_Name']]
 # one forward batch = 1 c1 + 26 igemm convs... find last head kernel and go back to the previous head
-n_ops = 2 * 6 + 5 * 3
+FUSED_C1 = not any('conv3x3_c1' in r['Kernel_Name'] for r in k)
+n_ops = 2 * 6 + 5 * 3 - (1 if FUSED_C1 else 0)
 seg = k[-n_ops:]
 nf = [32, 64, 128, 256, 512, 1024]
 # expected op list for flops
@@ -13,8 +14,11 @@ H = 384
 for l in range(6):
     h = H >> l
     cin = 1 if l == 0 else nf[l - 1]
-    ops.append((f"down{l}.conv1", h * h * 9 * cin * nf[l]))
-    ops.append((f"down{l}.conv2", h * h * 9 * nf[l] * nf[l]))
+    if l == 0 and FUSED_C1:
+        ops.append(("down0.conv1+2", h * h * 9 * (cin * nf[l] + nf[l] * nf[l])))
+    else:
+        ops.append((f"down{l}.conv1", h * h * 9 * cin * nf[l]))
+        ops.append((f"down{l}.conv2", h * h * 9 * nf[l] * nf[l]))
 for l in range(4, -1, -1):
     h = H >> l
     hin = h // 2

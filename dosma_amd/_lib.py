@@ -81,6 +81,19 @@ class QmriUnet2dDesc(ctypes.Structure):
     ]
 
 
+class QmriDessArgs(ctypes.Structure):
+    _fields_ = [
+        ("echo1", ctypes.c_void_p), ("echo2", ctypes.c_void_p),
+        ("dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("N", ctypes.c_int64),
+        ("c0", ctypes.c_double), ("k", ctypes.c_double), ("c1", ctypes.c_double),
+        ("use_bounds", ctypes.c_int32), ("use_nan_to_num", ctypes.c_int32),
+        ("lo", ctypes.c_double), ("hi", ctypes.c_double), ("nan_value", ctypes.c_double),
+        ("decimals", ctypes.c_int32), ("suppress_fat", ctypes.c_int32),
+        ("suppress_fluid", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("beta", ctypes.c_double), ("t2", ctypes.c_void_p), ("stream", ctypes.c_void_p),
+    ]
+
+
 PRECISION = {"bf16": 0, "bf16x3": 1}
 
 EXPORTS = (
@@ -88,7 +101,7 @@ EXPORTS = (
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
     "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
     "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
-    "qmri_conv2d_nhwc_host",
+    "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
 )
 
 _lib = None
@@ -175,6 +188,13 @@ def load():
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
         lib.qmri_conv2d_nhwc_host.restype = ctypes.c_int
+        for name in ("qmri_dess_t2_device", "qmri_dess_t2_host"):
+            fn = getattr(lib, name)
+            fn.argtypes = [ctypes.POINTER(QmriDessArgs)]
+            fn.restype = ctypes.c_int
+        lib.qmri_rss_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+        lib.qmri_rss_host.restype = ctypes.c_int
         _lib = lib
         return lib
 
@@ -401,3 +421,46 @@ class Unet2dEngine:
             self.close()
         except Exception:
             pass
+
+
+def dess_t2_host(echo1, echo2, c0, k, c1, *, bounds=None, nan_to_num=None, decimals=None,
+                 suppress_fat=False, suppress_fluid=False, beta=1.2, out_dtype=np.float64, device=0):
+    """Analytic DESS T2 map on the GPU from two host echo arrays of equal shape -> array of that shape."""
+    lib = load()
+    require_device()
+    e1 = np.ascontiguousarray(echo1)
+    e2 = np.ascontiguousarray(echo2)
+    if e1.shape != e2.shape or e1.dtype != e2.dtype:
+        raise ValueError("echo volumes must have the same shape and dtype")
+    a = QmriDessArgs()
+    a.echo1, a.echo2, a.dtype, a.N = _ptr(e1), _ptr(e2), qdtype(e1.dtype), e1.size
+    a.c0, a.k, a.c1 = float(c0), float(k), float(c1)
+    if bounds is not None:
+        a.use_bounds, a.lo, a.hi = 1, float(bounds[0]), float(bounds[1])
+    if nan_to_num is not None:
+        a.use_nan_to_num = 1
+        a.nan_value = 0.0 if isinstance(nan_to_num, bool) else float(nan_to_num)
+    a.decimals = -1000000 if decimals is None else int(decimals)
+    a.suppress_fat, a.suppress_fluid, a.beta = int(bool(suppress_fat)), int(bool(suppress_fluid)), float(beta)
+    od = np.dtype(out_dtype)
+    a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
+    out = np.empty(e1.shape, dtype=od)
+    a.t2 = _ptr(out)
+    a.device = int(device)
+    check(lib.qmri_dess_t2_host(ctypes.byref(a)))
+    return out
+
+
+def rss_host(echo1, echo2, method="rss", device=0):
+    lib = load()
+    require_device()
+    e1 = np.ascontiguousarray(echo1)
+    e2 = np.ascontiguousarray(echo2)
+    if e1.shape != e2.shape or e1.dtype != e2.dtype:
+        raise ValueError("echo volumes must have the same shape and dtype")
+    if method not in ("rss", "rms"):
+        raise ValueError(f"`method={method}` is not supported")
+    out = np.empty(e1.shape, dtype=np.float64)
+    check(lib.qmri_rss_host(_ptr(e1), _ptr(e2), qdtype(e1.dtype), e1.size, 0 if method == "rss" else 1,
+                            _ptr(out), int(device)))
+    return out

@@ -450,4 +450,107 @@ int qmri_linfit_host(const qmri_linfit_args *a) {
     return status;
 }
 
+
+static int dess_fill(const qmri_dess_args *a, qmri::DessKArgs &k) {
+    if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
+    if (!a->echo1 || !a->echo2 || !a->t2) return fail(QMRI_ERR_ARG, "echo1, echo2 and t2 are required");
+    if (dtype_size(a->dtype) == 0) return fail(QMRI_ERR_ARG, "unknown dtype %d", a->dtype);
+    if (a->out_dtype != QMRI_F32 && a->out_dtype != QMRI_F64) return fail(QMRI_ERR_ARG, "bad out_dtype");
+    if (a->N < 0) return fail(QMRI_ERR_ARG, "N < 0");
+    if (a->device < 0 || a->device >= kMaxDevices) return fail(QMRI_ERR_ARG, "bad device %d", a->device);
+    std::memset(&k, 0, sizeof(k));
+    k.echo1 = a->echo1;
+    k.echo2 = a->echo2;
+    k.N = a->N;
+    k.c0 = a->c0;
+    k.k = a->k;
+    k.c1 = a->c1;
+    k.use_bounds = a->use_bounds;
+    k.use_nan_to_num = a->use_nan_to_num;
+    k.lo = a->lo;
+    k.hi = a->hi;
+    k.nan_value = a->nan_value;
+    k.decimals = a->decimals <= -1000000 ? QMRI_NO_ROUND : a->decimals;
+    k.p10 = k.decimals == QMRI_NO_ROUND ? 1.0 : std::pow(10.0, std::abs(k.decimals));
+    k.suppress_fat = a->suppress_fat;
+    k.suppress_fluid = a->suppress_fluid;
+    k.out_f64 = a->out_dtype == QMRI_F64;
+    k.beta = a->beta;
+    k.t2 = a->t2;
+    return QMRI_OK;
+}
+
+int qmri_dess_t2_device(const qmri_dess_args *a) {
+    qmri::DessKArgs k;
+    const int rc = dess_fill(a, k);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    double *scratch = nullptr;
+    if (a->suppress_fat || a->suppress_fluid) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scratch), (2 * 1024 + 2) * 8, st));
+    HIP_TRY(qmri::dess_t2_launch(k, a->dtype, ctx->num_cu, scratch, st));
+    if (scratch) HIP_TRY(hipFreeAsync(scratch, st));
+    return QMRI_OK;
+}
+
+int qmri_dess_t2_host(const qmri_dess_args *a) {
+    qmri::DessKArgs k;
+    const int rc = dess_fill(a, k);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const size_t es = dtype_size(a->dtype), os = a->out_dtype == QMRI_F64 ? 8 : 4;
+    void *d1 = nullptr, *d2 = nullptr, *dt = nullptr;
+    hipError_t e = hipMalloc(&d1, (size_t)a->N * es);
+    if (e == hipSuccess) e = hipMalloc(&d2, (size_t)a->N * es);
+    if (e == hipSuccess) e = hipMalloc(&dt, (size_t)a->N * os);
+    if (e == hipSuccess) e = hipMemcpy(d1, a->echo1, (size_t)a->N * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d2, a->echo2, (size_t)a->N * es, hipMemcpyHostToDevice);
+    int status = QMRI_OK;
+    if (e == hipSuccess) {
+        qmri_dess_args d = *a;
+        d.echo1 = d1;
+        d.echo2 = d2;
+        d.t2 = dt;
+        d.stream = nullptr;
+        status = qmri_dess_t2_device(&d);
+        if (status == QMRI_OK) e = hipDeviceSynchronize();
+        if (status == QMRI_OK && e == hipSuccess) e = hipMemcpy(a->t2, dt, (size_t)a->N * os, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d1);
+    (void)hipFree(d2);
+    (void)hipFree(dt);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "dess_t2_host: %s", hipGetErrorString(e));
+    return status;
+}
+
+int qmri_rss_host(const void *echo1, const void *echo2, int32_t dtype, int64_t N, int32_t mode, double *out,
+                  int32_t device) {
+    if (!echo1 || !echo2 || !out) return fail(QMRI_ERR_ARG, "NULL argument");
+    if (dtype_size(dtype) == 0) return fail(QMRI_ERR_ARG, "unknown dtype %d", dtype);
+    if (mode != 0 && mode != 1) return fail(QMRI_ERR_ARG, "mode must be 0 (rss) or 1 (rms)");
+    if (N <= 0) return N == 0 ? QMRI_OK : fail(QMRI_ERR_ARG, "N < 0");
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(ctx_get(device, &ctx));
+    const size_t es = dtype_size(dtype);
+    void *d1 = nullptr, *d2 = nullptr;
+    double *dout = nullptr;
+    hipError_t e = hipMalloc(&d1, (size_t)N * es);
+    if (e == hipSuccess) e = hipMalloc(&d2, (size_t)N * es);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), (size_t)N * 8);
+    if (e == hipSuccess) e = hipMemcpy(d1, echo1, (size_t)N * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d2, echo2, (size_t)N * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qmri::rss_launch(d1, d2, dtype, N, mode, dout, ctx->num_cu, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)N * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d1);
+    (void)hipFree(d2);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "rss_host: %s", hipGetErrorString(e));
+    return QMRI_OK;
+}
+
 }  // extern "C"

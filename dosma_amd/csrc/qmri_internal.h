@@ -108,6 +108,24 @@ hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStre
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
                          hipStream_t stream);
 
+// Kernel-argument block of the analytic DESS T2 kernel (dess.hip).
+struct DessKArgs {
+    const void *echo1, *echo2;
+    long long N;
+    double c0, k, c1;          // t2 = c0 / (log(|e2/e1| / k) + c1)
+    int use_bounds;
+    int use_nan_to_num;
+    double lo, hi, nan_value;
+    int decimals;              // QMRI_NO_ROUND = none
+    int suppress_fat, suppress_fluid, out_f64;
+    double p10, beta;
+    const double *maxima;      // device [2]: max(echo1), max(echo1 - beta*echo2)
+    void *t2;
+};
+hipError_t dess_t2_launch(const DessKArgs &k, int dtype, int num_cu, double *scratch, hipStream_t stream);
+hipError_t rss_launch(const void *e1, const void *e2, int dtype, long long n, int rms, double *out, int num_cu,
+                      hipStream_t stream);
+
 void set_last_error(const char *msg);  // thread-local message behind qmri_last_error()
 
 int monoexp_tile_voxels();

@@ -213,6 +213,38 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
                           const float *bias, const float *scale, const float *shift, int32_t relu,
                           int32_t Cout, int32_t transposed, int32_t precision, float *y, int32_t device);
 
+/*
+ * ---- analytic T2 of a qDESS scan and echo combination -----------------------------
+ * Replaces the whole-volume numpy passes of QDess.generate_t2_map
+ *   (/root/reference/dosma/scan_sequences/mri/qdess.py:105-252; arithmetic :204-245) and calc_rss (:254-295).
+ *   t2 = c0 / (log(|echo2/echo1| / k) + c1) with the reference's nan_to_num / bounds / rounding / suppression
+ *   steps; c0 = -2000 (TR - TE), k and c1 are the scalar sequence constants of qdess.py:204-212, computed
+ *   by the caller (dosma_amd/scan_sequences/qdess.py does it with the reference's expressions).
+ */
+typedef struct qmri_dess_args {
+    const void *echo1;    /* [N] */
+    const void *echo2;    /* [N] */
+    int32_t dtype;        /* qmri_dtype of the echoes */
+    int32_t out_dtype;    /* QMRI_F64 (reference) or QMRI_F32 */
+    int64_t N;
+    double c0, k, c1;
+    int32_t use_bounds;   /* nan_bounds: values outside [lo, hi] -> NaN */
+    int32_t use_nan_to_num;
+    double lo, hi, nan_value;
+    int32_t decimals;     /* <= -1000000: no rounding */
+    int32_t suppress_fat;   /* t2 *= echo1 > 0.15 max(echo1) */
+    int32_t suppress_fluid; /* t2 *= (echo1 - beta echo2) > 0.1 max(echo1 - beta echo2) */
+    int32_t device;
+    double beta;
+    void *t2;             /* [N] out */
+    void *stream;
+} qmri_dess_args;
+int qmri_dess_t2_device(const qmri_dess_args *args); /* device pointers, asynchronous */
+int qmri_dess_t2_host(const qmri_dess_args *args);   /* host pointers, synchronous */
+/* out[i] = sqrt(e1^2 + e2^2) (mode 0, RSS) or sqrt((e1^2 + e2^2)/2) (mode 1, RMS), float64 like the reference */
+int qmri_rss_host(const void *echo1, const void *echo2, int32_t dtype, int64_t N, int32_t mode, double *out,
+                  int32_t device);
+
 /* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
  * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */
 void qmri_set_timing(int enable);

@@ -318,3 +318,40 @@ def monoexp_fit_arrays(x, y, mask=None, bounds=(0, 100.0), tc0=30.0, r2_threshol
     if decimal_precision is not None:
         tc = np.around(tc, decimal_precision)
     return tc, r2, popt
+
+
+# ----------------------------------------------------------------------------- qDESS
+def dess_t2_numpy(echo_1, echo_2, tr, te, tg, alpha_deg, gl_area, t1, diffusivity=1.25e-9,
+                  suppress_fat=False, suppress_fluid=False, beta=1.2, nan_bounds=(0, 100),
+                  nan_to_num=0.0, decimals=1):
+    """numpy restatement of QDess.generate_t2_map's arithmetic (dosma/scan_sequences/mri/qdess.py:190-245)."""
+    import math
+
+    xp = np
+    TR, TE, Tg, T1 = tr * 1e-3, te * 1e-3, tg * 1e-6, t1 * 1e-3
+    alpha = math.radians(alpha_deg)
+    Gl = gl_area / (Tg * 1e6) * 100
+    gamma = 4258 * 2 * math.pi
+    dkL = gamma * Gl * Tg
+    k = (xp.power((xp.sin(alpha / 2)), 2)
+         * (1 + xp.exp(-TR / T1 - TR * xp.power(dkL, 2) * diffusivity))
+         / (1 - xp.cos(alpha) * xp.exp(-TR / T1 - TR * xp.power(dkL, 2) * diffusivity)))
+    c1 = (TR - Tg / 3) * (xp.power(dkL, 2)) * diffusivity
+    with np.errstate(all="ignore"):
+        mask = xp.ones(echo_1.shape)
+        ratio = xp.nan_to_num(mask * echo_2 / echo_1)
+        t2map = -2000 * (TR - TE) / (xp.log(abs(ratio) / k) + c1)
+        t2map = xp.nan_to_num(t2map)
+        if nan_bounds is not None:
+            lower, upper = nan_bounds
+            t2map[(t2map < lower) | (t2map > upper)] = xp.nan
+        if nan_to_num is not None:
+            t2map = xp.nan_to_num(t2map) if isinstance(nan_to_num, bool) else xp.nan_to_num(t2map, nan=nan_to_num)
+        if decimals is not None:
+            t2map = xp.around(t2map, decimals)
+        if suppress_fat:
+            t2map = t2map * (echo_1 > 0.15 * xp.max(echo_1))
+        if suppress_fluid:
+            vol_null_fluid = echo_1 - beta * echo_2
+            t2map = t2map * (vol_null_fluid > 0.1 * xp.max(vol_null_fluid))
+    return t2map

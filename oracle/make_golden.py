@@ -230,11 +230,41 @@ def g5():
     save("g5_process_params.npz", x=x, y=y, **out)
 
 
+def g6():
+    """qDESS analytic T2 + RSS: the reference's QDess class on seeded echoes."""
+    from dosma.scan_sequences.mri.qdess import QDess
+
+    rng = np.random.default_rng(6)
+    shape = (24, 20, 6)
+    e1 = rng.uniform(20, 800, shape)
+    e2 = e1 * rng.uniform(0.02, 0.9, shape)
+    e1[0, 0, 0] = 0          # division by zero -> inf -> nan_to_num
+    e1[1, 1, 1] = e2[1, 1, 1] = 0  # 0/0 -> nan
+    e2[2, 2, 2] = 0          # log(0)
+    out = {}
+    pars = dict(gl_area=3132, tg=1904, tr=20.36, te=6.428, alpha=20.0, t1=1200.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for dt in (np.float32, np.float64, np.int16):
+            a, b = e1.astype(dt), e2.astype(dt)
+            q = QDess([MV(a, np.eye(4)), MV(b, np.eye(4))])
+            tag = np.dtype(dt).name
+            out[f"e1_{tag}"], out[f"e2_{tag}"] = a, b
+            out[f"t2_{tag}"] = q.generate_t2_map(**pars).volumetric_map.A
+            out[f"t2_sup_{tag}"] = q.generate_t2_map(suppress_fat=True, suppress_fluid=True, decimals=3,
+                                                     nan_bounds=(0, 80), **pars).volumetric_map.A
+            out[f"t2_raw_{tag}"] = q.generate_t2_map(nan_bounds=None, nan_to_num=None, decimals=None,
+                                                     **pars).volumetric_map.A
+            out[f"rss_{tag}"] = q.calc_rss().A
+    save("g6_qdess.npz", pars=np.array([pars[k] for k in ("gl_area", "tg", "tr", "te", "alpha", "t1")]), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for name in which:
         t = time.time()
         print(name, "...")
         globals()[name]()
         print(f"  {time.time() - t:.1f}s")
+

@@ -159,3 +159,17 @@ def test_oracle_vs_reference_live(relerr):
     assert relerr(popt, popt_ref).max() < 1e-6
     tc, r2tc, _ = fo.monoexp_fit_arrays(x, y, tc0="polyfit", decimal_precision=3)
     assert np.array_equal(tc, tc_ref.A.reshape(-1))
+
+
+def test_qdess_restatement_vs_reference_golden(golden):
+    """N2: the numpy restatement of QDess.generate_t2_map is bit-equal to the reference (g6)."""
+    g = golden("g6_qdess.npz")
+    gl, tg, tr, te, al, t1 = g["pars"]
+    for tag in ("float32", "float64", "int16"):
+        a, b = g[f"e1_{tag}"], g[f"e2_{tag}"]
+        assert np.array_equal(fo.dess_t2_numpy(a, b, tr, te, tg, al, gl, t1), g[f"t2_{tag}"], equal_nan=True)
+        assert np.array_equal(fo.dess_t2_numpy(a, b, tr, te, tg, al, gl, t1, suppress_fat=True,
+                                               suppress_fluid=True, decimals=3, nan_bounds=(0, 80)),
+                              g[f"t2_sup_{tag}"], equal_nan=True)
+        assert np.array_equal(fo.dess_t2_numpy(a, b, tr, te, tg, al, gl, t1, nan_bounds=None, nan_to_num=None,
+                                               decimals=None), g[f"t2_raw_{tag}"], equal_nan=True)

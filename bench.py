@@ -113,6 +113,38 @@ def cpu_baseline(y_dev, cores_cap=None):
     }
 
 
+def bench_dess(L, lib, torch, device, local_rank, world, args, barrier):
+    """qDESS analytic T2 map: one fused streaming pass over two fp32 echo volumes of
+    384x384x160 -> fp64 map (the reference's dtype).  HBM-bound: 2 x 4 B in + 8 B out per voxel."""
+    n = 384 * 384 * 160
+    gen = torch.Generator(device=device).manual_seed(11 + local_rank)
+    e1 = torch.rand(n, device=device, generator=gen) * 780 + 20
+    e2 = e1 * (torch.rand(n, device=device, generator=gen) * 0.88 + 0.02)
+    t2 = torch.empty(n, device=device, dtype=torch.float64)
+    a = L.QmriDessArgs()
+    a.echo1, a.echo2, a.dtype, a.out_dtype, a.N = e1.data_ptr(), e2.data_ptr(), L.QMRI_F32, L.QMRI_F64, n
+    a.c0, a.k, a.c1 = -27.864, 0.0434, 3.9e-3
+    a.use_bounds, a.lo, a.hi, a.use_nan_to_num, a.nan_value, a.decimals = 1, 0.0, 100.0, 1, 0.0, 1
+    a.t2, a.device = t2.data_ptr(), local_rank
+    stream = torch.cuda.current_stream(device)
+    a.stream = stream.cuda_stream
+    for _ in range(3):
+        L.check(lib.qmri_dess_t2_device(ctypes.byref(a)))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    ev0.record(stream)
+    reps = 20
+    for _ in range(reps):
+        L.check(lib.qmri_dess_t2_device(ctypes.byref(a)))
+    ev1.record(stream)
+    barrier()
+    ms = ev0.elapsed_time(ev1) / reps
+    gbs = 16.0 * n / (ms * 1e-3) / 1e9
+    return {"metric": "qDESS analytic T2 map, 384x384x160, fp32 echoes -> fp64 map", "voxels_per_s": n / (ms * 1e-3),
+            "kernel_ms": ms, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_voxel": 16}}
+
+
 UNET_HW = 384
 UNET_SLICES = 160
 UNET_GFLOP_PER_SLICE = 70.79   # SURVEY.md Appendix D: 35.39 GMAC per 384x384 slice
@@ -234,6 +266,7 @@ def main():
         results[recipe] = dict(elapsed=elapsed, kernel_ms=kernel_ms,
                                kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
 
+    dess = bench_dess(L, lib, torch, device, local_rank, world, args, barrier) if rank == 0 or world > 1 else None
     unet = None
     if not args.no_unet:
         unet = bench_unet(L, torch, dist, device, local_rank, world, args, barrier)
@@ -289,6 +322,8 @@ def main():
         }
         if unet is not None:
             out["unet2d"] = unet
+        if dess is not None:
+            out["dess_t2"] = dess
         if "B" in results:
             out["runs"]["B_polyfit_init"] = {
                 "voxel_fits_per_s": n * world * args.steps / results["B"]["elapsed"],

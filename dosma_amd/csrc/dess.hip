@@ -74,6 +74,33 @@ __global__ void dess_max_final_kernel(const double *__restrict__ part, int nbloc
     }
 }
 
+// one voxel of qdess.py:218-245
+template <typename S>
+__device__ __forceinline__ double dess_voxel(const DessKArgs &A, S s1, S s2, typename NfType<S>::type fat_thr,
+                                             typename NfType<S>::type fluid_thr,
+                                             typename NfType<S>::type beta) {
+    using NF = typename NfType<S>::type;
+    const double e1 = static_cast<double>(s1), e2 = static_cast<double>(s2);
+    double ratio = nan_to_num_d(e2 / e1, 0.0);                  // :218-219
+    double t2 = A.c0 / (log(fabs(ratio) / A.k) + A.c1);        // :222
+    t2 = nan_to_num_d(t2, 0.0);                                // :224
+    if (A.use_bounds && (t2 < A.lo || t2 > A.hi)) t2 = NAN;    // :227-229
+    if (A.use_nan_to_num) t2 = nan_to_num_d(t2, A.nan_value);  // :230-235
+    if (A.decimals != QMRI_NO_ROUND) {                         // :237-238
+        if (A.decimals == 0) t2 = rint(t2);
+        else if (A.decimals > 0) t2 = rint(t2 * A.p10) / A.p10;
+        else t2 = rint(t2 / A.p10) * A.p10;
+    }
+    if (A.suppress_fat) t2 = t2 * (static_cast<NF>(s1) > fat_thr ? 1.0 : 0.0);  // :240-241
+    if (A.suppress_fluid) {                                                       // :243-245
+        const NF nf = static_cast<NF>(s1) - beta * static_cast<NF>(s2);
+        t2 = t2 * (nf > fluid_thr ? 1.0 : 0.0);
+    }
+    return t2;
+}
+
+// 4 consecutive voxels per lane: 16-byte (f32) echo loads, 2 x 16-byte (f64) stores -> full-width HBM
+// transactions; a scalar tail handles N % 4 and unaligned bases.
 template <typename S>
 __global__ __launch_bounds__(256) void dess_t2_kernel(const DessKArgs A) {
     using NF = typename NfType<S>::type;
@@ -83,25 +110,28 @@ __global__ __launch_bounds__(256) void dess_t2_kernel(const DessKArgs A) {
     if (A.suppress_fat) fat_thr = static_cast<NF>(0.15) * static_cast<NF>(A.maxima[0]);
     if (A.suppress_fluid) fluid_thr = static_cast<NF>(0.1) * static_cast<NF>(A.maxima[1]);
     const NF beta = static_cast<NF>(A.beta);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.N;
-         i += (long long)gridDim.x * blockDim.x) {
-        const S s1 = e1p[i], s2 = e2p[i];
-        const double e1 = static_cast<double>(s1), e2 = static_cast<double>(s2);
-        double ratio = nan_to_num_d(e2 / e1, 0.0);                  // qdess.py:218-219
-        double t2 = A.c0 / (log(fabs(ratio) / A.k) + A.c1);        // :222
-        t2 = nan_to_num_d(t2, 0.0);                                // :224
-        if (A.use_bounds && (t2 < A.lo || t2 > A.hi)) t2 = NAN;    // :227-229
-        if (A.use_nan_to_num) t2 = nan_to_num_d(t2, A.nan_value);  // :230-235
-        if (A.decimals != QMRI_NO_ROUND) {                         // :237-238
-            if (A.decimals == 0) t2 = rint(t2);
-            else if (A.decimals > 0) t2 = rint(t2 * A.p10) / A.p10;
-            else t2 = rint(t2 / A.p10) * A.p10;
+    struct alignas(sizeof(S) * 4) V4 {
+        S v[4];
+    };
+    const bool vec = A.vec_ok;
+    const long long n4 = vec ? A.N / 4 : 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const V4 a = reinterpret_cast<const V4 *>(e1p)[q];
+        const V4 b = reinterpret_cast<const V4 *>(e2p)[q];
+        double o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dess_voxel<S>(A, a.v[j], b.v[j], fat_thr, fluid_thr, beta);
+        if (A.out_f64) {
+            double2 *dst = reinterpret_cast<double2 *>(static_cast<double *>(A.t2) + 4 * q);
+            dst[0] = make_double2(o[0], o[1]);
+            dst[1] = make_double2(o[2], o[3]);
+        } else {
+            reinterpret_cast<float4 *>(A.t2)[q] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
         }
-        if (A.suppress_fat) t2 = t2 * (static_cast<NF>(s1) > fat_thr ? 1.0 : 0.0);  // :240-241
-        if (A.suppress_fluid) {                                                       // :243-245
-            const NF nf = static_cast<NF>(s1) - beta * static_cast<NF>(s2);
-            t2 = t2 * (nf > fluid_thr ? 1.0 : 0.0);
-        }
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.N; i += stride) {
+        const double t2 = dess_voxel<S>(A, e1p[i], e2p[i], fat_thr, fluid_thr, beta);
         if (A.out_f64) static_cast<double *>(A.t2)[i] = t2;
         else static_cast<float *>(A.t2)[i] = static_cast<float>(t2);
     }

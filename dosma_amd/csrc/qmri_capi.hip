@@ -477,6 +477,8 @@ static int dess_fill(const qmri_dess_args *a, qmri::DessKArgs &k) {
     k.out_f64 = a->out_dtype == QMRI_F64;
     k.beta = a->beta;
     k.t2 = a->t2;
+    k.vec_ok = ((reinterpret_cast<uintptr_t>(a->echo1) | reinterpret_cast<uintptr_t>(a->echo2) |
+                 reinterpret_cast<uintptr_t>(a->t2)) % 32) == 0;
     return QMRI_OK;
 }
 

@@ -118,6 +118,7 @@ struct DessKArgs {
     double lo, hi, nan_value;
     int decimals;              // QMRI_NO_ROUND = none
     int suppress_fat, suppress_fluid, out_f64;
+    int vec_ok;                // bases are 32-byte aligned: 4 voxels per lane
     double p10, beta;
     const double *maxima;      // device [2]: max(echo1), max(echo1 - beta*echo2)
     void *t2;

@@ -151,7 +151,7 @@ UNET_GFLOP_PER_SLICE = 70.79   # 35.39 GMAC per 384x384 sl
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
-def bench_unet(L, torch, dist, device, local_rank, world, args, barrier):
+def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device):
     """UNet2D slices/s (BASELINE.json configs[3]: IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv).
 
     A step = one whole volume (160 sagittal slices incl. whole-volume whitening) per GPU through the
@@ -182,7 +182,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier):
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], device=device, dtype=torch.float64)
+            t = torch.tensor([el], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t[0].item()
         res[prec] = UNET_SLICES * world * steps / el
@@ -223,12 +223,22 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # QMRI_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices); the real runs use nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("QMRI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    red_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    local_rank = dev_index
 
     y = make_volume(torch, device, 20260928 + rank)
     n = y.shape[1]
@@ -260,7 +270,7 @@ def main():
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
         if world > 1:
-            t = torch.tensor([elapsed, kernel_ms], device=device, dtype=torch.float64)
+            t = torch.tensor([elapsed, kernel_ms], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = t[0].item(), t[1].item()
         results[recipe] = dict(elapsed=elapsed, kernel_ms=kernel_ms,
@@ -269,7 +279,7 @@ def main():
     dess = bench_dess(L, lib, torch, device, local_rank, world, args, barrier) if rank == 0 or world > 1 else None
     unet = None
     if not args.no_unet:
-        unet = bench_unet(L, torch, dist, device, local_rank, world, args, barrier)
+        unet = bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device)
 
     if rank == 0:
         ra = results["A"]

@@ -53,6 +53,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         "         offsetof(qmri_linfit_args, stream));\n"
         '  printf("%zu %zu %zu\\n", sizeof(qmri_unet2d_desc), offsetof(qmri_unet2d_desc, tensors),\n'
         "         offsetof(qmri_unet2d_desc, bn_eps));\n"
+        '  printf("%zu %zu %zu %zu %zu\\n", sizeof(qmri_dess_args), offsetof(qmri_dess_args, N),\n'
+        "         offsetof(qmri_dess_args, lo), offsetof(qmri_dess_args, beta), offsetof(qmri_dess_args, stream));\n"
         "  return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -64,6 +66,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
             Lf.x.offset, Lf.popt.offset, Lf.stream.offset,
             ctypes.sizeof(_lib.QmriUnet2dDesc), _lib.QmriUnet2dDesc.tensors.offset,
             _lib.QmriUnet2dDesc.bn_eps.offset]
+    D = _lib.QmriDessArgs
+    want += [ctypes.sizeof(D), D.N.offset, D.lo.offset, D.beta.offset, D.stream.offset]
     assert got == want
 
 

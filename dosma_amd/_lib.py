@@ -94,6 +94,23 @@ class QmriDessArgs(ctypes.Structure):
     ]
 
 
+class QmriLmfitArgs(ctypes.Structure):
+    _fields_ = [
+        ("model", ctypes.c_int32), ("y_dtype", ctypes.c_int32), ("y", ctypes.c_void_p),
+        ("E", ctypes.c_int32), ("maxfev", ctypes.c_int32), ("N", ctypes.c_int64), ("ld", ctypes.c_int64),
+        ("x", ctypes.POINTER(ctypes.c_double)),
+        ("p0", ctypes.c_double * 4), ("p0v", ctypes.c_void_p * 4),
+        ("ftol", ctypes.c_double), ("xtol", ctypes.c_double), ("gtol", ctypes.c_double),
+        ("factor", ctypes.c_double), ("epsfcn", ctypes.c_double), ("r2_eps", ctypes.c_double),
+        ("use_y_bounds", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("y_lo", ctypes.c_double), ("y_hi", ctypes.c_double),
+        ("popt", ctypes.c_void_p), ("r2", ctypes.c_void_p), ("info", ctypes.c_void_p),
+        ("nfev", ctypes.c_void_p), ("stream", ctypes.c_void_p),
+    ]
+
+
+MODELS = {"monoexponential": 0, "biexponential": 1}
+MODEL_NPARAMS = {"monoexponential": 2, "biexponential": 4}
 PRECISION = {"bf16": 0, "bf16x3": 1}
 
 EXPORTS = (
@@ -102,6 +119,7 @@ EXPORTS = (
     "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
     "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
+    "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host",
 )
 
 _lib = None
@@ -195,6 +213,12 @@ def load():
         lib.qmri_rss_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
         lib.qmri_rss_host.restype = ctypes.c_int
+        lib.qmri_lmfit_defaults.argtypes = [ctypes.POINTER(QmriLmfitArgs)]
+        lib.qmri_lmfit_defaults.restype = None
+        lib.qmri_lmfit_device.argtypes = [ctypes.POINTER(QmriLmfitArgs), ctypes.c_void_p]
+        lib.qmri_lmfit_device.restype = ctypes.c_int
+        lib.qmri_lmfit_host.argtypes = [ctypes.POINTER(QmriLmfitArgs)]
+        lib.qmri_lmfit_host.restype = ctypes.c_int
         _lib = lib
         return lib
 
@@ -346,6 +370,57 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
     a.device = int(device)
     check(lib.qmri_linfit_host(ctypes.byref(a)))
+    return out
+
+
+def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds=None, want_info=False,
+               device=0):
+    """General lmdif (true forward differences) on the GPU.  ``model``: "biexponential" | "monoexponential";
+    ``y`` (E, N) echo-major; ``p0``: one entry per parameter, a float or a float64 array of length N.
+    Returns dict(popt (N, n), r2 (N,), [info, nfev])."""
+    lib = load()
+    require_device()
+    n = MODEL_NPARAMS[model]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y)
+    E, N = y.shape
+    if x.shape != (E,):
+        raise ValueError(f"x has shape {x.shape}, expected ({E},)")
+    if len(p0) != n:
+        raise ValueError(f"`p0` has length {len(p0)} but the model has {n} parameters")
+    a = QmriLmfitArgs()
+    lib.qmri_lmfit_defaults(ctypes.byref(a))
+    a.model = MODELS[model]
+    a.y, a.y_dtype, a.E, a.N, a.ld = _ptr(y), qdtype(y.dtype), E, N, N
+    a.x = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    keep = []
+    for j, v in enumerate(p0):
+        if isinstance(v, np.ndarray):
+            v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
+            if v.shape[0] != N:
+                raise ValueError(f"per-voxel p0[{j}] has {v.shape[0]} entries, expected {N}")
+            keep.append(v)
+            a.p0v[j] = v.ctypes.data
+        else:
+            a.p0[j] = float(v)
+    if ftol is not None:
+        a.ftol = float(ftol)
+    if maxfev is not None:
+        a.maxfev = int(maxfev)
+    if r2_eps is not None:
+        a.r2_eps = float(r2_eps)
+    if y_bounds is not None:
+        a.use_y_bounds = 1
+        a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
+    out = {"popt": np.empty((N, n)), "r2": np.empty(N)}
+    a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
+    if want_info:
+        out["info"] = np.empty(N, dtype=np.int8)
+        out["nfev"] = np.empty(N, dtype=np.int16)
+        a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
+    a.device = int(device)
+    check(lib.qmri_lmfit_host(ctypes.byref(a)))
+    del keep
     return out
 
 

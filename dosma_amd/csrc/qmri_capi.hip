@@ -451,6 +451,146 @@ int qmri_linfit_host(const qmri_linfit_args *a) {
 }
 
 
+// ---- general lmdif (lm_generic.hip) ---------------------------------------------------------------------
+void qmri_lmfit_defaults(qmri_lmfit_args *a) {
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->model = QMRI_MODEL_BIEXP;
+    a->y_dtype = QMRI_F32;
+    a->ftol = 1e-5;  // dosma/core/fitting.py:761-763
+    a->xtol = 1.49012e-8;
+    a->gtol = 0.0;
+    a->factor = 100.0;
+    a->epsfcn = 2.220446049250313e-16;
+    a->r2_eps = 1e-8;
+    a->maxfev = 100;
+    a->y_lo = -INFINITY;
+    a->y_hi = INFINITY;
+    for (int j = 0; j < QMRI_LM_MAX_PARAMS; ++j) a->p0[j] = 1.0;  // scipy: ones(n) when p0 is None
+}
+
+static int lmfit_validate(const qmri_lmfit_args *a) {
+    if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
+    const int np = qmri::lm_generic_nparams(a->model);
+    if (np == 0) return fail(QMRI_ERR_UNSUPPORTED, "model %d is not implemented", a->model);
+    if (!a->y || !a->x || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, x, popt and r2 are required");
+    if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
+    if (a->E < np)  // scipy: "The number of func parameters must not exceed the number of data points"
+        return fail(QMRI_ERR_ARG, "E=%d: need at least as many samples as parameters (%d)", a->E, np);
+    if (a->E > QMRI_MAX_ECHOES)
+        return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds QMRI_MAX_ECHOES=%d", a->E, QMRI_MAX_ECHOES);
+    if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
+    if (a->maxfev <= 0 || !(a->ftol >= 0) || !(a->xtol >= 0) || !(a->gtol >= 0) || !(a->factor > 0))
+        return fail(QMRI_ERR_ARG, "maxfev > 0, ftol/xtol/gtol >= 0 and factor > 0 are required");
+    if (a->device < 0 || a->device >= kMaxDevices) return fail(QMRI_ERR_ARG, "bad device %d", a->device);
+    return QMRI_OK;
+}
+
+int qmri_lmfit_device(const qmri_lmfit_args *a, int32_t *nonfinite_flag) {
+    const int rc = lmfit_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    hipStream_t stream = static_cast<hipStream_t>(a->stream);
+    qmri::LmKArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.y = a->y;
+    k.ld = a->ld;
+    k.N = a->N;
+    k.E = a->E;
+    k.y_dtype = a->y_dtype;
+    k.maxfev = a->maxfev;
+    k.use_y_bounds = a->use_y_bounds;
+    k.y_lo = a->y_lo;
+    k.y_hi = a->y_hi;
+    for (int j = 0; j < QMRI_LM_MAX_PARAMS; ++j) {
+        k.p0[j] = a->p0[j];
+        k.p0v[j] = a->p0v[j];
+    }
+    k.ftol = a->ftol;
+    k.xtol = a->xtol;
+    k.gtol = a->gtol;
+    k.factor = a->factor;
+    k.epsfcn = a->epsfcn;
+    k.r2_eps = a->r2_eps;
+    k.popt = a->popt;
+    k.r2 = a->r2;
+    k.info = a->info;
+    k.nfev = a->nfev;
+    for (int i = 0; i < a->E; ++i) k.x[i] = a->x[i];
+    if (nonfinite_flag) {
+        k.nonfinite = nonfinite_flag;
+    } else {
+        const unsigned slot = ctx->next.fetch_add(1) % kSlots;
+        k.nonfinite = reinterpret_cast<int *>(ctx->counters + slot * 16 + 1);
+    }
+    HIP_TRY(qmri::lm_generic_launch(k, a->model, ctx->num_cu, stream));
+    return QMRI_OK;
+}
+
+int qmri_lmfit_host(const qmri_lmfit_args *a) {
+    const int rc = lmfit_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const int np = qmri::lm_generic_nparams(a->model);
+    const size_t es = dtype_size(a->y_dtype);
+    const size_t N = (size_t)a->N;
+    void *dy = nullptr;
+    double *dp = nullptr, *dr = nullptr, *dv[QMRI_LM_MAX_PARAMS] = {nullptr, nullptr, nullptr, nullptr};
+    int8_t *di = nullptr;
+    int16_t *dn = nullptr;
+    int32_t *dflag = nullptr;
+    int status = QMRI_OK;
+    int32_t hflag = 0;
+    hipError_t e = hipMalloc(&dy, (size_t)a->E * N * es);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dp), N * np * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dr), N * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dflag), 4);
+    if (e == hipSuccess) e = hipMemset(dflag, 0, 4);
+    if (e == hipSuccess && a->info) e = hipMalloc(reinterpret_cast<void **>(&di), N);
+    if (e == hipSuccess && a->nfev) e = hipMalloc(reinterpret_cast<void **>(&dn), N * 2);
+    for (int j = 0; j < np && e == hipSuccess; ++j) {
+        if (!a->p0v[j]) continue;
+        e = hipMalloc(reinterpret_cast<void **>(&dv[j]), N * 8);
+        if (e == hipSuccess) e = hipMemcpy(dv[j], a->p0v[j], N * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy2D(dy, N * es, a->y, (size_t)a->ld * es, N * es, (size_t)a->E, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        qmri_lmfit_args d = *a;
+        d.y = dy;
+        d.ld = a->N;
+        d.popt = dp;
+        d.r2 = dr;
+        d.info = di;
+        d.nfev = dn;
+        d.stream = nullptr;
+        for (int j = 0; j < QMRI_LM_MAX_PARAMS; ++j) d.p0v[j] = dv[j];
+        status = qmri_lmfit_device(&d, dflag);
+        if (status == QMRI_OK) {
+            e = hipMemcpy(a->popt, dp, N * np * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(a->r2, dr, N * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && a->info) e = hipMemcpy(a->info, di, N, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && a->nfev) e = hipMemcpy(a->nfev, dn, N * 2, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(&hflag, dflag, 4, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dy);
+    (void)hipFree(dp);
+    (void)hipFree(dr);
+    (void)hipFree(di);
+    (void)hipFree(dn);
+    (void)hipFree(dflag);
+    for (int j = 0; j < QMRI_LM_MAX_PARAMS; ++j) (void)hipFree(dv[j]);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "lmfit_host: %s", hipGetErrorString(e));
+    if (status == QMRI_OK && hflag) return fail(QMRI_ERR_NONFINITE, "array must not contain infs or NaNs");
+    return status;
+}
+
+
 static int dess_fill(const qmri_dess_args *a, qmri::DessKArgs &k) {
     if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
     if (!a->echo1 || !a->echo2 || !a->t2) return fail(QMRI_ERR_ARG, "echo1, echo2 and t2 are required");

@@ -60,6 +60,28 @@ struct LinfitKArgs {
     double xmean, sxx;
     double x[QMRI_MAX_ECHOES];
 };
+// Kernel-argument block of the general lmdif kernel (lm_generic.hip).
+struct LmKArgs {
+    const void *y;
+    long long ld;
+    long long N;
+    int E;
+    int y_dtype;
+    int maxfev;
+    int use_y_bounds;
+    double y_lo, y_hi;
+    double p0[QMRI_LM_MAX_PARAMS];
+    const double *p0v[QMRI_LM_MAX_PARAMS];
+    double ftol, xtol, gtol, factor, epsfcn, r2_eps;
+    double *popt;
+    double *r2;
+    signed char *info;
+    short *nfev;
+    int *nonfinite;
+    double x[QMRI_MAX_ECHOES];
+};
+int lm_generic_nparams(int model);
+hipError_t lm_generic_launch(const LmKArgs &k, int model, int num_cu, hipStream_t stream);
 hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
 
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).

@@ -72,6 +72,8 @@ def _model_of(func) -> str:
     """
     if func is monoexponential or getattr(func, "__qmri_model__", None) == "monoexponential":
         return "monoexponential"
+    if func is biexponential or getattr(func, "__qmri_model__", None) == "biexponential":
+        return "biexponential"
     try:
         params = list(inspect.signature(func).parameters)
     except (TypeError, ValueError):
@@ -91,8 +93,8 @@ def _model_of(func) -> str:
             return "monoexponential"
     name = getattr(func, "__name__", type(func).__name__)
     raise NotImplementedError(
-        f"dosma_amd fits the mono-exponential model y = a*exp(b*x) on the GPU; func={name!r} is not "
-        "that model and there is no CPU fallback (SURVEY.md section 8f, row N4).")
+        f"dosma_amd fits the mono-exponential (a*exp(b*x)) and bi-exponential models on the GPU; "
+        f"func={name!r} is neither and there is no CPU fallback.")
 
 
 def _func_param_names(func):
@@ -182,7 +184,7 @@ def curve_fit(
     is no per-voxel Python loop to parallelise).  Extra scipy ``**kwargs`` (``bounds=``, ``sigma=``,
     ``method=`` ...) select solvers this library does not implement -> NotImplementedError.
     """
-    _model_of(func)
+    model = _model_of(func)
     if kwargs:
         raise NotImplementedError(
             f"curve_fit(**{sorted(kwargs)}): only scipy's default unbounded Levenberg-Marquardt "
@@ -202,6 +204,12 @@ def curve_fit(
     if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
         warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
 
+    if model != "monoexponential":  # general lmdif kernel (lm_generic.hip)
+        if x.reshape(-1).shape[0] < len(param_args):
+            raise TypeError("The number of func parameters must not exceed the number of data points")  # scipy
+        out = _lib.lmfit_host(model, x.astype(np.float64).reshape(-1), _as_kernel_samples(y), p0,
+                              ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds)
+        return out["popt"], out["r2"]
     per_voxel = any(isinstance(v, np.ndarray) for v in p0)
     out = _lib.monoexp_fit_host(
         x.astype(np.float64).reshape(-1), _as_kernel_samples(y),
@@ -352,7 +360,7 @@ class CurveFitter(_Fitter):
     """Non-linear least squares fit of ``func`` per voxel of co-registered MedicalVolumes.
 
     Same constructor and ``fit`` contract as the reference's ``CurveFitter`` (:238-458).  ``func`` must
-    be the mono-exponential model (see :func:`curve_fit`).  ``num_workers`` / ``chunksize`` / ``verbose``
+    be the mono-exponential or the bi-exponential model (see :func:`curve_fit`).  ``num_workers`` / ``chunksize`` / ``verbose``
     are accepted and ignored.
     """
 
@@ -445,7 +453,7 @@ class CurveFitter(_Fitter):
             _decimals=None):
         """Fit every voxel; returns ``(popt, r2)`` MedicalVolumes (``popt`` has a trailing parameter
         axis).  Voxels outside ``mask`` hold NaN (or ``nan_to_num``) like the reference (:205-215)."""
-        _model_of(self._func)
+        model = _model_of(self._func)
         if self.kwargs:
             raise NotImplementedError(
                 f"CurveFitter(**{sorted(self.kwargs)}): extra scipy arguments are not implemented "
@@ -465,6 +473,9 @@ class CurveFitter(_Fitter):
 
         if self.y_bounds is not None and ((svs < self.y_bounds[0]).any() or (svs > self.y_bounds[1]).any()):
             warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+
+        if model != "monoexponential":
+            return self._fit_general(model, x, y, svs, mask_flat, p0, copy_headers)
 
         post = self._fusable_post()
         if post is not None and _decimals is not None:
@@ -491,6 +502,27 @@ class CurveFitter(_Fitter):
         if "tc" in out:
             self._last_tc = out["tc"]
         return popt_mv, r2_mv
+
+    def _fit_general(self, model, x, y, svs, mask_flat, p0, copy_headers):
+        """Models on the general lmdif kernel (bi-exponential): gather the masked columns like the
+        reference (:199-200), fit, post-process on the host (:109-146), scatter back (:205-215)."""
+        N = svs.shape[1]
+        sel = None if mask_flat is None else np.flatnonzero(mask_flat)
+        cols = svs if sel is None else np.ascontiguousarray(svs[:, sel])
+        p0 = [v[sel] if (sel is not None and isinstance(v, np.ndarray)) else v for v in p0]
+        out = _lib.lmfit_host(model, x.astype(np.float64).reshape(-1), _as_kernel_samples(cols), p0,
+                              y_bounds=self.y_bounds)
+        popt_s = self._process_params(out["popt"], out["r2"])
+        r2_s = out["r2"]
+        if sel is None:
+            popt, r2 = popt_s, r2_s
+        else:
+            fill = np.nan if self.nan_to_num is None else self.nan_to_num
+            popt = np.full((N, popt_s.shape[-1]), fill, dtype=np.float64)
+            r2 = np.full(N, fill, dtype=np.float64)
+            popt[sel] = popt_s
+            r2[sel] = r2_s
+        return self._wrap(y[0], popt, r2, copy_headers)
 
     def __str__(self) -> str:
         attrs = ["p0", "y_bounds", "out_bounds", "r2_threshold", "nan_to_num", "num_workers",

@@ -7,10 +7,11 @@ import yaml
 
 from dosma_amd.models.oaiunet2d import IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, OAIUnet2D
 from dosma_amd.models.seg_model import SegModel
+from dosma_amd.models.stanford_qdess import StanfordQDessUNet2D
 
 __all__ = ["get_model", "model_from_config", "SUPPORTED_MODELS"]
 
-__SUPPORTED_MODELS__ = [OAIUnet2D, IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized]
+__SUPPORTED_MODELS__ = [OAIUnet2D, IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, StanfordQDessUNet2D]
 SUPPORTED_MODELS = [x.ALIASES[0] for x in __SUPPORTED_MODELS__]
 
 

@@ -168,6 +168,44 @@ int qmri_linfit_device(const qmri_linfit_args *args); /* device pointers, asynch
 int qmri_linfit_host(const qmri_linfit_args *args);   /* host pointers, synchronous */
 
 /*
+ * ---- General Levenberg-Marquardt fit (models other than the mono-exponential hot path) -------------------
+ * Replaces curve_fit(func, x, y, p0, ftol=1e-5, maxfev=100) of the reference
+ *   (/root/reference/dosma/core/fitting.py:755-870; per-voxel wrapper :1026-1073) for
+ *     QMRI_MODEL_BIEXP    func = biexponential(x, a1, b1, a2, b2) = a1 e^{b1 x} + a2 e^{b2 x}   (:1021-1023)
+ *     QMRI_MODEL_MONOEXP  func = monoexponential (:1016-1018) with TRUE forward differences (cross-check of
+ *                         qmri_monoexp_fit_*, which emulates them; ~3x the exponentials)
+ * i.e. scipy leastsq -> MINPACK lmdif (fdjac2 forward differences, n + 1 model evaluations per iteration).
+ * Same skip / failure / r2 rules as qmri_monoexp_fit_*; popt is [N][n] float64, n = 2 or 4.
+ */
+typedef enum qmri_model { QMRI_MODEL_MONOEXP = 0, QMRI_MODEL_BIEXP = 1 } qmri_model;
+#define QMRI_LM_MAX_PARAMS 4
+typedef struct qmri_lmfit_args {
+    int32_t model;       /* qmri_model */
+    int32_t y_dtype;     /* qmri_dtype */
+    const void *y;       /* [E][ld] echo-major */
+    int32_t E;           /* n <= E <= QMRI_MAX_ECHOES */
+    int32_t maxfev;      /* 100 */
+    int64_t N;
+    int64_t ld;
+    const double *x;     /* HOST [E] */
+    double p0[QMRI_LM_MAX_PARAMS];          /* scalar initial guess (scipy: ones) */
+    const double *p0v[QMRI_LM_MAX_PARAMS];  /* nullable per-voxel initial guess [N] per parameter */
+    double ftol, xtol, gtol, factor, epsfcn, r2_eps;
+    int32_t use_y_bounds;
+    int32_t device;
+    double y_lo, y_hi;
+    double *popt;        /* [N][n] */
+    double *r2;          /* [N] */
+    int8_t *info;        /* nullable [N]: MINPACK info (0 = skipped) */
+    int16_t *nfev;       /* nullable [N] */
+    void *stream;
+} qmri_lmfit_args;
+void qmri_lmfit_defaults(qmri_lmfit_args *args); /* zero + the reference's constants; model = BIEXP */
+/* nonfinite_flag: device int32, set to 1 if any sample is not finite (scipy check_finite -> ValueError) */
+int qmri_lmfit_device(const qmri_lmfit_args *args, int32_t *nonfinite_flag);
+int qmri_lmfit_host(const qmri_lmfit_args *args); /* host pointers, synchronous; QMRI_ERR_NONFINITE */
+
+/*
  * ---- 2D U-Net segmentation (IWOAIOAIUnet2D / IWOAIOAIUnet2DNormalized) --------------------------------
  * Replaces `model.predict(v, batch_size)` inside SegModel.generate_mask
  *   (/root/reference/dosma/models/oaiunet2d.py:305; graph :197-289; whitening seg_model.py:114-127).

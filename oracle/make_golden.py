@@ -32,8 +32,9 @@ def vols(y3d):
     return [MV(np.array(v), affine=np.eye(4)) for v in y3d]
 
 
-def scipy_info(x, y, p0):
+def scipy_info(x, y, p0, func=None):
     """ier / nfev of the very call the reference makes (fitting.py:1030), per voxel."""
+    func = func or dosma.monoexponential
     from scipy import optimize as sop
 
     ier = np.zeros(y.shape[1], np.int32)
@@ -46,7 +47,7 @@ def scipy_info(x, y, p0):
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                out = sop.curve_fit(dosma.monoexponential, x, yi, p0=p0i, ftol=1e-5, maxfev=100,
+                out = sop.curve_fit(func, x, yi, p0=p0i, ftol=1e-5, maxfev=100,
                                     full_output=True)
             ier[i], nfev[i] = out[4], out[2]["nfev"]
         except RuntimeError:
@@ -259,9 +260,52 @@ def g6():
     save("g6_qdess.npz", pars=np.array([pars[k] for k in ("gl_area", "tg", "tr", "te", "alpha", "t1")]), **out)
 
 
+def g7():
+    """Bi-exponential model: dosma.curve_fit / CurveFitter with func=biexponential."""
+    rng = np.random.default_rng(7)
+    E = 12
+    x = np.linspace(4.0, 92.0, E)
+    n = 1500
+    a1 = rng.uniform(300, 900, n)
+    a2 = rng.uniform(200, 700, n)
+    ts = rng.uniform(5, 15, n)     # short compartment
+    tl = rng.uniform(40, 90, n)    # long compartment
+    clean = a1 * np.exp(-x[:, None] / ts) + a2 * np.exp(-x[:, None] / tl)
+    y = clean + rng.normal(0, 2.0, clean.shape)
+    y[:, :20] = 0.0                                   # skip rule
+    y[:, 20:60] = rng.normal(0, 5.0, (E, 40))         # pure noise: failures / garbage
+    y[:, 60:80] = clean[:, 60:80]                     # noise-free
+    p0 = (500.0, -0.1, 500.0, -0.02)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        popt, r2 = dosma.curve_fit(dosma.biexponential, x, y, p0=p0, num_workers=NW)
+        ier, nfev = scipy_info(x, y, p0, func=dosma.biexponential)
+        out.update(popt=popt, r2=r2, ier=ier, nfev=nfev)
+        # default p0 (ones) -- mostly failures: the failure class must agree
+        popt1, r21 = dosma.curve_fit(dosma.biexponential, x, y[:, :300], num_workers=NW)
+        out.update(popt_ones=popt1, r2_ones=r21)
+        # float32 / int16 samples, per-voxel p0 for two parameters, y_bounds
+        y32 = y.astype(np.float32)
+        p0v = {"a1": np.abs(y32[0].astype(np.float64)) * 0.6 + 1.0, "b1": -0.1, "a2": 400.0,
+               "b2": np.full(n, -0.015)}
+        popt2, r22 = dosma.curve_fit(dosma.biexponential, x, y32, p0=p0v, y_bounds=(-50, 1500), num_workers=NW)
+        out.update(y32=y32, p0v_a1=p0v["a1"], p0v_b2=p0v["b2"], popt_f32=popt2, r2_f32=r22)
+        # CurveFitter on volumes with a mask and host post-processing
+        shape = (15, 10, 10)
+        yv = y.reshape((E,) + shape)
+        mask = (rng.uniform(size=shape) < 0.6)
+        cf = dosma.CurveFitter(dosma.biexponential, p0=p0, out_ufuncs=[None, lambda v: 1 / np.abs(v), None,
+                                                                     lambda v: 1 / np.abs(v)],
+                               out_bounds=(0, 2000), r2_threshold=0.9, nan_to_num=0.0, num_workers=NW)
+        pm, rm = cf.fit(x, vols(yv), mask=MV(mask.astype(np.uint8), np.eye(4)))
+        out.update(mask=mask, popt_cf=pm.A, r2_cf=rm.A)
+    save("g7_biexp.npz", x=x, y=y, p0=np.array(p0), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for name in which:
         t = time.time()
         print(name, "...")

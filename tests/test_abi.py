@@ -55,6 +55,9 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         "         offsetof(qmri_unet2d_desc, bn_eps));\n"
         '  printf("%zu %zu %zu %zu %zu\\n", sizeof(qmri_dess_args), offsetof(qmri_dess_args, N),\n'
         "         offsetof(qmri_dess_args, lo), offsetof(qmri_dess_args, beta), offsetof(qmri_dess_args, stream));\n"
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(qmri_lmfit_args), offsetof(qmri_lmfit_args, x),\n'
+        "         offsetof(qmri_lmfit_args, p0v), offsetof(qmri_lmfit_args, ftol), offsetof(qmri_lmfit_args, y_lo),\n"
+        "         offsetof(qmri_lmfit_args, stream));\n"
         "  return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -68,6 +71,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
             _lib.QmriUnet2dDesc.bn_eps.offset]
     D = _lib.QmriDessArgs
     want += [ctypes.sizeof(D), D.N.offset, D.lo.offset, D.beta.offset, D.stream.offset]
+    M = _lib.QmriLmfitArgs
+    want += [ctypes.sizeof(M), M.x.offset, M.p0v.offset, M.ftol.offset, M.y_lo.offset, M.stream.offset]
     assert got == want
 
 

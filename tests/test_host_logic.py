@@ -85,7 +85,9 @@ def test_model_recognition():
     assert F._model_of(monoexponential) == "monoexponential"
     assert F._model_of(lambda x, a, b: a * np.exp(b * x)) == "monoexponential"
     assert F._model_of(lambda t, s0, r: s0 * np.exp(t * r)) == "monoexponential"
-    for bad in (lambda x, a, b: a * np.exp(-b * x), lambda x, a: a * x, F.biexponential,
+    assert F._model_of(F.biexponential) == "biexponential"
+    for bad in (lambda x, a, b: a * np.exp(-b * x), lambda x, a: a * x,
+                lambda x, a, b, c, d: a * np.exp(b * x) + c * np.exp(d * x),  # only the reference's own function
                 lambda x, a, b: a + b * x):
         with pytest.raises(NotImplementedError):
             F._model_of(bad)

@@ -5,18 +5,23 @@ import pytest
 
 from dosma_amd.models import SUPPORTED_MODELS, weights as W, whiten_volume
 from dosma_amd.models.oaiunet2d import IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, OAIUnet2D
+from dosma_amd.models.stanford_qdess import StanfordQDessUNet2D
 from oracle import unet_oracle as uo
 
 
 def test_aliases_nonempty_and_disjoint():
     """reference tests/models/test_util.py:6-34."""
-    models = [OAIUnet2D, IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized]
+    models = [OAIUnet2D, IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, StanfordQDessUNet2D]
     aliases = [set(m.ALIASES) for m in models]
     assert all(a and "" not in a for a in aliases)
     for i in range(len(aliases)):
         for j in range(i + 1, len(aliases)):
             assert not (aliases[i] & aliases[j])
-    assert SUPPORTED_MODELS == ["oai-unet2d", "iwoai-2019-t6", "iwoai-2019-t6-normalized"]
+    # the reference registry (models/util.py:18) + the SKM-TEA template (stanford_qdess.py:60), which the
+    # reference only exposes by class
+    assert SUPPORTED_MODELS == ["oai-unet2d", "iwoai-2019-t6", "iwoai-2019-t6-normalized",
+                                "stanford-qdess-2021-unet2d"]
+    assert StanfordQDessUNet2D.CATEGORIES == ("pc", "fc", "tc", "men")
 
 
 def test_weights_container(tmp_path):

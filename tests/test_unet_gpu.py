@@ -181,3 +181,30 @@ def test_generate_mask_drop_in(small_net, tmp_path):
     o4 = m4.generate_mask(mv)
     assert isinstance(o4, MedicalVolume) and o4.shape == mv.shape
     assert (o4.volume == out["fc"].volume).mean() > 0.999
+
+
+@pytest.mark.gpu
+def test_stanford_qdess_template(small_net):
+    """stanford_qdess.py:158-201: 3D = RSS volume, 4D (..., 2) = the two echoes -> RSS first; whiten(eps=1e-8);
+    dict pc / fc / tc / men."""
+    from dosma_amd import MedicalVolume
+    from dosma_amd.models import StanfordQDessUNet2D, get_model
+
+    w, _ = small_net
+    rng = np.random.default_rng(21)
+    H, Wd, S = 64, 32, 5
+    e = (rng.standard_normal((H, Wd, S, 2)) * 50 + 120).astype(np.float32)
+    aff = np.array([[0, 0, 1.5, -40.0], [0, -0.4, 0, 60.0], [-0.4, 0, 0, 70.0], [0, 0, 0, 1.0]])
+    model = StanfordQDessUNet2D((H, Wd, 1), w)
+    rss = np.sqrt(np.sum(e.astype(np.float64) ** 2, axis=-1))
+    out4 = model.generate_mask(MedicalVolume(e, aff))
+    out3 = get_model("skm-tea-unet2d", (H, Wd, 1), w).generate_mask(MedicalVolume(rss, aff))
+    assert list(out4) == ["pc", "fc", "tc", "men"] == list(out3)
+    xw = uo.whiten_volume(rss, eps=1e-8).astype(np.float32)
+    ref = uo.forward(w, np.transpose(xw, (2, 0, 1)), dtype="float64") > 0
+    for i, k in enumerate(out4):
+        assert out4[k].shape == (H, Wd, S) and out4[k].dtype == np.uint8
+        assert np.array_equal(out4[k].volume, out3[k].volume)
+        assert (out4[k].volume == np.transpose(ref[..., i], (1, 2, 0))).mean() > 0.9999
+    with pytest.raises(ValueError):
+        model.generate_mask(MedicalVolume(e[..., :1].repeat(3, -1), aff))

@@ -16,5 +16,6 @@ from dosma_amd.fitting import (  # noqa: F401
     polyfit,
 )
 from dosma_amd.med_volume import MedicalVolume  # noqa: F401
+from dosma_amd.io import ImageDataFormat, NiftiReader, NiftiWriter  # noqa: F401,E402
 
 __version__ = "0.1.0"

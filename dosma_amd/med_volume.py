@@ -142,6 +142,12 @@ class MedicalVolume(NDArrayOperatorsMixin):
         return headers.reshape((1,) * (self._volume.ndim - headers.ndim) + headers.shape)
 
     # ------------------------------------------------------------------ orientation
+    def save_volume(self, file_path: str, data_format=None):
+        """Write the volume (reference med_volume.py:160-175); only NIfTI is built."""
+        from dosma_amd.io import ImageDataFormat, get_writer
+
+        get_writer(ImageDataFormat.nifti if data_format is None else data_format).save(self, file_path)
+
     def reformat(self, new_orientation, inplace=False):
         """Transpose + flip the first three axes so that ``self.orientation == new_orientation``.
 

@@ -4,11 +4,12 @@ Mirror of the reference's ``dosma/core/quant_vals.py`` -- ``QuantitativeValue`` 
 + ``additional_volumes["r2"]``, ``to_metrics`` :145-229, ``get_qv`` :245-263) and ``T1Rho`` / ``T2`` /
 ``T2Star`` (:306-336).  What the scan classes do with the outputs of ``MonoExponentialFit.fit``:
 ``qv.T1Rho(t1rho_map); qv.add_additional_volume("r2", r2)`` (cube_quant.py:180-183).
-``save_data`` / ``load_data`` (:78-126) are NIfTI I/O -- SURVEY 8(f) row N3, not built yet.
+``save_data`` / ``load_data`` (:78-126) go through ``dosma_amd.io`` (NIfTI-1).
 """
 from abc import ABC
 from collections import defaultdict
 from enum import Enum
+import os
 from typing import Callable, Dict, Tuple, Union
 
 import numpy as np
@@ -42,10 +43,27 @@ class QuantitativeValue(ABC):
         self.additional_volumes[name] = volume
 
     def save_data(self, dir_path, data_format=None):
-        raise NotImplementedError("NIfTI I/O of quantitative maps is SURVEY.md 8(f) row N3 (not built yet)")
+        """Maps go to ``dir_path/NAME/NAME.nii.gz`` (+ ``NAME-<extra>.nii.gz``), always NIfTI (reference :78-108)."""
+        from dosma_amd.io import ImageDataFormat
+
+        if data_format is not None and data_format != ImageDataFormat.nifti:
+            import warnings
+
+            warnings.warn("Due to bit depth issues, only nifti format is supported for quantitative values. "
+                          "Writing as nifti file...")
+        if self.volumetric_map is not None:
+            filepath = os.path.join(dir_path, self.NAME, "{}.nii.gz".format(self.NAME))
+            self.volumetric_map.save_volume(filepath, data_format=ImageDataFormat.nifti)
+        for name, vol in self.additional_volumes.items():
+            filepath = os.path.join(dir_path, self.NAME, "{}-{}.nii.gz".format(self.NAME, name))
+            vol.save_volume(filepath, data_format=ImageDataFormat.nifti)
 
     def load_data(self, dir_path):
-        raise NotImplementedError("NIfTI I/O of quantitative maps is SURVEY.md 8(f) row N3 (not built yet)")
+        """Reload ``dir_path/NAME/NAME.nii.gz``; additional volumes are not reloaded (reference :110-124)."""
+        from dosma_amd.io import generic_load
+
+        file_path = os.path.join(dir_path, self.NAME, "{}.nii.gz".format(self.NAME))
+        self.volumetric_map = generic_load(file_path, expected_num_volumes=1)
 
     def to_metrics(self, mask: MedicalVolume = None, labels: Dict[int, str] = None,
                    bounds: Tuple[float, float] = None, closed: str = "right",

@@ -171,13 +171,31 @@ __device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, doub
     x1 = l0 ? wa0 : wa1;
 }
 
+#ifdef QMRI_STATS
+// debug build only (scripts/fit_stats.py): lane-utilisation counters per phase
+// [0] loop rounds (x64 = lane slots) [1] busy lanes [2] lanes entering lmpar [3] lane lmpar iterations
+// [4] wave lmpar iterations (max over lanes, summed) [5] lanes in Jacobian+QR [6] lanes finishing
+// [7] rounds with a refill
+__device__ unsigned long long g_fit_stats[8];
+#define QMRI_STAT_ADD(i, v) st_acc[i] += (unsigned long long)(v)
+#else
+#define QMRI_STAT_ADD(i, v)
+#endif
+
 // MINPACK lmpar for n = 2: step p (by original index) with ||diag*p|| ~ delta, and the LM parameter.
 // ir11, ir22 = 1/r11, 1/r22 and idg0, idg1 = 1/diag are maintained by the caller (they change only at
 // a QR).  ((fp/delta)/temp)/temp is evaluated as fp / (delta * temp^2): no square root of temp^2.
 __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, double ir11, double ir22,
                                        int l0, double dg0, double dg1, double idg0, double idg1,
                                        double qtb0, double qtb1, double delta, double &par, double &x0,
-                                       double &x1) {
+                                       double &x1
+#ifdef QMRI_STATS
+                                       , int &iters_out
+#endif
+                                       ) {
+#ifdef QMRI_STATS
+    iters_out = 0;
+#endif
     const double dwarf = DBL_MIN;
     const double dl0 = l0 ? dg1 : dg0;  // diag(ipvt(0))
     const double dl1 = l0 ? dg0 : dg1;  // diag(ipvt(1))
@@ -225,6 +243,9 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, doubl
     par = fmin(par, paru);
     if (par == 0.0) par = gnorm * idx;
     for (int iter = 1;; ++iter) {
+#ifdef QMRI_STATS
+        iters_out = iter;
+#endif
         if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
         const double sp = sqrt(par);
         double rsd0, rsd1, s10;
@@ -381,7 +402,11 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     int qpos = 0, qend = 0;
     bool more = true;
 
+#ifdef QMRI_STATS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
+        QMRI_STAT_ADD(0, 1);
         // ======================= refill: idle lanes pull voxels =======================
         {
             unsigned long long idle = __ballot(state == ST_IDLE);
@@ -548,15 +573,28 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
             }
         }
         if (!__ballot(state != ST_IDLE)) break;
+        QMRI_STAT_ADD(1, __popcll(__ballot(state != ST_IDLE)));
+        QMRI_STAT_ADD(2, __popcll(__ballot(state == ST_ITER)));
 
         // ======================= one LM step for every busy lane =======================
+#ifdef QMRI_STATS
+        int lm_it_lane = 0;
+        bool did_qr = false, did_finish = false;
+#endif
         if (state != ST_IDLE) {
             double ta, tb;           // trial point
             double p0 = 0, p1 = 0;   // step (by parameter)
             double pnorm = 0;
             if (state == ST_ITER) {
+#ifdef QMRI_STATS
+                int lm_it = 0;
+                lmpar2(r11, r12, r22, ir11, ir22, l0, dg0, dg1, idg0, idg1, qtf0, qtf1, delta, par,
+                       p0, p1, lm_it);
+                lm_it_lane = lm_it;
+#else
                 lmpar2(r11, r12, r22, ir11, ir22, l0, dg0, dg1, idg0, idg1, qtf0, qtf1, delta, par,
                        p0, p1);
+#endif
                 p0 = -p0;
                 p1 = -p1;
                 ta = pa + p0;
@@ -661,6 +699,9 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
             }
 
             if (info == 0 && accepted) {
+#ifdef QMRI_STATS
+                did_qr = true;
+#endif
                 // ---- Jacobian at the (new) current point + Householder QR with column pivoting ----
                 // lmdif's forward differences (fdjac2: h_j = sqrt(eps)*|x_j|, J_j = (f(x+h_j e_j)-f)/h_j),
                 // charged n = 2 evaluations, but evaluated WITHOUT new exponentials: the a-column reuses
@@ -807,9 +848,25 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 finish_voxel(A, vox, oa, ob, r2, info, nfev, false);
                 state = ST_IDLE;
                 nfev = 0;
+#ifdef QMRI_STATS
+                did_finish = true;
+#endif
             }
         }
+#ifdef QMRI_STATS
+        for (int k = 1; k <= 10; ++k) {
+            const unsigned long long m = __ballot(lm_it_lane >= k);
+            st_acc[3] += __popcll(m);
+            st_acc[4] += m ? 1 : 0;
+        }
+        st_acc[5] += __popcll(__ballot(did_qr));
+        st_acc[6] += __popcll(__ballot(did_finish));
+#endif
     }
+#ifdef QMRI_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_fit_stats[i], st_acc[i]);
+#endif
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------------
@@ -900,3 +957,14 @@ hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream) {
 }
 
 }  // namespace qmri
+
+#ifdef QMRI_STATS
+extern "C" int qmri_debug_fit_stats(unsigned long long *out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::g_fit_stats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(qmri::g_fit_stats), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

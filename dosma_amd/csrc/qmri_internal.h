@@ -118,8 +118,12 @@ struct ConvKArgs {
     const float *head_b; // [head_nc]
     float *logits;       // [pixels][head_nc]
     unsigned char *mask; // [pixels][head_nc]  (logit > 0)
+    int dbg;             // experiments only (QMRI_RW_DBG): bit mask of phases to skip in conv_rw_kernel
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
+// register-weights kernel for the Cout = 32 layers in plain-bf16 mode (unet_rw.hip)
+bool conv_rw_supported(const ConvKArgs &k);
+hipError_t conv_rw_launch(const ConvKArgs &k, hipStream_t stream);
 hipError_t conv3x3_c1_launch(const float *x, int B, int H, int W, const float *w, const float *bias,
                              int Cout, void *y, long long ldy, int yoff, int act_bf16, hipStream_t stream);
 hipError_t maxpool2_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y,

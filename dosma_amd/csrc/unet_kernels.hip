@@ -511,6 +511,7 @@ static int conv_tile_rows(int bn) {
 hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream) {
     // precision 0 (plain bf16): bf16 activations in HBM;  precision 1 (split-bf16 x3): fp32 activations
     ConvKArgs k = k0;
+    if (!split3 && conv_rw_supported(k)) return conv_rw_launch(k, stream);
     // the fused transposed convolution keeps 4 accumulator sets: cap the channel tile at 64
     const int bn = k.deconv ? ((split3 && k.Cout % 64 == 0) ? 64 : 32)
                             : (k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32));

@@ -36,14 +36,20 @@ namespace {
 
 __device__ uint4 g_zero16;  // source of the halo pixels outside the image (zero padding)
 
-constexpr int kTW = 32, kTH = 8;              // output tile: 8 rows of 32 pixels
-constexpr int kHW = kTW + 2, kHH = kTH + 2;   // halo 34 x 10
-constexpr int kHPix = kHW * kHH;              // 340
-constexpr int kORow = 36;                     // bf16 elements per output-tile row in LDS: 72 B -> conflict-free ds_write_b64
-constexpr int kWinW = kTW + 4, kWinH = kTH + 4;  // fused first layer: 36 x 12 window of the 1-channel image
+constexpr int kTW = 32;                       // output tile: rows of 32 pixels (one MFMA row-tile each)
+constexpr int kHW = kTW + 2;                  // halo width
+constexpr int kWinW = kTW + 4;                // fused first layer: window of the 1-channel image, 36 wide
 
-template <int CIN>
+// NT = 32-channel output tiles (waves along N): Cout = 32 NT.  A block's 4 waves are NT along N x 4 / NT along M,
+// each wave owns 2 pixel rows x 32 channels, so the tile is 8 (NT = 1) or 4 (NT = 2) rows of 32 pixels.
+template <int CIN, int NT>
 struct RwCfg {
+    static constexpr int COUT = 32 * NT;
+    static constexpr int TH = 2 * (4 / NT);              // tile rows
+    static constexpr int HH = TH + 2;                    // halo rows
+    static constexpr int HPIX = kHW * HH;                // 340 / 204
+    static constexpr int WINH = TH + 4;
+    static constexpr int OROW = NT == 1 ? 36 : 68;       // bf16 per output-tile row in LDS: 72 / 136 B -> conflict-free ds_write_b64
     static constexpr int ROWB = CIN * 2;                 // bytes per halo pixel
     static constexpr int GROUPS = CIN / 8;               // 16-byte chunks per pixel
     static constexpr int GSHIFT = CIN == 32 ? 2 : 3;     // log2(GROUPS)
@@ -54,18 +60,18 @@ struct RwCfg {
     // lane-linear, so the pad slots are DMA lanes too: they read the zero line.
     static constexpr int SPP = GROUPS + 1;               // 16-byte slots per pixel incl. the pad
     static constexpr int LROW = ROWB + 16;               // bytes per pixel row in LDS
-    static constexpr int NSLOT = kHPix * SPP;
+    static constexpr int NSLOT = HPIX * SPP;
     static constexpr int NGLDS = (NSLOT + 63) / 64;      // wave-level DMA instructions per tile (1 KiB each)
     static constexpr int PER_WAVE = (NGLDS + 3) / 4;
     static constexpr int HALO_BYTES = NGLDS * 1024;      // lane-linear image incl. the tail of the last instruction
     static constexpr int KSTEPS = CIN / 16;
     static constexpr int NFRAG = 9 * KSTEPS;
-    static constexpr int OTILE_BYTES = kTW * kTH * kORow * 2;
-    static constexpr int MISC_FLOATS = kWinW * kWinH + 320 + 132 + 96;  // c1 window | c1 w, b | head w, b | bias, scale, shift
+    static constexpr int OTILE_BYTES = kTW * TH * OROW * 2;
+    static constexpr int MISC_FLOATS = kWinW * WINH + 320 + 132 + 3 * COUT;  // c1 window | c1 w, b | head w, b | bias, scale, shift
 };
-template <int CIN, int NBUF>
+template <int CIN, int NT, int NBUF>
 constexpr size_t rw_lds_bytes() {
-    return (size_t)NBUF * RwCfg<CIN>::HALO_BYTES + RwCfg<CIN>::OTILE_BYTES + RwCfg<CIN>::MISC_FLOATS * 4;
+    return (size_t)NBUF * RwCfg<CIN, NT>::HALO_BYTES + RwCfg<CIN, NT>::OTILE_BYTES + RwCfg<CIN, NT>::MISC_FLOATS * 4;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -73,35 +79,39 @@ typedef __attribute__((address_space(3))) void lds_void;
 // Three 16-byte LDS reads the compiler does not see as LDS accesses: while an LDS-DMA is in flight hipcc puts
 // s_waitcnt vmcnt(0) in front of every ds_read it cannot prove disjoint from the DMA's destination, which would
 // drain the prefetch of the next tile at the start of the epilogue.
+template <int STRIDE_BYTES>
 __device__ __forceinline__ void lds_read3_f4(const float *p, float4 &a, float4 &b, float4 &c) {
     const unsigned off = (unsigned)(size_t)(lds_void *)p;
-    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:128\n\tds_read_b128 %2, %3 offset:256\n\ts_waitcnt lgkmcnt(0)"
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c)
-                 : "v"(off)
+                 : "v"(off), "n"(STRIDE_BYTES), "n"(2 * STRIDE_BYTES)
                  : "memory");
 }
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int CIN, bool C1, bool HEAD, int NBUF, int MINW>
+template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW>
 __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
-    using C = RwCfg<CIN>;
+    using C = RwCfg<CIN, NT>;
+    static_assert(NT == 1 || (!C1 && !HEAD), "the fused first layer and the head belong to 32-channel layers");
+    constexpr int kTH = C::TH, kHPix = C::HPIX, kORow = C::OROW, kWinH = C::WINH, COUT = C::COUT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *halo0 = smem;
     __bf16 *otile = reinterpret_cast<__bf16 *>(smem + NBUF * C::HALO_BYTES);
     float *c1img = reinterpret_cast<float *>(smem + NBUF * C::HALO_BYTES + C::OTILE_BYTES);  // [12][36]
     float *c1w = c1img + kWinW * kWinH;  // [9][32] + [32]
     float *hw = c1w + 320;               // head [32][4] (classes padded with zeros) + bias [4]
-    float *prm = hw + 132;               // bias | scale | shift, [32] each
+    float *prm = hw + 132;               // bias | scale | shift, [COUT] each
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % NT, wm = wave / NT;  // this wave's 32-channel tile and row pair
 
     // ---- all weights of the layer -> registers, once per block: fragment (tap, kk): lane (row = lane & 31,
     // k-group = lane >> 5) holds W[row][(chunk * 9 + tap) * 32 + (kk & 1) * 16 + (lane >> 5) * 8 .. + 8], chunk = kk >> 1
     bf16x8 wfrag[C::NFRAG];
     {
-        const __bf16 *wrow = A.w_hi + (long long)(lane & 31) * (9 * CIN) + (lane >> 5) * 8;
+        const __bf16 *wrow = A.w_hi + (long long)(wn * 32 + (lane & 31)) * (9 * CIN) + (lane >> 5) * 8;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -109,8 +119,8 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
                 wfrag[t * C::KSTEPS + kk] =
                     *reinterpret_cast<const bf16x8 *>(wrow + ((kk >> 1) * 9 + t) * 32 + (kk & 1) * 16);
     }
-    if (tid < 96) {
-        const int c = tid & 31, which = tid >> 5;
+    if (tid < 3 * COUT) {
+        const int c = tid % COUT, which = tid / COUT;
         prm[tid] = which == 0 ? (A.bias ? A.bias[c] : 0.f) : which == 1 ? (A.scale ? A.scale[c] : 1.f)
                                                                          : (A.shift ? A.shift[c] : 0.f);
     }
@@ -168,12 +178,12 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias_r[g] = *reinterpret_cast<const float4 *>(prm + 8 * g + 4 * (lane >> 5));
+    for (int g = 0; g < 4; ++g) bias_r[g] = *reinterpret_cast<const float4 *>(prm + wn * 32 + 8 * g + 4 * (lane >> 5));
 
     // un-shifted halo pixel of this lane in the wave's two row-tiles: tile row 2 * wave + i, column lane & 31
     int hpb[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) hpb[i] = (2 * wave + i + 1) * kHW + (lane & 31) + 1;
+    for (int i = 0; i < 2; ++i) hpb[i] = (2 * wm + i + 1) * kHW + (lane & 31) + 1;
 
     const int tiles_x = A.W / kTW, tiles_y = A.H / kTH;
     const int tiles_per_img = tiles_x * tiles_y;
@@ -228,8 +238,8 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
     if (have_prev && !(A.dbg & 8)) {                                                                           \
         const long long pib_ = (long long)pb_ * A.H * A.W;                                                     \
         if (A.y) {                                                                                             \
-            for (int idx = tid; idx < kTW * kTH * 4; idx += 256) {                                             \
-                const int row = idx >> 2, c = idx & 3;                                                         \
+            for (int idx = tid; idx < kTW * kTH * (COUT / 8); idx += 256) {                                    \
+                const int row = idx / (COUT / 8), c = idx % (COUT / 8);                                        \
                 const int yy = py0 + (row >> 5), xx = px0 + (row & 31);                                        \
                 const uint2 v0 = *reinterpret_cast<const uint2 *>(otile + row * kORow + c * 8);                \
                 const uint2 v1 = *reinterpret_cast<const uint2 *>(otile + row * kORow + c * 8 + 4);            \
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         }                                                                                                      \
         if (A.pool_y) { /* MaxPooling2D(2x2) of the tile (oaiunet2d.py:234-243): 4 x 16 pooled pixels x 4 chunks */ \
             const int Hp = A.H >> 1, Wp = A.W >> 1;                                                            \
-            const int q = tid >> 2, c = tid & 3;                                                               \
+            const int q = tid / (COUT / 8), c = tid % (COUT / 8); /* 16 x TH/2 pooled pixels x COUT/8 = 256 */  \
             const int qy = q >> 4, qx = q & 15;                                                                \
             const __bf16 *p0 = otile + ((2 * qy) * kTW + 2 * qx) * kORow + c * 8;                              \
             bf16x8 o;                                                                                          \
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         if (HEAD && lane < 32) { /* rows 0..3 of the head MFMA = classes, column = this lane's pixel */    \
             const int NC = A.head_nc;                                                                          \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
-                const long long pix = pib_ + (long long)(py0 + 2 * wave + i) * A.W + px0 + lane;               \
+                const long long pix = pib_ + (long long)(py0 + 2 * wm + i) * A.W + px0 + lane;                 \
                 if (NC == 4) {                                                                                 \
                     if (A.logits) *reinterpret_cast<float4 *>(A.logits + pix * 4) = plog[i];                   \
                     if (A.mask) *reinterpret_cast<unsigned *>(A.mask + pix * 4) = pmask[i];                    \
@@ -395,13 +405,13 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         if (!(A.dbg & 4))
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = (2 * wave + i) * kTW + (lane & 31);  // pixel of the tile
+            const int r = (2 * wm + i) * kTW + (lane & 31);  // pixel of the tile
             bf16x8 vb[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co0 = 8 * g + 4 * (lane >> 5);
                 float4 pb = bias_r[g], ps, pt;
-                if (!fold) lds_read3_f4(prm + co0, pb, ps, pt);
+                if (!fold) lds_read3_f4<COUT * 4>(prm + wn * 32 + co0, pb, ps, pt);
                 float v[4] = {acc[i][4 * g] + pb.x, acc[i][4 * g + 1] + pb.y, acc[i][4 * g + 2] + pb.z,
                               acc[i][4 * g + 3] + pb.w};
                 if (A.relu) {
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
                     bf16x4 o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = vb[g >> 1][(g & 1) * 4 + q];
-                    *reinterpret_cast<bf16x4 *>(otile + r * kORow + co0) = o;
+                    *reinterpret_cast<bf16x4 *>(otile + r * kORow + wn * 32 + co0) = o;
                 }
             }
             if (HEAD) {
@@ -449,10 +459,10 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
 #undef QMRI_RW_ISSUE_HALO
 }
 
-template <int CIN, bool C1, bool HEAD, int NBUF, int MINW>
+template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW>
 hipError_t rw_launch_one(const ConvKArgs &k, int num_cu, hipStream_t stream) {
-    auto fn = conv_rw_kernel<CIN, C1, HEAD, NBUF, MINW>;
-    const size_t lds = rw_lds_bytes<CIN, NBUF>();
+    auto fn = conv_rw_kernel<CIN, NT, C1, HEAD, NBUF, MINW>;
+    const size_t lds = rw_lds_bytes<CIN, NT, NBUF>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -460,7 +470,7 @@ hipError_t rw_launch_one(const ConvKArgs &k, int num_cu, hipStream_t stream) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    const long long ntiles = (long long)k.B * (k.H / kTH) * (k.W / kTW);
+    const long long ntiles = (long long)k.B * (k.H / RwCfg<CIN, NT>::TH) * (k.W / kTW);
     long long grid = (long long)num_cu * per_cu;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, k);
@@ -478,8 +488,9 @@ int env_int(const char *name, int dflt) {
 bool conv_rw_supported(const ConvKArgs &k) {
     static const int enabled = env_int("QMRI_CONV_RW", 1);
     if (!enabled) return false;
-    if (k.deconv || k.ntaps != 9 || k.Cout != 32 || (k.Cin != 32 && k.Cin != 64)) return false;
-    if (k.H % kTH || k.W % kTW || k.sy != 1 || k.sx != 1 || k.py || k.px || k.Ho != k.H || k.Wo != k.W) return false;
+    if (k.deconv || k.ntaps != 9 || (k.Cout != 32 && k.Cout != 64) || (k.Cin != 32 && k.Cin != 64)) return false;
+    if (k.Cout == 64 && (k.c1_x || k.head_w)) return false;
+    if (k.H % 8 || k.W % kTW || k.sy != 1 || k.sx != 1 || k.py || k.px || k.Ho != k.H || k.Wo != k.W) return false;
     if (k.c1_x && k.Cin != 32) return false;
     if (!k.c1_x && (k.ldx % 8 || k.xoff % 8)) return false;  // 16-byte DMA pieces
     if (k.head_w && (k.head_nc < 1 || k.head_nc > 4)) return false;
@@ -501,16 +512,20 @@ hipError_t conv_rw_launch(const ConvKArgs &k0, hipStream_t stream) {
     static const int nbuf64 = env_int("QMRI_RW_NBUF64", 1);
     ConvKArgs k = k0;
     k.dbg = dbg;
-    if (k.Cin == 64) {
-        if (k.head_w) return nbuf64 == 2 ? rw_launch_one<64, false, true, 2, 1>(k, num_cu, stream)
-                                         : rw_launch_one<64, false, true, 1, 2>(k, num_cu, stream);
-        return nbuf64 == 2 ? rw_launch_one<64, false, false, 2, 1>(k, num_cu, stream)
-                           : rw_launch_one<64, false, false, 1, 2>(k, num_cu, stream);
+    if (k.Cout == 64) {
+        if (k.Cin == 64) return rw_launch_one<64, 2, false, false, 1, 2>(k, num_cu, stream);
+        return rw_launch_one<32, 2, false, false, 2, 2>(k, num_cu, stream);
     }
-    if (k.c1_x) return k.head_w ? rw_launch_one<32, true, true, 1, 2>(k, num_cu, stream)
-                                : rw_launch_one<32, true, false, 1, 3>(k, num_cu, stream);
-    return k.head_w ? rw_launch_one<32, false, true, 2, 2>(k, num_cu, stream)
-                    : rw_launch_one<32, false, false, 2, 2>(k, num_cu, stream);
+    if (k.Cin == 64) {
+        if (k.head_w) return nbuf64 == 2 ? rw_launch_one<64, 1, false, true, 2, 1>(k, num_cu, stream)
+                                         : rw_launch_one<64, 1, false, true, 1, 2>(k, num_cu, stream);
+        return nbuf64 == 2 ? rw_launch_one<64, 1, false, false, 2, 1>(k, num_cu, stream)
+                           : rw_launch_one<64, 1, false, false, 1, 2>(k, num_cu, stream);
+    }
+    if (k.c1_x) return k.head_w ? rw_launch_one<32, 1, true, true, 1, 2>(k, num_cu, stream)
+                                : rw_launch_one<32, 1, true, false, 1, 3>(k, num_cu, stream);
+    return k.head_w ? rw_launch_one<32, 1, false, true, 2, 2>(k, num_cu, stream)
+                    : rw_launch_one<32, 1, false, false, 2, 2>(k, num_cu, stream);
 }
 
 }  // namespace qmri

@@ -191,7 +191,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     return {
         "metric": "UNet2D slices/sec (IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv)",
         "value": res["bf16"], "unit": "slices/s", "steps": steps, "batch": args.unet_batch,
-        "precision": "bf16 operands, fp32 accumulate, fp32 activations in HBM",
+        "precision": "plain-bf16 mode: bf16 weights and activations (in HBM too), fp32 accumulate; the split-bf16x3 parity mode is reported beside it",
         "slices_per_s_bf16x3": res["bf16x3"],
         "data": "synthetic (random He weights of the reference architecture, random-normal input)",
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

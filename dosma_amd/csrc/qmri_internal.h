@@ -118,7 +118,6 @@ struct ConvKArgs {
     const float *head_b; // [head_nc]
     float *logits;       // [pixels][head_nc]
     unsigned char *mask; // [pixels][head_nc]  (logit > 0)
-    int dbg;             // experiments only (QMRI_RW_DBG): bit mask of phases to skip in conv_rw_kernel
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
 // register-weights kernel for the Cout = 32 layers in plain-bf16 mode (unet_rw.hip)

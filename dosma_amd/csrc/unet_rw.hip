@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
     for (int i = 0; i < 2; ++i) plog[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define QMRI_RW_FLUSH_PREV()                                                                                   \
-    if (have_prev && !(A.dbg & 8)) {                                                                           \
+    if (have_prev) {                                                                           \
         const long long pib_ = (long long)pb_ * A.H * A.W;                                                     \
         if (A.y) {                                                                                             \
             for (int idx = tid; idx < kTW * kTH * (COUT / 8); idx += 256) {                                    \
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        if (!(A.dbg & 2)) {
+        {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int code = (int)((A.taps >> (4 * t)) & 0xF);  // (dy+1) | (dx+1) << 2
@@ -402,7 +402,6 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         // registers (MFMA); y / pool: 4 x 8-byte LDS writes per row-tile (bf16 x 4 channels).  The global stores are
         // deferred to the next iteration (QMRI_RW_FLUSH_PREV).
         if (want_tile) __syncthreads();  // every wave has flushed the previous output tile
-        if (!(A.dbg & 4))
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (2 * wm + i) * kTW + (lane & 31);  // pixel of the tile
@@ -508,10 +507,8 @@ hipError_t conv_rw_launch(const ConvKArgs &k0, hipStream_t stream) {
         num_cu = prop.multiProcessorCount;
     }
     (void)hipGetLastError();
-    static const int dbg = env_int("QMRI_RW_DBG", 0);
     static const int nbuf64 = env_int("QMRI_RW_NBUF64", 1);
-    ConvKArgs k = k0;
-    k.dbg = dbg;
+    const ConvKArgs &k = k0;
     if (k.Cout == 64) {
         if (k.Cin == 64) return rw_launch_one<64, 2, false, false, 1, 2>(k, num_cu, stream);
         return rw_launch_one<32, 2, false, false, 2, 2>(k, num_cu, stream);

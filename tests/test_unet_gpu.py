@@ -208,3 +208,43 @@ def test_stanford_qdess_template(small_net):
         assert (out4[k].volume == np.transpose(ref[..., i], (1, 2, 0))).mean() > 0.9999
     with pytest.raises(ValueError):
         model.generate_mask(MedicalVolume(e[..., :1].repeat(3, -1), aff))
+
+
+def _bf16_round(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw", [(32, 32, (16, 64)), (64, 32, (8, 32)), (32, 64, (24, 32)), (64, 64, (8, 96)),
+                                         (32, 32, (40, 32))])
+def test_register_weights_kernel_layers(cin, cout, hw):
+    """Shapes that dispatch to conv_rw_kernel (unet_rw.hip: plain-bf16 mode, Cout 32 / 64, Cin 32 / 64, H % 8 == 0,
+    W % 32 == 0), checked against the exact convolution of the bf16-rounded operands: what remains is fp32
+    accumulation order and the bf16 rounding of the stored output (2^-9 relative)."""
+    rng = np.random.default_rng(cin + 3 * cout + hw[0])
+    B, (H, W) = 3, hw
+    x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    xb, kb = _bf16_round(x), _bf16_round(k)
+    for relu in (True, False):
+        ref = torch_conv(xb, kb, b, relu=relu, transposed=False) * sc + sh
+        y = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=relu, precision="bf16")
+        assert y.shape == ref.shape
+        err = np.abs(y - ref)
+        assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), err.max()
+    # borders: every tile of the image touches the zero padding somewhere; an all-ones input makes a
+    # misplaced halo pixel visible as a wrong count of taps
+    ones = np.ones((1, H, W, cin), np.float32)
+    k1 = np.full((3, 3, cin, cout), 2.0 ** -6, np.float32)
+    y = L.conv2d_nhwc_host(ones, k1, np.zeros(cout, np.float32), relu=False, precision="bf16")
+    cnt = np.full((H, W), 9.0)
+    cnt[0, :] = cnt[-1, :] = 6.0
+    cnt[:, 0] = cnt[:, -1] = 6.0
+    cnt[0, 0] = cnt[0, -1] = cnt[-1, 0] = cnt[-1, -1] = 4.0
+    assert np.array_equal(y[0, :, :, 0], cnt * cin * 2.0 ** -6)
+    assert np.array_equal(y[0, :, :, cout - 1], cnt * cin * 2.0 ** -6)

@@ -279,7 +279,7 @@ def set_post(a: QmriMonoexpArgs, inv_abs_b=False, bounds=None, r2_threshold=None
 
 def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=None, b0v=None,
                      post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=0,
-                     ftol=None, maxfev=None, r2_eps=None, y_bounds=None):
+                     ftol=None, maxfev=None, r2_eps=None, y_bounds=None, out=None, want_popt=True):
     """Run the HIP fit on host (numpy) buffers.  ``y``: (E, N) C-contiguous, echo-major.
 
     Returns dict(popt (N,2), r2 (N,), [tc (N,)], [info (N,) int8, nfev (N,) int16]).
@@ -329,10 +329,27 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
         set_post(a, **post)
     od = np.dtype(out_dtype)
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
-    out = {"popt": np.empty((N, 2), dtype=od), "r2": np.empty(N, dtype=od)}
-    a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
+    if not want_popt and not want_tc:
+        raise ValueError("nothing to return: want_popt=False needs want_tc=True")
+    if out is None:
+        out = {"r2": np.empty(N, dtype=od)}
+        if want_popt:
+            out["popt"] = np.empty((N, 2), dtype=od)
+        if want_tc:
+            out["tc"] = np.empty(N, dtype=od)
+    else:  # reuse of a previous call's result arrays (no first-touch cost)
+        need = {"r2": (N,)}
+        if want_popt:
+            need["popt"] = (N, 2)
+        if want_tc:
+            need["tc"] = (N,)
+        for k, shp in need.items():
+            if k not in out or out[k].shape != shp or out[k].dtype != od or not out[k].flags.c_contiguous:
+                raise ValueError(f"`out[{k!r}]` does not match the request")
+    a.r2 = _ptr(out["r2"])
+    if want_popt:
+        a.popt = _ptr(out["popt"])
     if want_tc:
-        out["tc"] = np.empty(N, dtype=od)
         a.tc = _ptr(out["tc"])
     if want_info:
         out["info"] = np.empty(N, dtype=np.int8)

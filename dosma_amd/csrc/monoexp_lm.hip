@@ -307,13 +307,13 @@ __device__ __forceinline__ void finish_voxel(const FitKArgs &A, long long v, dou
         double2 o;
         o.x = pa;
         o.y = pb;
-        static_cast<double2 *>(A.popt)[v] = o;
+        if (A.popt) static_cast<double2 *>(A.popt)[v] = o;
         static_cast<double *>(A.r2)[v] = r2;
     } else {
         float2 o;
         o.x = static_cast<float>(pa);
         o.y = static_cast<float>(pb);
-        static_cast<float2 *>(A.popt)[v] = o;
+        if (A.popt) static_cast<float2 *>(A.popt)[v] = o;
         static_cast<float *>(A.r2)[v] = static_cast<float>(r2);
     }
     if (A.tc) {

@@ -11,7 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <vector>
+
+#include <sys/mman.h>
 
 #include "qmri_internal.h"
 
@@ -76,7 +81,8 @@ size_t dtype_size(int dt) {
 
 int validate(const qmri_monoexp_args *a) {
     if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
-    if (!a->y || !a->x || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, x, popt and r2 are required");
+    if (!a->y || !a->x || !a->r2 || (!a->popt && !a->tc))
+        return fail(QMRI_ERR_ARG, "y, x, r2 and popt (or tc) are required");
     if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
     if (a->out_dtype != QMRI_F32 && a->out_dtype != QMRI_F64)
         return fail(QMRI_ERR_ARG, "out_dtype must be QMRI_F32 or QMRI_F64");
@@ -129,7 +135,7 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     k.maxfev = a->maxfev;
     k.out_f64 = a->out_dtype == QMRI_F64;
     k.post = a->post;
-    if (!k.post.enable || k.post.decimals < -300) k.post.decimals = QMRI_NO_ROUND;
+    if (!k.post.enable || k.post.decimals < -300) k.post.decimals = QMRI_NO_ROUND;  // also: nothing below 1e-300
     k.p10 = k.post.decimals == QMRI_NO_ROUND ? 1.0 : std::pow(10.0, std::abs(k.post.decimals));
     k.popt = a->popt;
     k.r2 = a->r2;
@@ -229,7 +235,7 @@ void qmri_monoexp_defaults(qmri_monoexp_args *a) {
     a->a0 = 1.0;  // scipy: p0 = ones(n) when p0 is None
     a->b0 = 1.0;
     std::memset(&a->post, 0, sizeof(a->post));
-    a->post.decimals = -1;
+    a->post.decimals = QMRI_NO_ROUND;
     a->post.lb[0] = a->post.lb[1] = -INFINITY;
     a->post.ub[0] = a->post.ub[1] = INFINITY;
     a->out_dtype = QMRI_F64;
@@ -246,6 +252,66 @@ int qmri_monoexp_fit_device(const qmri_monoexp_args *a, int32_t *nonfinite_flag)
     return launch_fit(a, nonfinite_flag);
 }
 
+// ---- host entry: slab pipeline -------------------------------------------------------------------------
+// The caller's thread uploads slab i + 1 (pageable hipMemcpy: ~56 GB/s on this platform, measured, pinned or
+// not) while the kernel of slab i runs on its stream and a helper thread downloads slab i - 1: PCIe is used in
+// both directions at once.  Two things used to dominate the call (scripts/pin_probe.py, scripts/host_rate.py):
+// per-call hipMalloc / hipFree of the slab buffers (now cached per device), and the first touch of the freshly
+// allocated OUTPUT arrays -- the D2H copy faulted in and zeroed 1 GB of pages at 17 GB/s; now 8 threads touch the
+// output pages while the first slabs upload and compute.
+namespace {
+
+struct SlabBuf {
+    void *y = nullptr, *popt = nullptr, *r2 = nullptr, *tc = nullptr;
+    uint8_t *mask = nullptr;
+    double *a0v = nullptr, *b0v = nullptr;
+    int8_t *info = nullptr;
+    int16_t *nfev = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // kernel finished
+    size_t cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct HostPipe {
+    std::mutex mu;  // one host call at a time per device uses the cached buffers
+    SlabBuf buf[2];
+    int32_t *flag = nullptr;
+    hipStream_t d2h = nullptr;
+};
+HostPipe g_pipe[kMaxDevices];
+
+hipError_t ensure(void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(p, need);
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+
+// first touch of part `part` of `parts` of [base, base + bytes): MADV_POPULATE_WRITE (one call, no per-page trap)
+// on the page-aligned interior, a plain write per page otherwise
+void prefault(char *base, size_t bytes, int part, int parts) {
+    if (!base || !bytes) return;
+    const size_t share = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+    size_t lo = (size_t)part * share, hi = lo + share < bytes ? lo + share : bytes;
+    if (lo >= hi) return;
+    char *p = base + lo, *end = base + hi;
+    char *ap = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 4095) & ~(uintptr_t)4095);
+    char *ae = reinterpret_cast<char *>(reinterpret_cast<uintptr_t>(end) & ~(uintptr_t)4095);
+#ifdef MADV_POPULATE_WRITE
+    if (ae > ap && madvise(ap, (size_t)(ae - ap), MADV_POPULATE_WRITE) == 0) {
+        *reinterpret_cast<volatile char *>(p) = 0;
+        *reinterpret_cast<volatile char *>(end - 1) = 0;
+        return;
+    }
+#endif
+    for (char *q = p; q < end; q += 4096) *reinterpret_cast<volatile char *>(q) = 0;
+    *reinterpret_cast<volatile char *>(end - 1) = 0;
+}
+
+}  // namespace
+
 int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
     const int rc = validate(a);
     if (rc != QMRI_OK) return rc;
@@ -254,110 +320,171 @@ int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
 
     const size_t es = dtype_size(a->y_dtype);
     const size_t os = a->out_dtype == QMRI_F64 ? 8 : 4;
-    // slab size: keep the device footprint modest and give the copy engines something to overlap
-    const long long kSlab = 1LL << 22;  // 4 Mi voxels
+    const long long kSlab = 1LL << 22;  // 4 Mi voxels per slab
     const long long S = a->N < kSlab ? ((a->N + 255) / 256) * 256 : kSlab;
     const int nbuf = a->N > S ? 2 : 1;
-
-    struct Buf {
-        void *y = nullptr, *popt = nullptr, *r2 = nullptr, *tc = nullptr;
-        uint8_t *mask = nullptr;
-        double *a0v = nullptr, *b0v = nullptr;
-        int8_t *info = nullptr;
-        int16_t *nfev = nullptr;
-        hipStream_t stream = nullptr;
-    } buf[2];
-    int32_t *flag = nullptr;
-    int status = QMRI_OK;
-    auto cleanup = [&] {
-        for (int b = 0; b < 2; ++b) {
-            (void)hipFree(buf[b].y);
-            (void)hipFree(buf[b].popt);
-            (void)hipFree(buf[b].r2);
-            (void)hipFree(buf[b].tc);
-            (void)hipFree(buf[b].mask);
-            (void)hipFree(buf[b].a0v);
-            (void)hipFree(buf[b].b0v);
-            (void)hipFree(buf[b].info);
-            (void)hipFree(buf[b].nfev);
-            if (buf[b].stream) (void)hipStreamDestroy(buf[b].stream);
-        }
-        (void)hipFree(flag);
-    };
-#define HIP_TRY_C(expr)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            status = fail(QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                          __FILE__, __LINE__);                                                   \
-            cleanup();                                                                           \
-            return status;                                                                       \
-        }                                                                                        \
-    } while (0)
-
-    HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&flag), 4));
-    HIP_TRY_C(hipMemset(flag, 0, 4));
     const bool per_voxel = a->init == QMRI_INIT_PER_VOXEL;
+
+    HostPipe &P = g_pipe[a->device];
+    std::lock_guard<std::mutex> lock(P.mu);
+#define HIP_TRY_C(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+    if (!P.flag) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&P.flag), 4));
+    if (!P.d2h) HIP_TRY_C(hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+    HIP_TRY_C(hipMemset(P.flag, 0, 4));
     for (int b = 0; b < nbuf; ++b) {
-        HIP_TRY_C(hipStreamCreateWithFlags(&buf[b].stream, hipStreamNonBlocking));
-        HIP_TRY_C(hipMalloc(&buf[b].y, (size_t)a->E * S * es));
-        HIP_TRY_C(hipMalloc(&buf[b].popt, (size_t)S * 2 * os));
-        HIP_TRY_C(hipMalloc(&buf[b].r2, (size_t)S * os));
-        if (a->tc) HIP_TRY_C(hipMalloc(&buf[b].tc, (size_t)S * os));
-        if (a->mask) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].mask), (size_t)S));
-        if (per_voxel && a->a0v) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].a0v), (size_t)S * 8));
-        if (per_voxel && a->b0v) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].b0v), (size_t)S * 8));
-        if (a->info) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].info), (size_t)S));
-        if (a->nfev) HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&buf[b].nfev), (size_t)S * 2));
+        SlabBuf &B = P.buf[b];
+        if (!B.stream) HIP_TRY_C(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        if (!B.done) HIP_TRY_C(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
+        HIP_TRY_C(ensure(&B.y, &B.cap[0], (size_t)a->E * S * es));
+        if (a->popt) HIP_TRY_C(ensure(&B.popt, &B.cap[1], (size_t)S * 2 * os));
+        HIP_TRY_C(ensure(&B.r2, &B.cap[2], (size_t)S * os));
+        if (a->tc) HIP_TRY_C(ensure(&B.tc, &B.cap[3], (size_t)S * os));
+        if (a->mask) HIP_TRY_C(ensure(reinterpret_cast<void **>(&B.mask), &B.cap[4], (size_t)S));
+        if (per_voxel && a->a0v) HIP_TRY_C(ensure(reinterpret_cast<void **>(&B.a0v), &B.cap[5], (size_t)S * 8));
+        if (per_voxel && a->b0v) HIP_TRY_C(ensure(reinterpret_cast<void **>(&B.b0v), &B.cap[6], (size_t)S * 8));
+        if (a->info) HIP_TRY_C(ensure(reinterpret_cast<void **>(&B.info), &B.cap[7], (size_t)S));
+        if (a->nfev) HIP_TRY_C(ensure(reinterpret_cast<void **>(&B.nfev), &B.cap[8], (size_t)S * 2));
     }
 
-    int ib = 0;
-    for (long long s0 = 0; s0 < a->N; s0 += S, ib ^= 1) {
-        Buf &B = buf[nbuf == 1 ? 0 : ib];
+    // first touch of the output arrays, slab by slab in parallel, while the first slabs upload and compute
+    const long long nslabs = (a->N + S - 1) / S;
+    constexpr int kMaxTouchers = 16;
+    static const int kTouchers = [] {
+        const char *e = std::getenv("QMRI_HOST_TOUCHERS");
+        const int n = e ? std::atoi(e) : 4;  // 4, 8, 16 measured equal: the OS zero-fill does not scale further
+        return n < 0 ? 0 : (n > kMaxTouchers ? kMaxTouchers : n);
+    }();
+    std::thread touchers[kMaxTouchers];
+    const bool big = kTouchers > 0 && (size_t)a->N * 2 * os >= (64u << 20);
+    std::vector<std::atomic<int>> touched(big ? (size_t)nslabs : 0);
+    for (auto &t : touched) t.store(0);
+    if (big) {
+        for (int t = 0; t < kTouchers; ++t)
+            touchers[t] = std::thread([&, t] {
+                for (long long j = 0; j < nslabs; ++j) {
+                    const size_t s0 = (size_t)(j * S);
+                    const size_t cnt = (size_t)((a->N - j * S) < S ? (a->N - j * S) : S);
+                    if (a->popt) prefault(static_cast<char *>(a->popt) + s0 * 2 * os, cnt * 2 * os, t, kTouchers);
+                    prefault(static_cast<char *>(a->r2) + s0 * os, cnt * os, t, kTouchers);
+                    if (a->tc) prefault(static_cast<char *>(a->tc) + s0 * os, cnt * os, t, kTouchers);
+                    if (a->info) prefault(reinterpret_cast<char *>(a->info) + s0, cnt, t, kTouchers);
+                    if (a->nfev) prefault(reinterpret_cast<char *>(a->nfev) + s0 * 2, cnt * 2, t, kTouchers);
+                    touched[(size_t)j].fetch_add(1, std::memory_order_release);
+                }
+            });
+    }
+
+    // downloader: slab jobs in order; job i may start when its kernel is done and its output pages are touched;
+    // a device buffer is free again when its download has finished
+    std::mutex qmu;
+    std::condition_variable qcv;
+    long long submitted = 0, downloaded = 0;
+    hipError_t dl_err = hipSuccess;
+    bool abort_dl = false;
+    std::thread downloader([&] {
+        (void)hipSetDevice(a->device);
+        for (long long i = 0; i < nslabs; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [&] { return submitted > i || abort_dl; });
+                if (abort_dl) return;
+            }
+            SlabBuf &B = P.buf[nbuf == 1 ? 0 : (i & 1)];
+            const long long s0 = i * S;
+            const long long cnt = (a->N - s0) < S ? (a->N - s0) : S;
+            hipError_t e = hipEventSynchronize(B.done);
+            if (big)
+                while (touched[(size_t)i].load(std::memory_order_acquire) < kTouchers) std::this_thread::yield();
+            if (e == hipSuccess && a->popt)
+                e = hipMemcpyAsync(static_cast<char *>(a->popt) + (size_t)s0 * 2 * os, B.popt, (size_t)cnt * 2 * os,
+                                   hipMemcpyDeviceToHost, P.d2h);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(static_cast<char *>(a->r2) + (size_t)s0 * os, B.r2, (size_t)cnt * os,
+                                   hipMemcpyDeviceToHost, P.d2h);
+            if (e == hipSuccess && a->tc)
+                e = hipMemcpyAsync(static_cast<char *>(a->tc) + (size_t)s0 * os, B.tc, (size_t)cnt * os,
+                                   hipMemcpyDeviceToHost, P.d2h);
+            if (e == hipSuccess && a->info) e = hipMemcpyAsync(a->info + s0, B.info, (size_t)cnt, hipMemcpyDeviceToHost, P.d2h);
+            if (e == hipSuccess && a->nfev) e = hipMemcpyAsync(a->nfev + s0, B.nfev, (size_t)cnt * 2, hipMemcpyDeviceToHost, P.d2h);
+            if (e == hipSuccess) e = hipStreamSynchronize(P.d2h);
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                if (e != hipSuccess && dl_err == hipSuccess) dl_err = e;
+                downloaded = i + 1;
+            }
+            qcv.notify_all();
+        }
+    });
+
+    int status = QMRI_OK;
+    hipError_t up_err = hipSuccess;
+    for (long long i = 0; i < nslabs && status == QMRI_OK && up_err == hipSuccess; ++i) {
+        SlabBuf &B = P.buf[nbuf == 1 ? 0 : (i & 1)];
+        const long long s0 = i * S;
         const long long cnt = (a->N - s0) < S ? (a->N - s0) : S;
+        {  // this buffer's previous slab (i - nbuf) must have been downloaded
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return downloaded >= i - nbuf + 1; });
+            if (dl_err != hipSuccess) break;
+        }
         hipStream_t st = B.stream;
-        // the previous use of this buffer pair must have drained (its D2H copies are on `st`)
-        HIP_TRY_C(hipStreamSynchronize(st));
-        HIP_TRY_C(hipMemcpy2DAsync(B.y, (size_t)S * es,
-                                   static_cast<const char *>(a->y) + (size_t)s0 * es,
-                                   (size_t)a->ld * es, (size_t)cnt * es, (size_t)a->E,
-                                   hipMemcpyHostToDevice, st));
-        if (a->mask) HIP_TRY_C(hipMemcpyAsync(B.mask, a->mask + s0, (size_t)cnt, hipMemcpyHostToDevice, st));
-        if (B.a0v) HIP_TRY_C(hipMemcpyAsync(B.a0v, a->a0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
-        if (B.b0v) HIP_TRY_C(hipMemcpyAsync(B.b0v, a->b0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+        for (int e = 0; e < a->E && up_err == hipSuccess; ++e)
+            up_err = hipMemcpyAsync(static_cast<char *>(B.y) + (size_t)e * S * es,
+                                    static_cast<const char *>(a->y) + ((size_t)e * a->ld + s0) * es, (size_t)cnt * es,
+                                    hipMemcpyHostToDevice, st);
+        if (up_err == hipSuccess && a->mask) up_err = hipMemcpyAsync(B.mask, a->mask + s0, (size_t)cnt, hipMemcpyHostToDevice, st);
+        if (up_err == hipSuccess && B.a0v && per_voxel && a->a0v)
+            up_err = hipMemcpyAsync(B.a0v, a->a0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st);
+        if (up_err == hipSuccess && B.b0v && per_voxel && a->b0v)
+            up_err = hipMemcpyAsync(B.b0v, a->b0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st);
+        if (up_err != hipSuccess) break;
 
         qmri_monoexp_args d = *a;
         d.y = B.y;
         d.ld = S;
         d.N = cnt;
-        d.mask = B.mask;
-        d.a0v = B.a0v;
-        d.b0v = B.b0v;
-        d.popt = B.popt;
+        d.mask = a->mask ? B.mask : nullptr;
+        d.a0v = (per_voxel && a->a0v) ? B.a0v : nullptr;
+        d.b0v = (per_voxel && a->b0v) ? B.b0v : nullptr;
+        d.popt = a->popt ? B.popt : nullptr;
         d.r2 = B.r2;
-        d.tc = B.tc;
-        d.info = B.info;
-        d.nfev = B.nfev;
+        d.tc = a->tc ? B.tc : nullptr;
+        d.info = a->info ? B.info : nullptr;
+        d.nfev = a->nfev ? B.nfev : nullptr;
         d.stream = st;
-        const int lrc = launch_fit(&d, flag);
-        if (lrc != QMRI_OK) {
-            cleanup();
-            return lrc;
+        status = launch_fit(&d, P.flag);
+        if (status != QMRI_OK) break;
+        up_err = hipEventRecord(B.done, st);
+        if (up_err != hipSuccess) break;
+        {
+            std::lock_guard<std::mutex> lk(qmu);
+            submitted = i + 1;
         }
-        HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->popt) + (size_t)s0 * 2 * os, B.popt,
-                                 (size_t)cnt * 2 * os, hipMemcpyDeviceToHost, st));
-        HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->r2) + (size_t)s0 * os, B.r2, (size_t)cnt * os,
-                                 hipMemcpyDeviceToHost, st));
-        if (a->tc)
-            HIP_TRY_C(hipMemcpyAsync(static_cast<char *>(a->tc) + (size_t)s0 * os, B.tc,
-                                     (size_t)cnt * os, hipMemcpyDeviceToHost, st));
-        if (a->info) HIP_TRY_C(hipMemcpyAsync(a->info + s0, B.info, (size_t)cnt, hipMemcpyDeviceToHost, st));
-        if (a->nfev) HIP_TRY_C(hipMemcpyAsync(a->nfev + s0, B.nfev, (size_t)cnt * 2, hipMemcpyDeviceToHost, st));
+        qcv.notify_all();
     }
-    for (int b = 0; b < nbuf; ++b) HIP_TRY_C(hipStreamSynchronize(buf[b].stream));
+    {
+        std::lock_guard<std::mutex> lk(qmu);
+        if (status != QMRI_OK || up_err != hipSuccess || dl_err != hipSuccess) abort_dl = true;
+    }
+    qcv.notify_all();
+    downloader.join();
+    if (big)
+        for (int t = 0; t < kTouchers; ++t) touchers[t].join();
+    if (status != QMRI_OK) {
+        (void)hipDeviceSynchronize();
+        return status;
+    }
+    if (up_err != hipSuccess || dl_err != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        return fail(QMRI_ERR_HIP, "fit_host: %s", hipGetErrorString(up_err != hipSuccess ? up_err : dl_err));
+    }
     int32_t hflag = 0;
-    HIP_TRY_C(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
-    cleanup();
+    HIP_TRY_C(hipMemcpy(&hflag, P.flag, 4, hipMemcpyDeviceToHost));
     if (hflag) return fail(QMRI_ERR_NONFINITE, "array must not contain infs or NaNs");
     return QMRI_OK;
 #undef HIP_TRY_C

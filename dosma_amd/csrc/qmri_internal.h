@@ -6,7 +6,6 @@
 
 #include "qmri.h"
 
-#define QMRI_NO_ROUND (-1000000)
 
 namespace qmri {
 

@@ -450,7 +450,7 @@ class CurveFitter(_Fitter):
                     nan_to_num=self.nan_to_num)
 
     def fit(self, x, y: Sequence[MedicalVolume], mask=None, p0=np._NoValue, copy_headers: bool = True,
-            _decimals=None):
+            _decimals=None, _tc_only=False):
         """Fit every voxel; returns ``(popt, r2)`` MedicalVolumes (``popt`` has a trailing parameter
         axis).  Voxels outside ``mask`` hold NaN (or ``nan_to_num``) like the reference (:205-215)."""
         model = _model_of(self._func)
@@ -480,14 +480,20 @@ class CurveFitter(_Fitter):
         post = self._fusable_post()
         if post is not None and _decimals is not None:
             post["decimals"] = _decimals
+        tc_only = _tc_only and post is not None  # MonoExponentialFit: only (tc, r2) leave the GPU
         out = _lib.monoexp_fit_host(
             x.astype(np.float64).reshape(-1), _as_kernel_samples(svs), mask=mask_flat, init=init,
             p0=tuple(1.0 if isinstance(v, np.ndarray) else v for v in p0),
             a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
             b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,
-            post=post, want_tc=_decimals is not None and post is not None,
-            y_bounds=self.y_bounds,
+            post=post, want_tc=tc_only or (_decimals is not None and post is not None),
+            y_bounds=self.y_bounds, want_popt=not tc_only,
         )
+        if tc_only:
+            shape = y[0].shape
+            headers = deepcopy(y[0].headers()) if (copy_headers and y[0].headers() is not None) else None
+            return (y[0]._partial_clone(volume=out["tc"].reshape(shape), headers=headers),
+                    y[0]._partial_clone(volume=out["r2"].reshape(shape), headers=True if headers is not None else None))
         popt, r2 = out["popt"], out["r2"]
         if post is None:
             # arbitrary Python ufuncs: the reference's own post-processing, on the fitted rows only
@@ -645,14 +651,9 @@ class MonoExponentialFit:
         else:
             p0 = {"a": 1.0, "b": -1 / self.tc0}
         decimals = self.decimal_precision
-        popt, r_squared = fitter.fit(x, y, mask=mask, p0=p0,
-                                     _decimals=decimals if decimals is not None else None)
-        if decimals is not None:
-            tc = fitter._last_tc.reshape(y[0].shape)
-            tc_map = popt[..., 1]
-            tc_map._volume = tc
-        else:
-            tc_map = popt[..., 1]
+        # the kernel's fused epilogue (1/|b| -> bounds -> r2 threshold -> nan_to_num -> around) leaves exactly the two
+        # maps the reference returns (:721-739); the (a, tc) pairs never cross PCIe
+        tc_map, r_squared = fitter.fit(x, y, mask=mask, p0=p0, _decimals=decimals, _tc_only=True)
         return tc_map, r_squared
 
     def _check_y(self, x, y):

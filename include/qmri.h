@@ -65,13 +65,15 @@ typedef enum qmri_init {
  * ->  r2 < threshold -> whole row NaN  ->  nan_to_num (NaN -> value, +-inf -> +-DBL_MAX), then the
  * scatter fill for voxels outside the mask (fitting.py:205-215) and np.around of the tc map (:736-737).
  */
+#define QMRI_NO_ROUND (-1000000)
 typedef struct qmri_post {
     int32_t enable;         /* 0: popt/r2 are curve_fit()'s raw outputs                              */
     int32_t inv_abs_b;      /* 1: param 1 <- 1/|b|                                                   */
     int32_t use_bounds;     /* 1: apply lb/ub below                                                  */
     int32_t use_r2_thr;     /* 1: rows with r2 < r2_threshold -> NaN                                 */
     int32_t use_nan_to_num; /* 1: np.nan_to_num(x, nan=nan_value); also the fill outside the mask    */
-    int32_t decimals;       /* >= 0: tc = around(param 1, decimals) written to args->tc; < 0: none   */
+    int32_t decimals;       /* tc = np.around(param 1, decimals) written to args->tc (numpy semantics:
+                               negative = tens, hundreds ...); QMRI_NO_ROUND: tc is not rounded      */
     double lb[2], ub[2];    /* per-parameter bounds (use -inf/+inf for "none")                       */
     double r2_threshold;
     double nan_value;
@@ -103,9 +105,10 @@ typedef struct qmri_monoexp_args {
     int32_t reserved1;
     qmri_post post;
     /* ---- outputs ---- */
-    void *popt;          /* [N][2] (a, b)  -- or (a, tc) after post.inv_abs_b                         */
+    void *popt;          /* [N][2] (a, b)  -- or (a, tc) after post.inv_abs_b; nullable when tc is given
+                            (MonoExponentialFit needs only tc and r2: a third less output traffic)    */
     void *r2;            /* [N]                                                                       */
-    void *tc;            /* nullable [N]: rounded time-constant map (post.decimals >= 0)              */
+    void *tc;            /* nullable [N]: time-constant map = processed param 1, rounded per post.decimals */
     int32_t out_dtype;   /* QMRI_F32 or QMRI_F64 (the reference returns float64)                      */
     int32_t reserved2;
     int8_t *info;        /* nullable [N]: MINPACK info (1..4 success, 5..8 failure), 0 = skipped

@@ -40,6 +40,9 @@ out = {
     "traffic_over_algorithmic": (rd + wr) / alg,
     "sq": sq,
     "lanes_active_per_valu_instr": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+    # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU execution summed over SIMDs; SQ_BUSY_CYCLES is summed over the
+    # 32 shader engines (8 XCD x 4) -> kernel duration in clocks = SQ_BUSY_CYCLES / 32; 1024 SIMDs
+    "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * sq["SQ_BUSY_CYCLES"] / 32.0),
 }
 json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_counters.json"},

@@ -90,3 +90,60 @@ def test_scan_recipes_vs_reference_golden(golden):
     cq2 = CubeQuant([mvs(g["y"])[i] for i in order], g["tsl"][order])
     assert np.array_equal(cq2.generate_t1_rho_map().volumetric_map.volume,
                           cq.generate_t1_rho_map().volumetric_map.volume)
+
+
+def test_baseline_config0_size_vs_scipy():
+    """BASELINE.json configs[0]: MonoExponentialFit on a synthetic 64 x 64 x 16 volume, 4 echoes -- the whole
+    volume against the reference's own call (one scipy.optimize.curve_fit per voxel + its post-processing, restated in
+    oracle/fit_oracle.py and pinned to the real reference by tests/test_oracle.py)."""
+    import dosma_amd as dm
+    from oracle import fit_oracle as fo
+
+    rng = np.random.default_rng(64)
+    shape, x = (64, 64, 16), np.array([10.0, 25.0, 45.0, 70.0])
+    t2 = rng.uniform(15, 90, shape)
+    s0 = rng.uniform(300, 1500, shape)
+    vols = [(s0 * np.exp(-t / t2) + rng.normal(0, 4.0, shape)).astype(np.float32) for t in x]
+    for v in vols:
+        v[:8] = 0  # background slab: skip rule
+    ys = [dm.MedicalVolume(v, np.eye(4)) for v in vols]
+    tc, r2 = dm.MonoExponentialFit(bounds=(0, 100), tc0=30.0, decimal_precision=3).fit(x, ys)
+    y2 = np.stack([v.reshape(-1) for v in vols])
+    ref_tc, ref_r2, _ = fo.monoexp_fit_arrays(x, y2, tc0=30.0, bounds=(0, 100), decimal_precision=3, threads=8)
+    ref_tc, ref_r2 = ref_tc.reshape(shape), ref_r2.reshape(shape)
+    assert tc.shape == shape and tc.dtype == np.float64
+    assert (tc.A[:8] == 0).all() and (r2.A[:8] == 0).all()
+    differ = np.abs(tc.A - ref_tc) > 1e-4 * np.maximum(np.abs(ref_tc), 1.0)
+    assert differ.mean() < 2e-3, differ.mean()  # voxels on a rounding / threshold boundary
+    assert np.abs(r2.A - ref_r2)[~differ].max() < 1e-4
+
+
+def test_baseline_config2_size_cubequant_roi():
+    """BASELINE.json configs[2]: T1rho (CubeQuant), 4 spin-lock times, 384 x 384 x 120 int16 volumes, cartilage-mask
+    ROI only (~2 % of the voxels).  Outside the ROI: the scatter fill; inside: the C restatement of the reference's
+    scipy loop on every ROI voxel, and exact recovery of the noise-free truth."""
+    import dosma_amd as dm
+    from dosma_amd.scan_sequences import CubeQuant
+    from oracle import fit_oracle as fo
+
+    rng = np.random.default_rng(384)
+    shape = (384, 384, 120)
+    tsl = np.array([1.0, 10.0, 30.0, 60.0])
+    t1r = rng.uniform(25, 70, shape)
+    s0 = rng.uniform(800, 3000, shape)
+    vols = [np.rint(s0 * np.exp(-t / t1r)).astype(np.int16) for t in tsl]
+    mask = np.zeros(shape, np.uint8)
+    mask[150:230, 120:260, 40:70] = (rng.uniform(size=(80, 140, 30)) < 0.85)  # a cartilage-plate-like slab
+    assert 0.01 < mask.mean() < 0.03
+    scan = CubeQuant([dm.MedicalVolume(v, np.eye(4)) for v in vols], tsl)
+    qv = scan.generate_t1_rho_map(mask=dm.MedicalVolume(mask, np.eye(4)))
+    t1map, r2 = qv.volumetric_map.A, qv.additional_volumes["r2"].A
+    assert t1map.shape == shape and (t1map[mask == 0] == 0).all() and (r2[mask == 0] == 0).all()
+    sel = mask.reshape(-1) > 0
+    y2 = np.stack([v.reshape(-1)[sel] for v in vols]).astype(np.float64)
+    ref_tc, ref_r2, _ = fo.monoexp_fit_arrays(tsl, y2, tc0="polyfit", bounds=(0, 500), decimal_precision=3, threads=8)
+    got = t1map.reshape(-1)[sel]
+    differ = np.abs(got - ref_tc) > 1e-4 * np.maximum(np.abs(ref_tc), 1.0)
+    assert differ.mean() < 2e-3, differ.mean()
+    ok = got > 0
+    assert ok.mean() > 0.99 and np.abs(got[ok] - t1r.reshape(-1)[sel][ok]).max() < 0.5  # int16-rounded samples

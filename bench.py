@@ -72,6 +72,54 @@ def make_args(L, y, popt, r2, stream, recipe):
     return a
 
 
+def bench_t1rho_roi(L, lib, torch, device, local_rank, args):
+    """BASELINE.json configs[2] (a parity-test configuration, reported for information): CubeQuant T1rho, 4 spin-lock
+    times, 384 x 384 x 120 int16 volumes, cartilage-mask ROI (~2 % of the voxels), tc0="polyfit", bounds (0, 500),
+    3 decimals.  Device-resident, kernel time from HIP events."""
+    shape = (384, 384, 120)
+    n = shape[0] * shape[1] * shape[2]
+    tsl = np.array([1.0, 10.0, 30.0, 60.0])
+    gen = torch.Generator(device=device).manual_seed(384)
+    s0 = torch.rand(n, device=device, generator=gen) * 2200 + 800
+    t1r = torch.rand(n, device=device, generator=gen) * 45 + 25
+    t = torch.tensor(tsl, device=device, dtype=torch.float32)
+    y = s0[None, :] * torch.exp(-t[:, None] / t1r[None, :]) + 20.0 * torch.randn((4, n), device=device, generator=gen)
+    y = y.round().clamp(-32768, 32767).to(torch.int16).contiguous()
+    mask = torch.zeros(shape, dtype=torch.uint8, device=device)
+    mask[150:230, 120:260, 40:70] = (torch.rand((80, 140, 30), device=device, generator=gen) < 0.85).to(torch.uint8)
+    mask = mask.reshape(-1).contiguous()
+    roi = int(mask.sum().item())
+    popt = torch.empty((n, 2), dtype=torch.float32, device=device)
+    r2 = torch.empty(n, dtype=torch.float32, device=device)
+    tc = torch.empty(n, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device)
+    a = L.default_args()
+    a.y, a.y_dtype, a.E, a.N, a.ld = y.data_ptr(), L.QMRI_I16, 4, n, n
+    a.x = tsl.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    a.mask = mask.data_ptr()
+    a.popt, a.r2, a.tc, a.out_dtype = popt.data_ptr(), r2.data_ptr(), tc.data_ptr(), L.QMRI_F32
+    a.stream = stream.cuda_stream
+    a.device = local_rank
+    a.init = L.INIT_LOGLIN
+    L.set_post(a, inv_abs_b=True, bounds=((-np.inf, np.inf), (0.0, 500.0)), r2_threshold=0.9, nan_to_num=0.0, decimals=3)
+    for _ in range(max(args.warmup, 1)):
+        L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    ev0.record(stream)
+    for _ in range(args.steps):
+        L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    ms = ev0.elapsed_time(ev1) / args.steps
+    return {"config": "T1rho (CubeQuant recipe), 4 spin-lock times, 384x384x120 int16, ROI mask only (BASELINE configs[2])",
+            "volume_voxels": n, "roi_voxels": roi, "kernel_ms": ms,
+            "roi_voxel_fits_per_s": roi / (ms * 1e-3), "volume_voxels_per_s": n / (ms * 1e-3),
+            "hbm_gb_per_s": (n * (1 + 3 * 4) + roi * 4 * 2) / (ms * 1e-3) / 1e9,
+            "kernel": lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode()}
+
+
 def cpu_baseline(y_dev, cores_cap=None):
     """The reference's per-voxel scipy loop under multiprocessing.Pool(all cores) (fitting.py:855-868)
     on a bounded sample of the bench volume: ~6000 voxels per core (a few seconds per core)."""
@@ -276,6 +324,7 @@ def main():
         results[recipe] = dict(elapsed=elapsed, kernel_ms=kernel_ms,
                                kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
 
+    roi_run = bench_t1rho_roi(L, lib, torch, device, local_rank, args) if rank == 0 else None
     dess = bench_dess(L, lib, torch, device, local_rank, world, args, barrier) if rank == 0 or world > 1 else None
     unet = None
     if not args.no_unet:
@@ -339,6 +388,8 @@ def main():
             out["unet2d"] = unet
         if dess is not None:
             out["dess_t2"] = dess
+        if roi_run is not None:
+            out["runs"]["cfg2_t1rho_roi"] = roi_run
         if "B" in results:
             out["runs"]["B_polyfit_init"] = {
                 "voxel_fits_per_s": n * world * args.steps / results["B"]["elapsed"],

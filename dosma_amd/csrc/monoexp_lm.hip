@@ -401,6 +401,14 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     long long tile_base = 0;
     int qpos = 0, qend = 0;
     bool more = true;
+    const long long ntiles = A.tile_list ? (long long)*A.tile_list_count : (A.N + kSub - 1) / kSub;
+    const int nwaves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    unsigned int tnext = 0, tend = 0;  // tiles this wave has claimed
+    unsigned int chunk;
+    {
+        const long long want = ntiles / ((long long)nwaves * 4);
+        chunk = want > 16 ? 16u : (want < 1 ? 1u : (unsigned int)want);
+    }
 
 #ifdef QMRI_STATS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -414,19 +422,41 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
             if (nidle >= A.refill_idle || nidle == 64) {
                 // ---- queue empty: claim tiles until one has fit-able voxels (or the volume is done) ----
                 while (qpos >= qend && more) {
-                    unsigned int t = 0;
-                    if (lane == 0) t = atomicAdd(A.tile_counter, 1u);
-                    t = __builtin_amdgcn_readfirstlane(t);
-                    const long long start = (long long)t * kSub;
-                    if (start >= A.N) {
+                    // guided self-scheduling: one atomic claims `chunk` consecutive tiles (16 early, 1 at the end).
+                    // One atomic per tile made the single counter the bottleneck of sparse volumes: a 2 % ROI mask
+                    // over 17.7 M voxels is 69 k claims for 0.05 ms of fitting -> 0.83 ms (BASELINE configs[2]).
+                    if (tnext >= tend) {
+                        unsigned int t0 = 0;
+                        if (lane == 0) t0 = atomicAdd(A.tile_counter, chunk);
+                        t0 = __builtin_amdgcn_readfirstlane(t0);
+                        tnext = t0;
+                        tend = t0 + chunk;
+                        const long long left = ntiles - (long long)tend;
+                        const long long want = left / ((long long)nwaves * 4);
+                        chunk = want > 16 ? 16u : (want < 1 ? 1u : (unsigned int)want);
+                    }
+                    const unsigned int ti = tnext++;
+                    if ((long long)ti >= ntiles) {
                         more = false;
                         break;
                     }
+                    const unsigned int t = A.tile_list ? A.tile_list[ti] : ti;
+                    const long long start = (long long)t * kSub;
                     tile_base = start;
                     const long long rem = A.N - start;
                     const int count = rem < kSub ? (int)rem : kSub;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    bool any_selected = true;  // a tile without a single voxel in the mask needs no samples at all
+                    if (A.mask) {
+                        bool s = false;
+                        for (int k = 0; k < kSub / 64; ++k) {
+                            const int j = k * 64 + lane;
+                            if (j < count) s = s || A.mask[start + j] != 0;
+                        }
+                        any_selected = __ballot(s) != 0;
+                    }
+                    if (any_selected)
                     switch (A.y_dtype) {
                         case QMRI_F32:
                             stage_rows(static_cast<const float *>(A.y) + start, A.ld, E, count, tile,
@@ -867,6 +897,47 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_fit_stats[i], st_acc[i]);
 #endif
+}
+
+// ---- masked volumes: tile classification pre-pass ---------------------------------------------------
+// One wave per 256-voxel tile: no voxel selected -> the scatter fill of fitting.py:205-215 for the whole tile
+// (streaming writes); otherwise the tile index goes to a compact list that the fit kernel walks.  A cartilage ROI is
+// ~2 % of the voxels in one or two slabs: without the list the fit waves spend their time claiming empty tiles, and
+// the few waves whose claims fall inside the slab do all the fitting.
+__global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArgs A, unsigned int *list,
+                                                                   unsigned int *count) {
+    const int lane = threadIdx.x & 63;
+    const long long ntiles = (A.N + kSub - 1) / kSub;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long t = wave0; t < ntiles; t += nwaves) {
+        const long long start = t * kSub;
+        const long long rem = A.N - start;
+        const int cnt = rem < kSub ? (int)rem : kSub;
+        bool s = false;
+        for (int k = 0; k < kSub / 64; ++k) {
+            const int j = k * 64 + lane;
+            if (j < cnt) s = s || A.mask[start + j] != 0;
+        }
+        if (__ballot(s)) {
+            if (lane == 0) list[atomicAdd(count, 1u)] = (unsigned int)t;
+        } else {
+            for (int k = 0; k < kSub / 64; ++k) {
+                const int j = k * 64 + lane;
+                if (j < cnt) finish_voxel(A, start + j, 0, 0, 0, -1, 0, true);
+            }
+        }
+    }
+}
+
+hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu,
+                                hipStream_t stream) {
+    const long long ntiles = (k.N + kSub - 1) / kSub;
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > (long long)num_cu * 8) blocks = (long long)num_cu * 8;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(monoexp_mask_prepass_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, k, list, count);
+    return hipGetLastError();
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------------

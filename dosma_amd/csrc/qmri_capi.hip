@@ -171,6 +171,15 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
     HIP_TRY(hipMemsetAsync(cnt, 0, 8, stream));
 
     const long long tiles = (a->N + qmri::monoexp_tile_voxels() - 1) / qmri::monoexp_tile_voxels();
+    // masked volume: fill the tiles without a selected voxel and compact the others first (stream-ordered scratch)
+    unsigned int *tile_list = nullptr;
+    if (a->mask && tiles >= 4096) {
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&tile_list), (size_t)(tiles + 1) * 4, stream));
+        HIP_TRY(hipMemsetAsync(tile_list + tiles, 0, 4, stream));
+        HIP_TRY(qmri::monoexp_mask_prepass(k, tile_list, tile_list + tiles, ctx->num_cu, stream));
+        k.tile_list = tile_list;
+        k.tile_list_count = tile_list + tiles;
+    }
     const int per_cu = qmri::monoexp_blocks_per_cu(k);
     long long grid = (long long)ctx->num_cu * per_cu;
     const int wpb = qmri::monoexp_waves_per_block(k);
@@ -185,6 +194,7 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     HIP_TRY(qmri::monoexp_launch(k, static_cast<int>(grid), stream));
+    if (tile_list) HIP_TRY(hipFreeAsync(tile_list, stream));
     if (g_timing) {
         HIP_TRY(hipEventRecord(ev1, stream));
         HIP_TRY(hipEventSynchronize(ev1));

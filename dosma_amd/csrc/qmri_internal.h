@@ -36,6 +36,10 @@ struct FitKArgs {
     signed char *info;
     short *nfev;
     unsigned int *tile_counter;  // zeroed before every launch
+    // masked launches: tiles with at least one selected voxel, compacted by monoexp_mask_prepass (the other tiles
+    // are filled there); tile_list == nullptr -> every tile of the volume
+    const unsigned int *tile_list;
+    const unsigned int *tile_list_count;
     int *nonfinite;
     double xmean, sxx;           // of x: closed-form degree-1 least squares (log-linear init)
     double x[QMRI_MAX_ECHOES];
@@ -81,6 +85,8 @@ struct LmKArgs {
 };
 int lm_generic_nparams(int model);
 hipError_t lm_generic_launch(const LmKArgs &k, int model, int num_cu, hipStream_t stream);
+// masked launches: classify tiles, fill the empty ones, list the others (list: [tiles] u32, count: 1 u32, zeroed)
+hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu, hipStream_t stream);
 hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
 
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).

@@ -118,6 +118,7 @@ EXPORTS = (
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
     "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
     "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
+    "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host",
 )
@@ -199,6 +200,9 @@ def load():
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
             ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         lib.qmri_unet2d_forward.restype = ctypes.c_int
+        lib.qmri_unet2d_segment_volume.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        lib.qmri_unet2d_segment_volume.restype = ctypes.c_int
         lib.qmri_unet2d_destroy.argtypes = [ctypes.c_void_p]
         lib.qmri_unet2d_destroy.restype = ctypes.c_int
         lib.qmri_conv2d_nhwc_host.argtypes = [
@@ -498,6 +502,19 @@ class Unet2dEngine:
         check(self._lib.qmri_unet2d_forward(self._handle, _ptr(x), S, 0, 1 if whiten else 0, float(eps),
                                             _ptr(logits), _ptr(mask), 0, None))
         return logits, mask
+
+    def segment_volume(self, vol_hws, *, whiten=False, eps=0.0):
+        """(H, W, S) float32 volume as MedicalVolume holds it (sagittal) -> (C, H, W, S) uint8 masks, one
+        contiguous (H, W, S) volume per class; the (S, H, W) <-> (H, W, S) transposes of the reference's
+        generate_mask run on the GPU (one upload, one download)."""
+        v = np.ascontiguousarray(vol_hws, dtype=np.float32)
+        if v.ndim != 3 or v.shape[:2] != (self.H, self.W):
+            raise ValueError(f"volume is {v.shape}, model was built for slices of {(self.H, self.W)}")
+        S = v.shape[2]
+        out = np.empty((self.n_classes, self.H, self.W, S), np.uint8)
+        check(self._lib.qmri_unet2d_segment_volume(self._handle, _ptr(v), S, 1 if whiten else 0, float(eps),
+                                                   _ptr(out), None))
+        return out
 
     def forward_device(self, x_ptr, S, logits_ptr, mask_ptr, *, whiten=False, eps=0.0, stream=None):
         check(self._lib.qmri_unet2d_forward(self._handle, x_ptr, int(S), 1, 1 if whiten else 0, float(eps),

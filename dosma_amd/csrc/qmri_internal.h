@@ -135,6 +135,9 @@ hipError_t maxpool2_launch(const void *x, long long ldx, int xoff, int B, int H,
 hipError_t head_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC,
                        float *logits, unsigned char *mask, int act_bf16, hipStream_t stream);
 hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStream_t stream);
+hipError_t transpose_ps_launch(const float *x, long long P, int S, float *y, hipStream_t stream);
+hipError_t mask_planes_launch(const unsigned char *mask_sp4, long long P, int S, int C, unsigned char *out,
+                              hipStream_t stream);
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
                          hipStream_t stream);
 

@@ -214,7 +214,8 @@ struct Unet {
     DevBuf in;
     std::vector<std::unique_ptr<DevBuf>> tmp, cat, pool, upout;
     DevBuf bottom, stats, vol, logits, mask;
-    long long vol_cap = 0;
+    DevBuf vol_in, mask_all, mask_planes;  // whole-volume staging of qmri_unet2d_segment_volume
+    long long vol_cap = 0, seg_cap = 0;
 };
 
 }  // namespace
@@ -500,6 +501,55 @@ int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_de
         }
     }
     if (!out_on_device || !x_on_device) U_TRY(hipStreamSynchronize(st));
+    return QMRI_OK;
+}
+
+// Whole-volume segmentation in the reference's own layouts (see include/qmri.h): both transposes on the GPU, one
+// upload and one download.
+int qmri_unet2d_segment_volume(void *handle, const float *vol_hws, int32_t S, int32_t whiten, double whiten_eps,
+                               uint8_t *mask_chws, void *stream) {
+    if (!handle || !vol_hws || !mask_chws) return ufail(QMRI_ERR_ARG, "handle / volume / mask is NULL");
+    if (S < 0) return ufail(QMRI_ERR_ARG, "S < 0");
+    if (S == 0) return QMRI_OK;
+    Unet *U = static_cast<Unet *>(handle);
+    if (U->ncls > 4) return ufail(QMRI_ERR_UNSUPPORTED, "at most 4 classes");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    U_TRY(hipSetDevice(U->device));
+    const long long P = (long long)U->H * U->W;
+    const long long n = (long long)S * P;
+    if (U->seg_cap < n) {
+        U_TRY(U->vol_in.alloc((size_t)n * 4));
+        U_TRY(U->mask_all.alloc((size_t)n * 4));  // 4 bytes per pixel (classes padded to 4)
+        U_TRY(U->mask_planes.alloc((size_t)n * U->ncls));
+        U->seg_cap = n;
+    }
+    if (U->vol_cap < n) {
+        U_TRY(U->vol.alloc((size_t)n * 4));
+        U->vol_cap = n;
+    }
+    U_TRY(hipMemcpyAsync(U->vol_in.p, vol_hws, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    U_TRY(qmri::transpose_ps_launch(U->vol_in.as<float>(), P, S, U->vol.as<float>(), st));
+    if (whiten) U_TRY(qmri::whiten_launch(U->vol.as<float>(), n, whiten_eps, U->stats.as<double>(), U->vol.as<float>(), st));
+    if (U->ncls < 4) U_TRY(hipMemsetAsync(U->mask_all.p, 0, (size_t)n * 4, st));
+    unsigned char *mk_all = U->mask_all.as<unsigned char>();
+    for (int s0 = 0; s0 < S; s0 += U->maxB) {
+        const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
+        U_TRY(hipMemcpyAsync(U->in.p, U->vol.as<float>() + (long long)s0 * P, (size_t)Bt * P * 4, hipMemcpyDeviceToDevice, st));
+        unsigned char *mk = U->ncls == 4 ? mk_all + (long long)s0 * P * 4 : nullptr;
+        if (U->ncls == 4) {
+            const int rc = forward_batch(U, Bt, nullptr, mk, st);
+            if (rc != QMRI_OK) return rc;
+        } else {  // fewer classes: the network writes ncls bytes per pixel; widen to the 4-byte records on the way
+            if (!U->mask.p) U_TRY(U->mask.alloc((size_t)U->maxB * P * U->ncls));
+            const int rc = forward_batch(U, Bt, nullptr, U->mask.as<unsigned char>(), st);
+            if (rc != QMRI_OK) return rc;
+            U_TRY(hipMemcpy2DAsync(mk_all + (long long)s0 * P * 4, 4, U->mask.p, (size_t)U->ncls, (size_t)U->ncls,
+                                   (size_t)Bt * P, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    U_TRY(qmri::mask_planes_launch(mk_all, P, S, U->ncls, U->mask_planes.as<unsigned char>(), st));
+    U_TRY(hipMemcpyAsync(mask_chws, U->mask_planes.p, (size_t)n * U->ncls, hipMemcpyDeviceToHost, st));
+    U_TRY(hipStreamSynchronize(st));
     return QMRI_OK;
 }
 

@@ -833,4 +833,62 @@ hipError_t whiten_launch(const float *x, long long n, double eps, double *stats 
     return hipGetLastError();
 }
 
+// ---- volume layout kernels (SegModel.generate_mask's transposes, oaiunet2d.py:295-303, 309-316) --------------
+// x (P, S) fp32 -> y (S, P): the reference reorders the sagittal volume (H, W, slices) to (slices, H, W, 1)
+__global__ __launch_bounds__(256) void transpose_ps_kernel(const float *__restrict__ x, long long P, int S,
+                                                           float *__restrict__ y) {
+    __shared__ float tile[32][33];
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int s0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long long p = p0 + r;
+        const int s = s0 + tx;
+        tile[r][tx] = (p < P && s < S) ? x[p * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int s = s0 + r;
+        const long long p = p0 + tx;
+        if (s < S && p < P) y[(long long)s * P + p] = tile[tx][r];
+    }
+}
+// mask (S, P, 4) u8 -> planes (C, P, S): one (H, W, slices) uint8 volume per class
+__global__ __launch_bounds__(256) void mask_planes_kernel(const unsigned int *__restrict__ m, long long P, int S, int C,
+                                                          unsigned char *__restrict__ out) {
+    __shared__ unsigned int tile[32][33];
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int s0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int s = s0 + r;
+        const long long p = p0 + tx;
+        tile[r][tx] = (s < S && p < P) ? m[(long long)s * P + p] : 0u;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long p = p0 + r;
+        const int s = s0 + tx;
+        if (p < P && s < S) {
+            const unsigned int v = tile[tx][r];
+            for (int c = 0; c < C; ++c) out[((long long)c * P + p) * S + s] = (unsigned char)((v >> (8 * c)) & 0xFFu);
+        }
+    }
+}
+
+hipError_t transpose_ps_launch(const float *x, long long P, int S, float *y, hipStream_t stream) {
+    (void)hipGetLastError();
+    dim3 grid((unsigned)((P + 31) / 32), (unsigned)((S + 31) / 32));
+    hipLaunchKernelGGL(transpose_ps_kernel, grid, dim3(256), 0, stream, x, P, S, y);
+    return hipGetLastError();
+}
+hipError_t mask_planes_launch(const unsigned char *mask_sp4, long long P, int S, int C, unsigned char *out,
+                              hipStream_t stream) {
+    (void)hipGetLastError();
+    dim3 grid((unsigned)((P + 31) / 32), (unsigned)((S + 31) / 32));
+    hipLaunchKernelGGL(mask_planes_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const unsigned int *>(mask_sp4), P, S,
+                       C, out);
+    return hipGetLastError();
+}
+
 }  // namespace qmri

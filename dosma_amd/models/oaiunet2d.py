@@ -36,25 +36,35 @@ class OAIUnet2D(HipSegModel):
         return 0.0
 
     def _segment(self, volume: MedicalVolume):
+        """-> (sagittal MedicalVolume of the input, list of per-class (H, W, S) uint8 arrays)."""
         if not isinstance(volume, MedicalVolume) or volume.ndim != 3:
             raise ValueError("`volume` must be a 3D MedicalVolume")
-        vol_copy = deepcopy(volume)
-        vol_copy.reformat(SAGITTAL, inplace=True)
-        vol = vol_copy.volume
+        # the reference deep-copies and reformats in place (:292-296); a reformat to SAGITTAL gives the same volume
+        # (a view when only axes move) without copying the voxels twice
+        vol_sag = volume.reformat(SAGITTAL)
+        vol = vol_sag.volume
         eng = self.seg_model
         if vol.shape[:2] != (eng.H, eng.W):
             raise ValueError(f"model was built for slices of {(eng.H, eng.W)}, volume has {vol.shape[:2]}")
+        if int(self.batch_size) != eng.max_batch:  # the CLI sets model.batch_size after construction
+            raise ValueError("batch_size was changed after the engine was built; rebuild the model")
         cut = self._check_threshold()
-        logits, mask = self._predict(vol, self._WHITEN, self._WHITEN_EPS, want_logits=cut != 0.0)
-        if cut != 0.0:
-            mask = (logits > cut).astype(np.uint8)
-        return vol_copy, mask  # mask: (S, H, W, C)
+        if cut == 0.0:
+            planes = eng.segment_volume(vol, whiten=self._WHITEN, eps=self._WHITEN_EPS)  # (C, H, W, S)
+            return vol_sag, [planes[i] for i in range(planes.shape[0])]
+        logits, _ = self._predict(vol, self._WHITEN, self._WHITEN_EPS, want_logits=True)
+        mask = (logits > cut).astype(np.uint8)  # (S, H, W, C)
+        return vol_sag, [np.ascontiguousarray(np.transpose(mask[..., i], (1, 2, 0))) for i in range(mask.shape[-1])]
+
+    def _wrap_mask(self, vol_sag: MedicalVolume, plane: np.ndarray, orientation):
+        """uint8 (H, W, S) mask -> MedicalVolume with the sagittal volume's affine / headers (the reference's
+        ``deepcopy(vol_copy); .volume = mask`` :312-316 without copying the float voxels), back in ``orientation``."""
+        m = vol_sag._partial_clone(volume=plane, headers=True)
+        return m.reformat(orientation, inplace=True) if m.orientation != tuple(orientation) else m
 
     def generate_mask(self, volume: MedicalVolume):
-        vol_copy, mask = self._segment(volume)
-        vol_copy.volume = np.ascontiguousarray(np.transpose(mask[..., 0], (1, 2, 0)))
-        vol_copy.reformat(volume.orientation, inplace=True)
-        return vol_copy
+        vol_sag, planes = self._segment(volume)
+        return self._wrap_mask(vol_sag, planes[0], volume.orientation)
 
     def __preprocess_volume__(self, volume: np.ndarray):
         return whiten_volume(volume, eps=1e-8)
@@ -80,15 +90,9 @@ class IWOAIOAIUnet2D(OAIUnet2D):
         return 4
 
     def generate_mask(self, volume: MedicalVolume):
-        vol_copy, mask = self._segment(volume)
-        mask = np.transpose(mask, (1, 2, 0, 3))  # (x, y, slice, classes)
-        vols = {}
-        for i, category in enumerate(self.CATEGORIES):
-            vol_cp = deepcopy(vol_copy)
-            vol_cp.volume = np.ascontiguousarray(mask[..., i])
-            vol_cp.reformat(volume.orientation, inplace=True)
-            vols[category] = vol_cp
-        return vols
+        vol_sag, planes = self._segment(volume)
+        return {category: self._wrap_mask(vol_sag, planes[i], volume.orientation)
+                for i, category in enumerate(self.CATEGORIES)}
 
     def __preprocess_volume__(self, volume: np.ndarray):
         return volume

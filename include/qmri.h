@@ -243,6 +243,16 @@ int qmri_unet2d_set_precision(void *handle, int32_t precision);
 int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_device, int32_t whiten,
                         double whiten_eps, float *logits, uint8_t *mask, int32_t out_on_device,
                         void *stream);
+/*
+ * Whole-volume segmentation in the reference's own array layouts, host pointers, synchronous:
+ *   vol_hws    [H][W][S] fp32 -- MedicalVolume.volume in the sagittal orientation; the reference transposes it to
+ *              (S, H, W, 1) for model.predict (oaiunet2d.py:295-303)
+ *   mask_chws  [n_classes][H][W][S] uint8 -- one volume per class; the reference transposes each class of
+ *              (model.predict(...) > 0.5) back to (H, W, S) (:306-316)
+ * Both transposes, the optional whitening and the threshold run on the GPU: one upload, one download.
+ */
+int qmri_unet2d_segment_volume(void *handle, const float *vol_hws, int32_t S, int32_t whiten, double whiten_eps,
+                               uint8_t *mask_chws, void *stream);
 int qmri_unet2d_destroy(void *handle);
 /*
  * One layer on host NHWC fp32 arrays (operator-level entry; also what the unit tests drive):

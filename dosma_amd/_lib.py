@@ -54,6 +54,7 @@ class QmriMonoexpArgs(ctypes.Structure):
         ("info", ctypes.c_void_p), ("nfev", ctypes.c_void_p),
         ("device", ctypes.c_int32), ("reserved3", ctypes.c_int32),
         ("stream", ctypes.c_void_p),
+        ("y_rows", ctypes.POINTER(ctypes.c_void_p)),
     ]
 
 
@@ -291,20 +292,31 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
     lib = load()
     require_device()
     x = np.ascontiguousarray(x, dtype=np.float64)
-    y = np.asarray(y)
-    if y.ndim != 2:
-        raise ValueError("y must be (E, N)")
-    if not y.flags.c_contiguous:
-        y = np.ascontiguousarray(y)
-    E, N = y.shape
+    a = default_args()
+    if isinstance(y, (list, tuple)):
+        # one contiguous 1-D array per echo (the flattened MedicalVolumes): fitted in place, no (E, N) stacking copy
+        rows = [np.ascontiguousarray(r).reshape(-1) for r in y]
+        E, N = len(rows), rows[0].shape[0]
+        if any(r.shape[0] != N or r.dtype != rows[0].dtype for r in rows):
+            raise ValueError("echo rows must have equal length and dtype")
+        row_ptrs = (ctypes.c_void_p * E)(*[r.ctypes.data for r in rows])
+        a.y_rows = ctypes.cast(row_ptrs, ctypes.POINTER(ctypes.c_void_p))
+        a.y_dtype = qdtype(rows[0].dtype)
+        keep = [x, rows, row_ptrs]
+    else:
+        y = np.asarray(y)
+        if y.ndim != 2:
+            raise ValueError("y must be (E, N)")
+        if not y.flags.c_contiguous:
+            y = np.ascontiguousarray(y)
+        E, N = y.shape
+        a.y = _ptr(y)
+        a.y_dtype = qdtype(y.dtype)
+        keep = [x, y]
     if x.shape != (E,):
         raise ValueError(f"x has shape {x.shape}, expected ({E},)")
-    a = default_args()
-    a.y = _ptr(y)
-    a.y_dtype = qdtype(y.dtype)
     a.E, a.N, a.ld = E, N, N
     a.x = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    keep = [x, y]
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
         if mask.shape[0] != N:

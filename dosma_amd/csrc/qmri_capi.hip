@@ -81,8 +81,11 @@ size_t dtype_size(int dt) {
 
 int validate(const qmri_monoexp_args *a) {
     if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
-    if (!a->y || !a->x || !a->r2 || (!a->popt && !a->tc))
+    if ((!a->y && !a->y_rows) || !a->x || !a->r2 || (!a->popt && !a->tc))
         return fail(QMRI_ERR_ARG, "y, x, r2 and popt (or tc) are required");
+    if (a->y_rows)
+        for (int e = 0; e < a->E && e < QMRI_MAX_ECHOES; ++e)
+            if (!a->y_rows[e]) return fail(QMRI_ERR_ARG, "y_rows[%d] is NULL", e);
     if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
     if (a->out_dtype != QMRI_F32 && a->out_dtype != QMRI_F64)
         return fail(QMRI_ERR_ARG, "out_dtype must be QMRI_F32 or QMRI_F64");
@@ -259,6 +262,7 @@ const char *qmri_monoexp_kernel_name(const qmri_monoexp_args *a) {
 int qmri_monoexp_fit_device(const qmri_monoexp_args *a, int32_t *nonfinite_flag) {
     const int rc = validate(a);
     if (rc != QMRI_OK) return rc;
+    if (!a->y) return fail(QMRI_ERR_ARG, "the device entry needs the (E, ld) array y (y_rows is for the host entry)");
     return launch_fit(a, nonfinite_flag);
 }
 
@@ -445,8 +449,9 @@ int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
         hipStream_t st = B.stream;
         for (int e = 0; e < a->E && up_err == hipSuccess; ++e)
             up_err = hipMemcpyAsync(static_cast<char *>(B.y) + (size_t)e * S * es,
-                                    static_cast<const char *>(a->y) + ((size_t)e * a->ld + s0) * es, (size_t)cnt * es,
-                                    hipMemcpyHostToDevice, st);
+                                    a->y_rows ? static_cast<const char *>(a->y_rows[e]) + (size_t)s0 * es
+                                              : static_cast<const char *>(a->y) + ((size_t)e * a->ld + s0) * es,
+                                    (size_t)cnt * es, hipMemcpyHostToDevice, st);
         if (up_err == hipSuccess && a->mask) up_err = hipMemcpyAsync(B.mask, a->mask + s0, (size_t)cnt, hipMemcpyHostToDevice, st);
         if (up_err == hipSuccess && B.a0v && per_voxel && a->a0v)
             up_err = hipMemcpyAsync(B.a0v, a->a0v + s0, (size_t)cnt * 8, hipMemcpyHostToDevice, st);
@@ -456,6 +461,7 @@ int qmri_monoexp_fit_host(const qmri_monoexp_args *a) {
 
         qmri_monoexp_args d = *a;
         d.y = B.y;
+        d.y_rows = nullptr;
         d.ld = S;
         d.N = cnt;
         d.mask = a->mask ? B.mask : nullptr;

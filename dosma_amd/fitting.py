@@ -160,6 +160,14 @@ def _as_kernel_samples(y):
     raise TypeError(f"Cannot fit data of dtype {y.dtype}")
 
 
+def _as_kernel_rows(rows):
+    """Per-echo flattened volumes in ONE dtype the kernel reads natively (the reference's np.concatenate promotes
+    mixed dtypes to a common one, fitting.py:195)."""
+    dt = np.result_type(*[r.dtype for r in rows])
+    probe = _as_kernel_samples(np.empty(0, dtype=dt)).dtype
+    return [np.ascontiguousarray(r, dtype=probe) for r in rows]
+
+
 def curve_fit(
     func,
     x,
@@ -324,7 +332,7 @@ class _Fitter:
         return ob[:, 0].copy(), ob[:, 1].copy()
 
     # ---- shared front half of fit(): checks + flatten to (E, N) ----
-    def _prepare(self, x, y, mask):
+    def _prepare(self, x, y, mask, rows=False):
         if (not isinstance(y, (list, tuple))) or (not all(isinstance(_y, MedicalVolume) for _y in y)):
             raise TypeError("`y` must be sequence of MedicalVolumes.")
         x = np.asarray(x)
@@ -337,6 +345,8 @@ class _Fitter:
         if mask is not None:
             mask = self._process_mask(mask, y[0])
             mask_flat = np.ascontiguousarray(mask.volume.reshape(-1))
+        if rows:  # the flattened volumes themselves (views when contiguous): no (E, N) stacking copy
+            return x, y, [_y.volume.reshape(-1) for _y in y], mask_flat
         svs = np.concatenate([_y.volume.reshape((1, -1)) for _y in y], axis=0)
         return x, y, svs, mask_flat
 
@@ -460,8 +470,8 @@ class CurveFitter(_Fitter):
                 "on the GPU; there is no CPU fallback.")
         if isinstance(x, MedicalVolume):
             raise RuntimeError("`x` must be on the CPU")
-        x, y, svs, mask_flat = self._prepare(x, y, mask)
-        N = svs.shape[1]
+        x, y, svs, mask_flat = self._prepare(x, y, mask, rows=model == "monoexponential")
+        N = svs[0].shape[0] if isinstance(svs, list) else svs.shape[1]
         if p0 is np._NoValue:
             p0 = self.p0
         p0 = self._format_p0(p0, ref=y[0], flatten=True)
@@ -471,7 +481,8 @@ class CurveFitter(_Fitter):
         if getattr(self, "_loglin_init", False):
             init = _lib.INIT_LOGLIN
 
-        if self.y_bounds is not None and ((svs < self.y_bounds[0]).any() or (svs > self.y_bounds[1]).any()):
+        if self.y_bounds is not None and any((r < self.y_bounds[0]).any() or (r > self.y_bounds[1]).any()
+                                             for r in (svs if isinstance(svs, list) else [svs])):
             warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
 
         if model != "monoexponential":
@@ -482,7 +493,7 @@ class CurveFitter(_Fitter):
             post["decimals"] = _decimals
         tc_only = _tc_only and post is not None  # MonoExponentialFit: only (tc, r2) leave the GPU
         out = _lib.monoexp_fit_host(
-            x.astype(np.float64).reshape(-1), _as_kernel_samples(svs), mask=mask_flat, init=init,
+            x.astype(np.float64).reshape(-1), _as_kernel_rows(svs), mask=mask_flat, init=init,
             p0=tuple(1.0 if isinstance(v, np.ndarray) else v for v in p0),
             a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
             b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,

@@ -118,6 +118,10 @@ typedef struct qmri_monoexp_args {
     int32_t device;      /* HIP device ordinal                                                        */
     int32_t reserved3;
     void *stream;        /* hipStream_t (NULL = default stream); the call is asynchronous on it       */
+    /* ---- host entry only ---- */
+    const void *const *y_rows; /* nullable HOST [E]: echo e is the contiguous array y_rows[e][0..N) and y / ld are
+                            ignored -- the E MedicalVolumes are fitted where they lie, without the 4 E N-byte
+                            np.concatenate of fitting.py:194-196                                       */
 } qmri_monoexp_args;
 
 /* Fill the solver constants and post block with the reference's defaults. */

@@ -39,17 +39,17 @@ constexpr int kTW = 16;         // output tile width (pixels)
 // chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
 // LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
 // fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
-template <int BN, int TH_, bool WALL>
+template <int BN, int TH_, bool WALL, int TW = 16>
 struct TileCfg {
     // WALL (small BN): the weights of ALL taps of a chunk are staged at once -> 2 barriers per chunk
     // instead of one per tap (at BN <= 64 a tap is only 2-4 MFMAs per wave, less than a barrier costs)
     static constexpr int TH = TH_;
-    static constexpr int BM = TH * kTW;
+    static constexpr int BM = TH * TW;
     static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
     static constexpr int WAVES_M = 4 / WAVES_N;
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
-    static constexpr int HALO_PIX = (TH + 2) * (kTW + 2);
+    static constexpr int HALO_PIX = (TH + 2) * (TW + 2);
     static constexpr int HALO_PAIRS = (HALO_PIX * 4 + 255) / 256;  // (pixel, 8-channel group) per thread
     static constexpr int B_PAIRS = (BN * 4 + 255) / 256;
     static constexpr int WALL_PAIRS = (9 * BN * 4 + 255) / 256;
@@ -73,8 +73,13 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false>
+template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
+    // TW: tile width.  16 in general; the deep levels of a 384 x 384 input are 24 and 12 pixels wide, where 16-wide
+    // tiles waste 25 % / 44 % of the MFMA rows on padding: TW = 24 (x 8 rows = 6 row-tiles) and TW = 12 (x 16 rows, the
+    // whole 12 x 12 image + 4 padding rows = 6 row-tiles) cover them with 0 % / 25 %.  A row-tile is any 32 consecutive
+    // pixels of the tile in row-major order (a_row0 is per lane), so nothing else depends on the width.
+    constexpr int kTW = TW;
     // DECONV: all four output phases of Conv2DTranspose(3x3, stride 2, SAME) in one pass: the 9 taps are
     // ordered [phase (0,0): 4][phase (0,1): 2][phase (1,0): 2][phase (1,1): 1], each tap accumulates into
     // its phase's accumulator, and the epilogue writes four interleaved output tiles.  The input halo is
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
-    using C = TileCfg<BN, TH, WALL>;
+    using C = TileCfg<BN, TH, WALL, TW>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
@@ -483,10 +488,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #undef QMRI_LOAD_WALL
 #undef QMRI_STORE_WALL
 
-template <int BN, int TH, bool S3>
+template <int BN, int TH, bool S3, int TW = 16>
 static size_t conv_lds_bytes() {
     constexpr bool WALL = BN <= 64 && !S3;
-    using C = TileCfg<BN, TH, WALL>;
+    using C = TileCfg<BN, TH, WALL, TW>;
     const int planes = S3 ? 2 : 1;
     const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
@@ -514,6 +519,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     if (!split3 && conv_rw_supported(k)) return conv_rw_launch(k, stream);
     // the fused transposed convolution keeps 4 accumulator sets: cap the channel tile at 64
     // (plain-bf16 transposed convolution: 64- and 128-channel tiles measured 10-40 % slower than 32)
+    // (64-channel tiles for the deep levels, where 128-channel tiles leave ~1 block per CU: measured 25-45 % slower)
     const int bn = k.deconv ? ((split3 && k.Cout % 64 == 0) ? 64 : 32)
                             : (k.Cout % 128 == 0 ? 128 : (k.Cout % 64 == 0 ? 64 : 32));
     if (k.deconv && (k.ntaps != 9 || k.sy != 2 || k.sx != 2 || k.pool_y || k.head_w)) return hipErrorInvalidValue;
@@ -527,10 +533,27 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         if (split3) th = bn == 128 ? 8 : 16;
         else th = (k.H % 16 == 0) ? conv_tile_rows(bn) : 8;
     }
+    static const int narrow_ok = [] { const char *e = std::getenv("QMRI_CONV_NARROW"); return e ? std::atoi(e) : 1; }();
+    int tw = kTW;
+    if (narrow_ok && !k.deconv && !split3 && bn == 128 && th == 8) {
+        if (k.W == 24 && k.H % 8 == 0) tw = 24;
+        else if (k.W == 12 && k.H <= 16) tw = 12, th = 16;
+    }
     k.tiles_y = (k.H + th - 1) / th;
-    k.tiles_x = (k.W + kTW - 1) / kTW;
+    k.tiles_x = (k.W + tw - 1) / tw;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
+#define QMRI_CONV_CASE_TW(BN_, TH_, TW_)                                                            \
+    do {                                                                                            \
+        auto fn = conv_igemm_kernel<BN_, TH_, false, __bf16, false, false, TW_>;                    \
+        const size_t lds = conv_lds_bytes<BN_, TH_, false, TW_>();                                  \
+        if (lds > 64 * 1024) {                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                          \
+        }                                                                                           \
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);                                    \
+    } while (0)
 #define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_, ...)                                                     \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_, ##__VA_ARGS__>;                                  \
@@ -552,7 +575,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         else if (k.c1_x) QMRI_CONV_CASE(32, 16, true, float, false, true);
         else QMRI_CONV_CASE(32, 16, true, float, false);
     } else if (bn == 128) {
-        if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
+        if (tw == 24) QMRI_CONV_CASE_TW(128, 8, 24);
+        else if (tw == 12) QMRI_CONV_CASE_TW(128, 16, 12);
+        else if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {
         if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);
     } else {
@@ -564,6 +589,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         }
     }
 #undef QMRI_CONV_CASE
+#undef QMRI_CONV_CASE_TW
     return hipGetLastError();
 }
 

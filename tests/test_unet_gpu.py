@@ -32,7 +32,8 @@ def torch_conv(x, k, b, relu, transposed):
 
 @pytest.mark.parametrize("cin,cout,hw,transposed", [(32, 32, (20, 12), False), (64, 32, (9, 7), False),
                                                     (32, 64, (16, 16), False), (128, 128, (8, 24), False),
-                                                    (64, 256, (5, 6), False), (64, 32, (6, 5), True),
+                                                    (64, 256, (5, 6), False), (128, 128, (12, 12), False),
+                                                    (64, 256, (24, 24), False), (64, 32, (6, 5), True),
                                                     (128, 64, (8, 8), True), (256, 128, (3, 4), True)])
 def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     rng = np.random.default_rng(cin * 7 + cout)

@@ -374,9 +374,9 @@ def main():
                 "note": "the kernel is fp64-VALU bound, not HBM bound: MINPACK's early-stopped trajectory needs ~53 "
                         "model evaluations (x 8 exps) + 17 QR / lmpar rounds per voxel in fp64; see `valu` and DESIGN.md 3.1",
                 # measured with rocprofv3 PMC on this kernel and workload (profiles/r01d_counters.json; constants, not
-                # re-measured by this run): VALU pipes busy 83 % of the kernel's cycles, 38.7 of 64 lanes active per
+                # re-measured by this run): VALU pipes busy 84 % of the kernel's cycles, 38.6 of 64 lanes active per
                 # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.14x algorithmic
-                "valu": {"busy_frac": 0.83, "lanes_active_frac": 0.604, "hbm_traffic_over_algorithmic": 1.14,
+                "valu": {"busy_frac": 0.84, "lanes_active_frac": 0.604, "hbm_traffic_over_algorithmic": 1.14,
                          "source": "profiles/r01d_counters.json"},
             },
             "runs": {

@@ -11,8 +11,11 @@ bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlin
 json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
 
 
-def last_dispatch(path, kernel="monoexp"):
-    rows = [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"]]
+HEADLINE = ("monoexp_lm_kernel<8, true, float>", "monoexp_lm_kernelILi8ELb1EfEE")  # the bench's headline variant
+
+
+def last_dispatch(path, kernel=HEADLINE):
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in kernel)]
     last = max(int(r["Dispatch_Id"]) for r in rows)
     return {r["Counter_Name"]: float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last}, rows[0]
 
@@ -24,7 +27,7 @@ n = bench["config"]["voxels_per_gpu_per_step"]
 alg = bench["roofline"]["algorithmic_bytes_per_voxel"] * n
 rd = 2 * fetch["FETCH_SIZE"] * 1024   # MI355X_MICROARCH.md: FETCH_SIZE counts 1/2 of a wide coalesced read
 wr = write["WRITE_SIZE"] * 1024
-stats = [r for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")) if "monoexp" in r["Name"]][0]
+stats = [r for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")) if any(k in r["Name"] for k in HEADLINE)][0]
 out = {
     "tag": tag,
     "kernel": stats["Name"],

@@ -16,6 +16,7 @@ from dosma_amd.fitting import (  # noqa: F401
     polyfit,
 )
 from dosma_amd.med_volume import MedicalVolume  # noqa: F401
+from dosma_amd._lib import default_device, set_default_device  # noqa: F401
 from dosma_amd.io import ImageDataFormat, NiftiReader, NiftiWriter  # noqa: F401,E402
 
 __version__ = "0.1.0"

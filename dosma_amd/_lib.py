@@ -239,6 +239,24 @@ def check(rc: int):
     raise QmriError(msg)
 
 
+_default_device = int(os.environ.get("DOSMA_AMD_DEVICE", "0"))
+
+
+def set_default_device(index: int):
+    """HIP device used by every host-level call of this process that does not name one (one process per GPU:
+    ``dosma_amd.dist.init`` sets it to the local rank).  Also settable with ``DOSMA_AMD_DEVICE``."""
+    global _default_device
+    _default_device = int(index)
+
+
+def default_device() -> int:
+    return _default_device
+
+
+def _dev(device):
+    return _default_device if device is None else int(device)
+
+
 def require_device() -> int:
     n = load().qmri_device_count()
     if n <= 0:
@@ -283,7 +301,7 @@ def set_post(a: QmriMonoexpArgs, inv_abs_b=False, bounds=None, r2_threshold=None
 
 
 def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=None, b0v=None,
-                     post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=0,
+                     post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=None,
                      ftol=None, maxfev=None, r2_eps=None, y_bounds=None, out=None, want_popt=True):
     """Run the HIP fit on host (numpy) buffers.  ``y``: (E, N) C-contiguous, echo-major.
 
@@ -371,14 +389,14 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
         out["info"] = np.empty(N, dtype=np.int8)
         out["nfev"] = np.empty(N, dtype=np.int16)
         a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
-    a.device = int(device)
+    a.device = _dev(device)
     check(lib.qmri_monoexp_fit_host(ctypes.byref(a)))
     del keep
     return out
 
 
 def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds=None, r2_eps=1e-8,
-                out_dtype=np.float64, device=0):
+                out_dtype=np.float64, device=None):
     """Degree-1 least squares per column of ``y`` (E, N) on the GPU -> dict(popt (N,2), r2 (N,))."""
     lib = load()
     require_device()
@@ -401,13 +419,13 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
     out = {"popt": np.empty((N, 2), dtype=od), "r2": np.empty(N, dtype=od)}
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
-    a.device = int(device)
+    a.device = _dev(device)
     check(lib.qmri_linfit_host(ctypes.byref(a)))
     return out
 
 
 def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds=None, want_info=False,
-               device=0):
+               device=None):
     """General lmdif (true forward differences) on the GPU.  ``model``: "biexponential" | "monoexponential";
     ``y`` (E, N) echo-major; ``p0``: one entry per parameter, a float or a float64 array of length N.
     Returns dict(popt (N, n), r2 (N,), [info, nfev])."""
@@ -451,14 +469,14 @@ def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds
         out["info"] = np.empty(N, dtype=np.int8)
         out["nfev"] = np.empty(N, dtype=np.int16)
         a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
-    a.device = int(device)
+    a.device = _dev(device)
     check(lib.qmri_lmfit_host(ctypes.byref(a)))
     del keep
     return out
 
 
 def conv2d_nhwc_host(x, kernel, bias, *, scale=None, shift=None, relu=True, transposed=False,
-                     precision="bf16x3", device=0):
+                     precision="bf16x3", device=None):
     """One conv layer on the GPU from host arrays: x (B,H,W,Cin) f32; kernel in the Keras layout --
     (3,3,Cin,Cout) for Conv2D, (3,3,Cout,Cin) for Conv2DTranspose(strides=2).  Returns NHWC f32."""
     lib = load()
@@ -475,7 +493,7 @@ def conv2d_nhwc_host(x, kernel, bias, *, scale=None, shift=None, relu=True, tran
     y = np.empty((B, 2 * H, 2 * W, Cout) if transposed else (B, H, W, Cout), dtype=np.float32)
     check(lib.qmri_conv2d_nhwc_host(_ptr(x), B, H, W, Cin, _ptr(kernel), _ptr(bias), _ptr(sc), _ptr(sh),
                                     1 if relu else 0, Cout, 1 if transposed else 0, PRECISION[precision],
-                                    _ptr(y), int(device)))
+                                    _ptr(y), _dev(device)))
     return y
 
 
@@ -483,7 +501,7 @@ class Unet2dEngine:
     """Owns a native U-Net instance (weights packed on the GPU + activation buffers)."""
 
     def __init__(self, tensors, H, W, *, depth=6, base_features=32, n_classes=4, max_batch=16,
-                 precision="bf16x3", device=0, bn_eps=1e-3):
+                 precision="bf16x3", device=None, bn_eps=1e-3):
         lib = load()
         require_device()
         self._lib = lib
@@ -493,7 +511,7 @@ class Unet2dEngine:
         d = QmriUnet2dDesc()
         d.depth, d.base_features, d.n_classes = depth, base_features, n_classes
         d.H, d.W, d.max_batch = int(H), int(W), int(max_batch)
-        d.precision, d.device = PRECISION[precision], int(device)
+        d.precision, d.device = PRECISION[precision], _dev(device)
         d.tensors = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
         d.n_tensors = len(keep)
         d.bn_eps = float(bn_eps)
@@ -545,7 +563,7 @@ class Unet2dEngine:
 
 
 def dess_t2_host(echo1, echo2, c0, k, c1, *, bounds=None, nan_to_num=None, decimals=None,
-                 suppress_fat=False, suppress_fluid=False, beta=1.2, out_dtype=np.float64, device=0):
+                 suppress_fat=False, suppress_fluid=False, beta=1.2, out_dtype=np.float64, device=None):
     """Analytic DESS T2 map on the GPU from two host echo arrays of equal shape -> array of that shape."""
     lib = load()
     require_device()
@@ -567,12 +585,12 @@ def dess_t2_host(echo1, echo2, c0, k, c1, *, bounds=None, nan_to_num=None, decim
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
     out = np.empty(e1.shape, dtype=od)
     a.t2 = _ptr(out)
-    a.device = int(device)
+    a.device = _dev(device)
     check(lib.qmri_dess_t2_host(ctypes.byref(a)))
     return out
 
 
-def rss_host(echo1, echo2, method="rss", device=0):
+def rss_host(echo1, echo2, method="rss", device=None):
     lib = load()
     require_device()
     e1 = np.ascontiguousarray(echo1)
@@ -583,5 +601,5 @@ def rss_host(echo1, echo2, method="rss", device=0):
         raise ValueError(f"`method={method}` is not supported")
     out = np.empty(e1.shape, dtype=np.float64)
     check(lib.qmri_rss_host(_ptr(e1), _ptr(e2), qdtype(e1.dtype), e1.size, 0 if method == "rss" else 1,
-                            _ptr(out), int(device)))
+                            _ptr(out), _dev(device)))
     return out

@@ -40,6 +40,10 @@ def init(backend: str = None):
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    if torch.cuda.is_available():  # one process per GPU: this rank's host-level calls go to its own device
+        from dosma_amd import _lib
+
+        _lib.set_default_device(local_rank % max(torch.cuda.device_count(), 1))
     return rank, local_rank, world
 
 

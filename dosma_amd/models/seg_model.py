@@ -57,7 +57,7 @@ class HipSegModel(SegModel):
 
     #: "bf16x3" (split-bf16, ~fp32 accuracy: logits within 1e-3 of an fp32 run) or "bf16" (single MFMA)
     precision = "bf16x3"
-    device = 0
+    device = None  # None: dosma_amd.set_default_device / DOSMA_AMD_DEVICE (0)
 
     def build_model(self, input_shape, weights_path=None):
         from dosma_amd import _lib

@@ -39,20 +39,21 @@ constexpr int kTW = 16;         // output tile width (pixels)
 // chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
 // LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
 // fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
-template <int BN, int TH_, bool WALL, int TW = 16>
+template <int BN, int TH_, bool WALL, int TW = 16, int NW = 4>
 struct TileCfg {
+    static constexpr int NT = NW * 64;  // threads per block
     // WALL (small BN): the weights of ALL taps of a chunk are staged at once -> 2 barriers per chunk
     // instead of one per tap (at BN <= 64 a tap is only 2-4 MFMAs per wave, less than a barrier costs)
     static constexpr int TH = TH_;
     static constexpr int BM = TH * TW;
     static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
-    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WAVES_M = NW / WAVES_N;
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
     static constexpr int HALO_PIX = (TH + 2) * (TW + 2);
-    static constexpr int HALO_PAIRS = (HALO_PIX * 4 + 255) / 256;  // (pixel, 8-channel group) per thread
-    static constexpr int B_PAIRS = (BN * 4 + 255) / 256;
-    static constexpr int WALL_PAIRS = (9 * BN * 4 + 255) / 256;
+    static constexpr int HALO_PAIRS = (HALO_PIX * 4 + NT - 1) / NT;  // (pixel, 8-channel group) per thread
+    static constexpr int B_PAIRS = (BN * 4 + NT - 1) / NT;
+    static constexpr int WALL_PAIRS = (9 * BN * 4 + NT - 1) / NT;
 };
 
 __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo,
@@ -73,8 +74,9 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
+template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) {
+    constexpr int kNT = NW * 64;  // NW = 8: a 16 x 16-pixel tile on 8 waves (4 x 2), twice the MFMAs per weight tile and barrier
     // TW: tile width.  16 in general; the deep levels of a 384 x 384 input are 24 and 12 pixels wide, where 16-wide
     // tiles waste 25 % / 44 % of the MFMA rows on padding: TW = 24 (x 8 rows = 6 row-tiles) and TW = 12 (x 16 rows, the
     // whole 12 x 12 image + 4 padding rows = 6 row-tiles) cover them with 0 % / 25 %.  A row-tile is any 32 consecutive
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
-    using C = TileCfg<BN, TH, WALL, TW>;
+    using C = TileCfg<BN, TH, WALL, TW, NW>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     const int y0 = ty * C::TH, x0 = tx * kTW;
     const long long img_base = (long long)b * A.H * A.W;
 
-    for (int r = tid; r < C::BM; r += 256) {
+    for (int r = tid; r < C::BM; r += kNT) {
         const int ly = r / kTW, lx = r % kTW;
         const int yy = y0 + ly, xx = x0 + lx;
         int pix = -1;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     int h_dst[C::HALO_PAIRS];        // byte offset inside a halo plane
 #pragma unroll
     for (int r = 0; r < C::HALO_PAIRS; ++r) {
-        const int idx = tid + r * 256;
+        const int idx = tid + r * kNT;
         const int hp = idx >> 2, grp = idx & 3;
         const int hy = hp / (kTW + 2), hx = hp - hy * (kTW + 2);
         const int yy = y0 + hy - 1, xx = x0 + hx - 1;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     // weights of K step `step` (= chunk * ntaps + tap): [BN][32] slice of W[co][step*32 + c]
 #define QMRI_LOAD_W(step_)                                                                         \
     _Pragma("unroll") for (int r = 0; r < C::B_PAIRS; ++r) {                                       \
-        const int idx_ = tid + r * 256;                                                            \
+        const int idx_ = tid + r * kNT;                                                            \
         if (idx_ < BN * 4) {                                                                       \
             const long long off_ =                                                                 \
                 (long long)(n0 + (idx_ >> 2)) * K + (long long)(step_) * kBK + (idx_ & 3) * 8;     \
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     {                                                                                              \
         unsigned char *base_ = w_base + (buf_) * NPLANES * W_BYTES;                                \
         _Pragma("unroll") for (int r = 0; r < C::B_PAIRS; ++r) {                                   \
-            const int idx_ = tid + r * 256;                                                        \
+            const int idx_ = tid + r * kNT;                                                        \
             if (idx_ < BN * 4) {                                                                   \
                 const int off_ = ((idx_ >> 2) * kLdsRow + (idx_ & 3) * 8) * 2;                     \
                 *reinterpret_cast<bf16x8 *>(base_ + off_) = rb_hi[r];                              \
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     // WALL: all taps of chunk `ch_`: tap-major [ntaps][BN][32]
 #define QMRI_LOAD_WALL(ch_)                                                                        \
     _Pragma("unroll") for (int r = 0; r < C::WALL_PAIRS; ++r) {                                    \
-        const int idx_ = tid + r * 256;                                                            \
+        const int idx_ = tid + r * kNT;                                                            \
         if (idx_ < ntaps * BN * 4) {                                                               \
             const int tap_ = idx_ / (BN * 4), rem_ = idx_ - tap_ * (BN * 4);                       \
             const long long off_ = (long long)(n0 + (rem_ >> 2)) * K +                             \
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     }
 #define QMRI_STORE_WALL()                                                                          \
     _Pragma("unroll") for (int r = 0; r < C::WALL_PAIRS; ++r) {                                    \
-        const int idx_ = tid + r * 256;                                                            \
+        const int idx_ = tid + r * kNT;                                                            \
         if (idx_ < ntaps * BN * 4) {                                                               \
             const int off_ = ((idx_ >> 2) * kLdsRow + (idx_ & 3) * 8) * 2;                         \
             *reinterpret_cast<bf16x8 *>(w_base + off_) = rb_hi[r];                                 \
@@ -248,13 +250,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         // input is computed here -- relu(conv3x3(image) + bias), 32 channels -- straight into the staging
         // registers, so the first feature map never goes to HBM.  Pixels outside the image are the zero
         // padding of this convolution, not conv1 outputs.
-        for (int i = tid; i < 9 * 32 + 32; i += 256) c1w[i] = i < 288 ? A.c1_w[i] : A.c1_b[i - 288];
+        for (int i = tid; i < 9 * 32 + 32; i += kNT) c1w[i] = i < 288 ? A.c1_w[i] : A.c1_b[i - 288];
         __syncthreads();
         const int grp = tid & 3;
         const float *img = A.c1_x + img_base;
 #pragma unroll
         for (int r = 0; r < C::HALO_PAIRS; ++r) {
-            const int hp = (tid + r * 256) >> 2;
+            const int hp = (tid + r * kNT) >> 2;
             const int hy = hp / (kTW + 2), hx = hp - hy * (kTW + 2);
             const int yy = y0 + hy - 1, xx = x0 + hx - 1;
             const bool inside = hp < C::HALO_PIX && yy >= 0 && yy < A.H && xx >= 0 && xx < A.W;
@@ -405,12 +407,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         }
     }
     if (A.head_w) {
-        for (int i = tid; i < BN * A.head_nc + A.head_nc; i += 256)
+        for (int i = tid; i < BN * A.head_nc + A.head_nc; i += kNT)
             hw[i] = i < BN * A.head_nc ? A.head_w[i] : A.head_b[i - BN * A.head_nc];
     }
     __syncthreads();
     if (A.y) {
-        for (int idx = tid; idx < C::BM * CH; idx += 256) {
+        for (int idx = tid; idx < C::BM * CH; idx += kNT) {
             const int row = idx / CH, c = idx - row * CH;
             const int pix = rowpix[row];
             if (pix >= 0) {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
     if (A.pool_y) {
         constexpr int VPC = 16 / (int)sizeof(AT);  // values per 16-byte chunk
         const int Hp = A.H >> 1, Wp = A.W >> 1;
-        for (int idx = tid; idx < (C::BM / 4) * CH; idx += 256) {
+        for (int idx = tid; idx < (C::BM / 4) * CH; idx += kNT) {
             const int q = idx / CH, c = idx - q * CH;
             const int qy = q / (kTW / 2), qx = q - qy * (kTW / 2);
             const int yy = (y0 >> 1) + qy, xx = (x0 >> 1) + qx;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 4; ++c) wr[q][c] = c < NC ? hw[(sub * 4 + q) * NC + c] : 0.f;
-        for (int row = tid / LPP; row < C::BM; row += 256 / LPP) {
+        for (int row = tid / LPP; row < C::BM; row += kNT / LPP) {
             float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -488,10 +490,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs A) {
 #undef QMRI_LOAD_WALL
 #undef QMRI_STORE_WALL
 
-template <int BN, int TH, bool S3, int TW = 16>
+template <int BN, int TH, bool S3, int TW = 16, int NW = 4>
 static size_t conv_lds_bytes() {
     constexpr bool WALL = BN <= 64 && !S3;
-    using C = TileCfg<BN, TH, WALL, TW>;
+    using C = TileCfg<BN, TH, WALL, TW, NW>;
     const int planes = S3 ? 2 : 1;
     const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
@@ -539,6 +541,9 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         if (k.W == 24 && k.H % 8 == 0) tw = 24;
         else if (k.W == 12 && k.H <= 16) tw = 12, th = 16;
     }
+    static const int w8 = [] { const char *e = std::getenv("QMRI_CONV_W8"); return e ? std::atoi(e) : 1; }();
+    const bool eight = w8 && !k.deconv && !split3 && bn == 128 && th == 8 && tw == kTW && k.H % 16 == 0 && k.W % 16 == 0;
+    if (eight) th = 16;
     k.tiles_y = (k.H + th - 1) / th;
     k.tiles_x = (k.W + tw - 1) / tw;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
@@ -575,7 +580,13 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         else if (k.c1_x) QMRI_CONV_CASE(32, 16, true, float, false, true);
         else QMRI_CONV_CASE(32, 16, true, float, false);
     } else if (bn == 128) {
-        if (tw == 24) QMRI_CONV_CASE_TW(128, 8, 24);
+        if (eight) {
+            auto fn = conv_igemm_kernel<128, 16, false, __bf16, false, false, 16, 8>;
+            const size_t lds = conv_lds_bytes<128, 16, false, 16, 8>();
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, k);
+        } else if (tw == 24) QMRI_CONV_CASE_TW(128, 8, 24);
         else if (tw == 12) QMRI_CONV_CASE_TW(128, 16, 12);
         else if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {

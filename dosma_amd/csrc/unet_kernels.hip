@@ -548,16 +548,16 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     k.tiles_x = (k.W + tw - 1) / tw;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
     (void)hipGetLastError();
-#define QMRI_CONV_CASE_TW(BN_, TH_, TW_)                                                            \
+#define QMRI_CONV_CASE_TW(BN_, TH_, TW_, NW_)                                                       \
     do {                                                                                            \
-        auto fn = conv_igemm_kernel<BN_, TH_, false, __bf16, false, false, TW_>;                    \
-        const size_t lds = conv_lds_bytes<BN_, TH_, false, TW_>();                                  \
+        auto fn = conv_igemm_kernel<BN_, TH_, false, __bf16, false, false, TW_, NW_>;               \
+        const size_t lds = conv_lds_bytes<BN_, TH_, false, TW_, NW_>();                             \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                          \
         }                                                                                           \
-        hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);                                    \
+        hipLaunchKernelGGL(fn, grid, dim3(64 * NW_), lds, stream, k);                               \
     } while (0)
 #define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_, ...)                                                     \
     do {                                                                                            \
@@ -603,8 +603,8 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, k);
-        } else if (tw == 24) QMRI_CONV_CASE_TW(128, 8, 24);
-        else if (tw == 12) QMRI_CONV_CASE_TW(128, 16, 12);
+        } else if (tw == 24) QMRI_CONV_CASE_TW(128, 8, 24, 4);  // (6 waves = 3 x 2 on these 192-pixel tiles: 24 x 24 levels
+        else if (tw == 12) QMRI_CONV_CASE_TW(128, 16, 12, 4);   //  50 % slower -- 6 waves do not spread over 4 SIMDs)
         else if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {
         if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);

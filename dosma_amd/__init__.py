@@ -17,6 +17,8 @@ from dosma_amd.fitting import (  # noqa: F401
 )
 from dosma_amd.med_volume import MedicalVolume  # noqa: F401
 from dosma_amd._lib import default_device, set_default_device  # noqa: F401
-from dosma_amd.io import ImageDataFormat, NiftiReader, NiftiWriter  # noqa: F401,E402
+from dosma_amd.io import ImageDataFormat, NiftiReader, NiftiWriter, read, write  # noqa: F401,E402
+from dosma_amd.orientation import to_affine  # noqa: F401,E402
+from dosma_amd import models, quant_vals, scan_sequences  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -5,7 +5,7 @@ import os
 from dosma_amd.io.format_io import ImageDataFormat
 from dosma_amd.io.nifti_io import NiftiReader, NiftiWriter
 
-__all__ = ["get_reader", "get_writer", "convert_image_data_format", "generic_load"]
+__all__ = ["get_reader", "get_writer", "convert_image_data_format", "generic_load", "read", "write"]
 
 
 def get_reader(data_format: ImageDataFormat):
@@ -53,3 +53,28 @@ def generic_load(file_or_dir_path, expected_num_volumes: int = None):
         vols = [vols]
     assert len(vols) == expected_num_volumes, "Expected %d volumes, got %d" % (expected_num_volumes, len(vols))
     return vols[0] if len(vols) == 1 else vols
+
+
+def read(path, data_format: ImageDataFormat = None, unpack: bool = False, **kwargs):
+    """``dm.read`` (reference :158-193): the format comes from the extension unless given (enum or its name)."""
+    if data_format is None:
+        data_format = ImageDataFormat.get_image_data_format(path)
+    elif isinstance(data_format, str):
+        data_format = ImageDataFormat[data_format]
+    out = get_reader(data_format).load(path, **kwargs)
+    if unpack and isinstance(out, (tuple, list)) and len(out) == 1:
+        out = out[0]
+    return out
+
+
+def write(vol, path, data_format: ImageDataFormat = None, **kwargs) -> None:
+    """``dm.write`` (reference :196-222)."""
+    if data_format is None:
+        data_format = ImageDataFormat.get_image_data_format(path)
+    elif isinstance(data_format, str):
+        data_format = ImageDataFormat[data_format]
+    get_writer(data_format).save(vol, path, **kwargs)
+
+
+load = read
+save = write

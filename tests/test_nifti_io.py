@@ -126,6 +126,14 @@ def test_round_trips_and_orientations(tmp_path):
     assert ImageDataFormat.get_image_data_format("a/b") == ImageDataFormat.dicom
     r = NiftiReader()
     r.load_state_dict({k: "foo" for k in r.state_dict()})
+    # dm.read / dm.write (format from the extension or by name)
+    import dosma_amd as dm
+
+    dm.write(m, str(tmp_path / "w.nii.gz"))
+    assert np.array_equal(dm.read(str(tmp_path / "w.nii.gz"), data_format="nifti").volume, m.volume.astype(np.float64))
+    with pytest.raises(NotImplementedError):
+        dm.read(str(tmp_path / "a_dicom_directory"))
+    assert dm.to_affine(("SI", "AP", "LR"), (0.4, 0.4, 1.5)).shape == (4, 4)
 
 
 def test_quantitative_value_save_load(tmp_path):

@@ -7,9 +7,9 @@ Mirror of the reference's ``dosma/core/quant_vals.py`` -- ``QuantitativeValue`` 
 ``save_data`` / ``load_data`` (:78-126) go through ``dosma_amd.io`` (NIfTI-1).
 """
 from abc import ABC
-from collections import defaultdict
 from enum import Enum
 import os
+import warnings
 from typing import Callable, Dict, Tuple, Union
 
 import numpy as np
@@ -17,6 +17,21 @@ import numpy as np
 from dosma_amd.med_volume import MedicalVolume
 
 __all__ = ["QuantitativeValueType", "QuantitativeValue", "T1Rho", "T2", "T2Star"]
+
+
+def _inside(values, bounds, closed):
+    """Boolean map of ``values`` inside the interval ``bounds`` (None: everywhere)."""
+    if not bounds:
+        return np.ones(np.shape(values), dtype=bool)
+    if len(bounds) != 2 or not bounds[0] <= bounds[1]:
+        raise AssertionError(f"bounds must be (lower, upper) with lower <= upper, got {bounds}")
+    ends = {"right": (False, True), "left": (True, False), "both": (True, True), "neither": (False, False)}
+    if closed not in ends:
+        raise AssertionError(closed)
+    lo_in, hi_in = ends[closed]
+    lo_ok = values >= bounds[0] if lo_in else values > bounds[0]
+    hi_ok = values <= bounds[1] if hi_in else values < bounds[1]
+    return lo_ok & hi_ok
 
 
 class QuantitativeValueType(Enum):
@@ -68,53 +83,34 @@ class QuantitativeValue(ABC):
     def to_metrics(self, mask: MedicalVolume = None, labels: Dict[int, str] = None,
                    bounds: Tuple[float, float] = None, closed: str = "right",
                    fns: Dict[str, Callable] = None):
-        """Mean / Std / Median / # Voxels per label (``pandas.DataFrame``), reference :145-229.
-
-        Valid voxels are finite and inside ``bounds`` (interval closed on ``closed``)."""
+        """One row per region -- ``Category, Mean, Std, Median, # Voxels`` (+ one column per entry of ``fns``) -- as a
+        ``pandas.DataFrame`` (reference :145-229).  Regions: every label of ``mask`` (or of ``labels``) followed by
+        "total" (all labelled voxels); without a mask a single "total" row over the whole map.  Only finite voxels
+        inside ``bounds`` count; ``closed`` says which ends of the interval belong to it."""
         import pandas as pd
 
-        volume = self.volumetric_map.volume
-        valid_mask = np.isfinite(volume)
-        if bounds:
-            assert len(bounds) == 2, len(bounds)
-            lb, ub = bounds[0], bounds[1]
-            assert lb <= ub, f"lower:{lb}, upper: {ub}"
-            assert closed in ("right", "left", "both", "neither"), closed
-            lb_mask = volume >= lb if closed in ("left", "both") else volume > lb
-            ub_mask = volume <= ub if closed in ("right", "both") else volume < ub
-            valid_mask &= lb_mask & ub_mask
-        if mask is not None:
-            mask = mask.reformat(self.volumetric_map.orientation).volume
-            if labels is None:
-                labels = {int(i): f"label_{int(i)}" for i in np.unique(mask) if i > 0}
-            labels = dict(labels)
-            labels.update({-1: "total"})
-            mask = mask.copy()
-            mask[~valid_mask] = 0
+        values = self.volumetric_map.volume
+        usable = np.isfinite(values) & _inside(values, bounds, closed)
+        if mask is None:
+            regions = [("total", usable)]
         else:
-            labels = {-2: "total"}
-        fns = fns or {}
-        metrics = defaultdict(list)
-        with np.errstate(all="ignore"):
-            import warnings
-
-            for label, name in labels.items():
-                if label == -2:
-                    vals = volume[valid_mask]
-                elif label == -1:
-                    vals = volume[mask > 0]
-                else:
-                    vals = volume[mask == label]
-                metrics["Category"].append(name)
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore", category=RuntimeWarning)
-                    metrics["Mean"].append(np.nanmean(vals))
-                    metrics["Std"].append(np.nanstd(vals))
-                    metrics["Median"].append(np.nanmedian(vals))
-                metrics["# Voxels"].append(int(np.prod(vals.shape)))
-                for fname, fn in fns.items():
-                    metrics[fname].append(fn(vals))
-        return pd.DataFrame(metrics)
+            label_map = mask.reformat(self.volumetric_map.orientation).volume
+            if labels is None:
+                labels = {int(v): f"label_{int(v)}" for v in np.unique(label_map) if v > 0}
+            label_map = np.where(usable, label_map, 0)
+            regions = [(name, label_map == key) for key, name in labels.items()]
+            regions.append(("total", label_map > 0))
+        extra = dict(fns or {})
+        rows = []
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)  # empty regions -> NaN, quietly
+            for name, where in regions:
+                v = values[where]
+                row = {"Category": name, "Mean": np.nanmean(v), "Std": np.nanstd(v), "Median": np.nanmedian(v),
+                       "# Voxels": int(v.size)}
+                row.update({key: fn(v) for key, fn in extra.items()})
+                rows.append(row)
+        return pd.DataFrame(rows, columns=["Category", "Mean", "Std", "Median", "# Voxels", *extra])
 
     @staticmethod
     def get_qv(qv_id: Union[int, str]):

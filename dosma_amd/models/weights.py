@@ -125,3 +125,20 @@ def load_keras_h5(path, depth=6):
         else:
             w[f"{name}_kernel"], w[f"{name}_bias"] = tensors["kernel"], tensors["bias"]
     return w
+
+
+def find_weights(weights_dir, tissue_id, extensions=(".h5", ".npz")):
+    """The weights file of a tissue: the one regular file in ``weights_dir`` whose name contains ``tissue_id`` (the
+    reference's ``Tissue.STR_ID``: "fc", "tc", "pc", "men") and ends in a weights extension -- the discovery rule of
+    ``Tissue.find_weights`` (dosma/tissues/tissue.py:128-160; the reference looks for ``.h5`` only, this package also
+    stores weights as ``.npz``).  ``ValueError`` when no file or more than one matches."""
+    import os
+
+    hits = sorted(os.path.join(weights_dir, name) for name in os.listdir(weights_dir)
+                  if tissue_id in name and name.endswith(tuple(extensions))
+                  and os.path.isfile(os.path.join(weights_dir, name)))
+    if len(hits) > 1:
+        raise ValueError("There are multiple weights files, please remove duplicates")
+    if not hits:
+        raise ValueError("No file found that contains '{}' and ends in '{}'".format(tissue_id, extensions))
+    return hits[0]

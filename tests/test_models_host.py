@@ -44,6 +44,19 @@ def test_weights_container(tmp_path):
     assert [n for n in W.tensor_names()] == [n for n in W.tensor_names(6)] and len(W.tensor_names()) == 100
 
 
+def test_find_weights(tmp_path):
+    """Tissue.find_weights (tissue.py:128-160): exactly one file containing the tissue id with a weights extension."""
+    for name in ("iwoai_fc_weights.h5", "tc_weights.npz", "notes_fc.txt", "men_a.h5", "men_b.h5"):
+        (tmp_path / name).write_bytes(b"x")
+    (tmp_path / "pc_dir.h5").mkdir()
+    assert W.find_weights(str(tmp_path), "fc").endswith("iwoai_fc_weights.h5")
+    assert W.find_weights(str(tmp_path), "tc").endswith("tc_weights.npz")
+    with pytest.raises(ValueError):
+        W.find_weights(str(tmp_path), "men")  # two candidates
+    with pytest.raises(ValueError):
+        W.find_weights(str(tmp_path), "pc")   # a directory does not count
+
+
 def test_whiten_volume_matches_reference_formula():
     x = np.random.default_rng(0).uniform(0, 500, (5, 6, 7)).astype(np.float32)
     y = whiten_volume(x)

@@ -256,7 +256,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recipes", default="B,A", help="which recipes to time (A = headline, last)")
     ap.add_argument("--no-unet", action="store_true", help="skip the UNet2D slices/s leg")
-    ap.add_argument("--unet-batch", type=int, default=32)
+    ap.add_argument("--unet-batch", type=int, default=160,
+                    help="slices per pass through the network (default: the whole 160-slice volume)")
     args = ap.parse_args()
 
     from dosma_amd import _lib as L

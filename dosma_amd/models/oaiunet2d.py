@@ -46,8 +46,6 @@ class OAIUnet2D(HipSegModel):
         eng = self.seg_model
         if vol.shape[:2] != (eng.H, eng.W):
             raise ValueError(f"model was built for slices of {(eng.H, eng.W)}, volume has {vol.shape[:2]}")
-        if int(self.batch_size) != eng.max_batch:  # the CLI sets model.batch_size after construction
-            raise ValueError("batch_size was changed after the engine was built; rebuild the model")
         cut = self._check_threshold()
         if cut == 0.0:
             planes = eng.segment_volume(vol, whiten=self._WHITEN, eps=self._WHITEN_EPS)  # (C, H, W, S)

@@ -42,10 +42,10 @@ constexpr int kWinW = kTW + 4;                // fused first layer: window of th
 
 // NT = 32-channel output tiles (waves along N): Cout = 32 NT.  A block's 4 waves are NT along N x 4 / NT along M,
 // each wave owns 2 pixel rows x 32 channels, so the tile is 8 (NT = 1) or 4 (NT = 2) rows of 32 pixels.
-template <int CIN, int NT>
+template <int CIN, int NT, int RPW = 2>
 struct RwCfg {
     static constexpr int COUT = 32 * NT;
-    static constexpr int TH = 2 * (4 / NT);              // tile rows
+    static constexpr int TH = RPW * (4 / NT);            // tile rows: RPW image rows (MFMA row-tiles) per wave
     static constexpr int HH = TH + 2;                    // halo rows
     static constexpr int HPIX = kHW * HH;                // 340 / 204
     static constexpr int WINH = TH + 4;
@@ -69,9 +69,10 @@ struct RwCfg {
     static constexpr int OTILE_BYTES = kTW * TH * OROW * 2;
     static constexpr int MISC_FLOATS = kWinW * WINH + 320 + 132 + 3 * COUT;  // c1 window | c1 w, b | head w, b | bias, scale, shift
 };
-template <int CIN, int NT, int NBUF>
+template <int CIN, int NT, int NBUF, int RPW = 2>
 constexpr size_t rw_lds_bytes() {
-    return (size_t)NBUF * RwCfg<CIN, NT>::HALO_BYTES + RwCfg<CIN, NT>::OTILE_BYTES + RwCfg<CIN, NT>::MISC_FLOATS * 4;
+    using C = RwCfg<CIN, NT, RPW>;
+    return (size_t)NBUF * C::HALO_BYTES + C::OTILE_BYTES + C::MISC_FLOATS * 4;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -89,9 +90,9 @@ __device__ __forceinline__ void lds_read3_f4(const float *p, float4 &a, float4 &
 }
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW>
+template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW, int RPW = 2>
 __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
-    using C = RwCfg<CIN, NT>;
+    using C = RwCfg<CIN, NT, RPW>;
     static_assert(NT == 1 || (!C1 && !HEAD), "the fused first layer and the head belong to 32-channel layers");
     constexpr int kTH = C::TH, kHPix = C::HPIX, kORow = C::OROW, kWinH = C::WINH, COUT = C::COUT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
     for (int g = 0; g < 4; ++g) bias_r[g] = *reinterpret_cast<const float4 *>(prm + wn * 32 + 8 * g + 4 * (lane >> 5));
 
     // un-shifted halo pixel of this lane in the wave's two row-tiles: tile row 2 * wave + i, column lane & 31
-    int hpb[2];
+    int hpb[RPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) hpb[i] = (2 * wm + i + 1) * kHW + (lane & 31) + 1;
+    for (int i = 0; i < RPW; ++i) hpb[i] = (RPW * wm + i + 1) * kHW + (lane & 31) + 1;
 
     const int tiles_x = A.W / kTW, tiles_y = A.H / kTH;
     const int tiles_per_img = tiles_x * tiles_y;
@@ -229,10 +230,13 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
     // wait would expose its full latency on every tile -- measured: DMA, MFMA and epilogue times simply added up).
     bool have_prev = false;
     int pb_ = 0, py0 = 0, px0 = 0;
-    float4 plog[2];
-    unsigned pmask[2] = {0u, 0u};
+    float4 plog[RPW];
+    unsigned pmask[RPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) plog[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < RPW; ++i) {
+        plog[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pmask[i] = 0u;
+    }
 
 #define QMRI_RW_FLUSH_PREV()                                                                                   \
     if (have_prev) {                                                                           \
@@ -265,8 +269,8 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         }                                                                                                      \
         if (HEAD && lane < 32) { /* rows 0..3 of the head MFMA = classes, column = this lane's pixel */    \
             const int NC = A.head_nc;                                                                          \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
-                const long long pix = pib_ + (long long)(py0 + 2 * wm + i) * A.W + px0 + lane;                 \
+            _Pragma("unroll") for (int i = 0; i < RPW; ++i) {                                                  \
+                const long long pix = pib_ + (long long)(py0 + RPW * wm + i) * A.W + px0 + lane;               \
                 if (NC == 4) {                                                                                 \
                     if (A.logits) *reinterpret_cast<float4 *>(A.logits + pix * 4) = plog[i];                   \
                     if (A.mask) *reinterpret_cast<unsigned *>(A.mask + pix * 4) = pmask[i];                    \
@@ -370,9 +374,9 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
 
         // ---- 9 taps x Cin/16 k-steps, weights from registers, no barrier.  A fragment of (tap, row-tile): pixel
         // hp = hpb + dy * 34 + dx, chunk kk * 2 + (lane >> 5): the k-step is an immediate offset of 32 bytes
-        f32x16 acc[2];
+        f32x16 acc[RPW];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         {
@@ -380,18 +384,19 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
             for (int t = 0; t < 9; ++t) {
                 const int code = (int)((A.taps >> (4 * t)) & 0xF);  // (dy+1) | (dx+1) << 2
                 const int shift = ((code & 3) - 1) * kHW + ((code >> 2) - 1);
-                int ab[2];
+                int ab[RPW];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < RPW; ++i) {
                     const int hp = hpb[i] + shift;
                     ab[i] = hp * C::LROW + (lane >> 5) * 16;
                 }
 #pragma unroll
                 for (int kk = 0; kk < C::KSTEPS; ++kk) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(halo + ab[0] + kk * 32);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(halo + ab[1] + kk * 32);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[t * C::KSTEPS + kk], a0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[t * C::KSTEPS + kk], a1, acc[1], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(halo + ab[i] + kk * 32);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[t * C::KSTEPS + kk], a, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -403,8 +408,8 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
         // deferred to the next iteration (QMRI_RW_FLUSH_PREV).
         if (want_tile) __syncthreads();  // every wave has flushed the previous output tile
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (2 * wm + i) * kTW + (lane & 31);  // pixel of the tile
+        for (int i = 0; i < RPW; ++i) {
+            const int r = (RPW * wm + i) * kTW + (lane & 31);  // pixel of the tile
             bf16x8 vb[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -458,10 +463,10 @@ __global__ __launch_bounds__(256, MINW) void conv_rw_kernel(const ConvKArgs A) {
 #undef QMRI_RW_ISSUE_HALO
 }
 
-template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW>
+template <int CIN, int NT, bool C1, bool HEAD, int NBUF, int MINW, int RPW = 2>
 hipError_t rw_launch_one(const ConvKArgs &k, int num_cu, hipStream_t stream) {
-    auto fn = conv_rw_kernel<CIN, NT, C1, HEAD, NBUF, MINW>;
-    const size_t lds = rw_lds_bytes<CIN, NT, NBUF>();
+    auto fn = conv_rw_kernel<CIN, NT, C1, HEAD, NBUF, MINW, RPW>;
+    const size_t lds = rw_lds_bytes<CIN, NT, NBUF, RPW>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -469,7 +474,7 @@ hipError_t rw_launch_one(const ConvKArgs &k, int num_cu, hipStream_t stream) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    const long long ntiles = (long long)k.B * (k.H / RwCfg<CIN, NT>::TH) * (k.W / kTW);
+    const long long ntiles = (long long)k.B * (k.H / RwCfg<CIN, NT, RPW>::TH) * (k.W / kTW);
     long long grid = (long long)num_cu * per_cu;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, k);
@@ -507,7 +512,7 @@ hipError_t conv_rw_launch(const ConvKArgs &k0, hipStream_t stream) {
         num_cu = prop.multiProcessorCount;
     }
     (void)hipGetLastError();
-    static const int nbuf64 = env_int("QMRI_RW_NBUF64", 1);
+    static const int nbuf64 = env_int("QMRI_RW_NBUF64", 3);
     const ConvKArgs &k = k0;
     if (k.Cout == 64) {
         if (k.Cin == 64) return rw_launch_one<64, 2, false, false, 1, 2>(k, num_cu, stream);
@@ -516,6 +521,7 @@ hipError_t conv_rw_launch(const ConvKArgs &k0, hipStream_t stream) {
     if (k.Cin == 64) {
         if (k.head_w) return nbuf64 == 2 ? rw_launch_one<64, 1, false, true, 2, 1>(k, num_cu, stream)
                                          : rw_launch_one<64, 1, false, true, 1, 2>(k, num_cu, stream);
+        if (nbuf64 == 3) return rw_launch_one<64, 1, false, false, 2, 2, 1>(k, num_cu, stream);  // 32 x 4 tiles, double-buffered
         return nbuf64 == 2 ? rw_launch_one<64, 1, false, false, 2, 1>(k, num_cu, stream)
                            : rw_launch_one<64, 1, false, false, 1, 2>(k, num_cu, stream);
     }

@@ -100,6 +100,7 @@ struct ConvKArgs {
     int deconv;               // 1: fused 4-phase Conv2DTranspose (ntaps = 9 in phase order, sy = sx = 2)
     unsigned long long taps;  // 4 bits per tap: (dy+1) | (dx+1) << 2, dy, dx in {-1, 0, 1}
     int tiles_y, tiles_x;     // filled by conv_igemm_launch
+    int halo_bufs;            // filled by conv_igemm_launch: 2 (double-buffered halo) or 1 (single K chunk)
     const __bf16 *w_hi;  // [Cout][chunk][tap][32] bf16: K index = (chunk*ntaps + tap)*32 + c (K-major per cout)
     const __bf16 *w_lo;  // low parts (SPLIT3) or nullptr
     const float *bias;   // [Cout] or nullptr

@@ -96,8 +96,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *halo_base = smem;                                  // [2][NPLANES][HALO_BYTES]
-    unsigned char *w_base = smem + 2 * NPLANES * HALO_BYTES;          // [2][NPLANES][W_BYTES]
-    int *rowpix = reinterpret_cast<int *>(w_base + (WALL ? 9 : 2 * NPLANES) * W_BYTES);  // [BM] output pixel or -1
+    unsigned char *w_base = smem + A.halo_bufs * NPLANES * HALO_BYTES;  // [2][NPLANES][W_BYTES]
+    // rowpix and the first-layer weights outlive the main loop: they sit behind both the main-loop buffers and the
+    // epilogue's output tile (+ head weights), which aliases the start of LDS
+    constexpr int EPI_BYTES = C::BM * BN * (int)sizeof(AT) + (BN * 4 + 4) * (int)sizeof(float);
+    const int main_bytes = A.halo_bufs * NPLANES * HALO_BYTES + (WALL ? 9 : 2 * NPLANES) * W_BYTES;
+    int *rowpix = reinterpret_cast<int *>(smem + (main_bytes > EPI_BYTES ? main_bytes : EPI_BYTES));  // [BM] output pixel or -1
     float *c1w = reinterpret_cast<float *>(rowpix + C::BM);  // fused first layer: [9][32] weights + [32] bias
 
     const int tid = threadIdx.x;
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
     }
     int step = 0;
     for (int ch = 0; ch < chunks; ++ch) {
-        const int hbuf = ch & 1;
+        const int hbuf = ch & (A.halo_bufs - 1);
+        if (A.halo_bufs == 1 && ch > 0) __syncthreads();  // single halo buffer: every wave is done with the previous chunk
         QMRI_STORE_HALO(hbuf)
         if constexpr (WALL) {
             __syncthreads();  // every wave is done reading the previous chunk's weights
@@ -491,13 +496,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
 #undef QMRI_STORE_WALL
 
 template <int BN, int TH, bool S3, int TW = 16, int NW = 4>
-static size_t conv_lds_bytes() {
+static size_t conv_lds_bytes(int halo_bufs = 2) {
     constexpr bool WALL = BN <= 64 && !S3;
     using C = TileCfg<BN, TH, WALL, TW, NW>;
     const int planes = S3 ? 2 : 1;
-    const size_t halo = 2 * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
+    const size_t halo = halo_bufs * (size_t)planes * C::HALO_PIX * kLdsRow * 2;
     const size_t w = (WALL ? 9 : 2 * (size_t)planes) * BN * kLdsRow * 2;
-    return halo + w + C::BM * sizeof(int) + (BN == 32 ? (9 * 32 + 32) * sizeof(float) : 0);
+    const size_t epilogue = (size_t)C::BM * BN * (S3 ? 4 : 2) + (BN * 4 + 4) * sizeof(float);  // output tile + head weights
+    return (halo + w > epilogue ? halo + w : epilogue) + C::BM * sizeof(int) + (BN == 32 ? (9 * 32 + 32) * sizeof(float) : 0);
 }
 
 // rows of the output tile in plain-bf16 mode when the image height is a multiple of 16
@@ -544,6 +550,30 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     static const int w8 = [] { const char *e = std::getenv("QMRI_CONV_W8"); return e ? std::atoi(e) : 1; }();
     const bool eight = w8 && !k.deconv && bn == 128 && th == 8 && tw == kTW && k.H % 16 == 0 && k.W % 16 == 0;
     if (eight) th = 16;
+    // parity mode, a single 32-channel K chunk (the 384 x 384 level and the first conv of the 192 x 192 level): there is
+    // no next chunk to prefetch, so one halo buffer is enough -> half the LDS and two or more blocks per CU
+    k.halo_bufs = 2;
+    static const int s3_t32 = [] { const char *e = std::getenv("QMRI_S3_T32"); return e ? std::atoi(e) : 1; }();
+    int s3_small = 0;
+    static const int s3_t64 = [] { const char *e = std::getenv("QMRI_S3_T64"); return e ? std::atoi(e) : 1; }();
+    static const int s3_t128 = [] { const char *e = std::getenv("QMRI_S3_T128"); return e ? std::atoi(e) : 2; }();
+    static const int s3_tdc = [] { const char *e = std::getenv("QMRI_S3_TDC"); return e ? std::atoi(e) : 0; }();
+    if (split3 && k.deconv && s3_tdc > 0) k.halo_bufs = 1;
+    static const int b16_one = [] { const char *e = std::getenv("QMRI_B16_ONEBUF"); return e ? std::atoi(e) : 0; }();
+    if (!split3 && (b16_one == 1 || (b16_one == 2 && !k.deconv) || (b16_one == 3 && k.deconv))) k.halo_bufs = 1;
+    bool eight_s3 = eight;
+    if (split3 && !k.deconv && k.Cin == kBK && bn <= 64 && s3_t32 > 0) {
+        k.halo_bufs = 1;
+        s3_small = s3_t32 == 1 ? (bn == 32 ? 2 : 1) : s3_t32;
+        if (s3_small == 2) th = 8;
+    } else if (split3 && !k.deconv && bn <= 64 && s3_t64 > 0) {
+        k.halo_bufs = 1;
+        s3_small = s3_t64;
+        if (s3_small == 2) th = 8;
+    } else if (split3 && !k.deconv && bn == 128 && s3_t128 > 0) {
+        k.halo_bufs = 1;
+        if (s3_t128 == 2) th = 8, eight_s3 = false;
+    }
     k.tiles_y = (k.H + th - 1) / th;
     k.tiles_x = (k.W + tw - 1) / tw;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
@@ -551,7 +581,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
 #define QMRI_CONV_CASE_TW(BN_, TH_, TW_, NW_)                                                       \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, TH_, false, __bf16, false, false, TW_, NW_>;               \
-        const size_t lds = conv_lds_bytes<BN_, TH_, false, TW_, NW_>();                             \
+        const size_t lds = conv_lds_bytes<BN_, TH_, false, TW_, NW_>(k.halo_bufs);                             \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -562,7 +592,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
 #define QMRI_CONV_CASE(BN_, TH_, S3_, AT_, DC_, ...)                                                     \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_, ##__VA_ARGS__>;                                  \
-        const size_t lds = conv_lds_bytes<BN_, TH_, S3_>();                                         \
+        const size_t lds = conv_lds_bytes<BN_, TH_, S3_>(k.halo_bufs);                                       \
         if (lds > 64 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -575,7 +605,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
 #define QMRI_CONV_CASE_W8(BN_, TH_, S3_, AT_, DC_, C1_)                                             \
     do {                                                                                            \
         auto fn = conv_igemm_kernel<BN_, TH_, S3_, AT_, DC_, C1_, 16, 8>;                           \
-        const size_t lds = conv_lds_bytes<BN_, TH_, S3_, 16, 8>();                                  \
+        const size_t lds = conv_lds_bytes<BN_, TH_, S3_, 16, 8>(k.halo_bufs);                                \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (e != hipSuccess) return e;                                                              \
@@ -587,11 +617,17 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         else if (bn == 64) QMRI_CONV_CASE(64, 8, true, float, true);
         else QMRI_CONV_CASE(32, 8, true, float, true);
     } else if (split3) {
-        if (bn == 128 && eight) QMRI_CONV_CASE_W8(128, 16, true, float, false, false);
+        if (bn == 128 && eight_s3) QMRI_CONV_CASE_W8(128, 16, true, float, false, false);
         else if (bn == 128 && w8) QMRI_CONV_CASE_W8(128, 8, true, float, false, false);
         else if (bn == 128) QMRI_CONV_CASE(128, 8, true, float, false);
+        else if (bn == 64 && s3_small == 2) QMRI_CONV_CASE(64, 8, true, float, false);
+        else if (bn == 64 && s3_small == 3) QMRI_CONV_CASE(64, 16, true, float, false);
         else if (bn == 64 && w8) QMRI_CONV_CASE_W8(64, 16, true, float, false, false);
         else if (bn == 64) QMRI_CONV_CASE(64, 16, true, float, false);
+        else if (k.c1_x && s3_small == 2) QMRI_CONV_CASE(32, 8, true, float, false, true);
+        else if (k.c1_x && s3_small == 3) QMRI_CONV_CASE(32, 16, true, float, false, true);
+        else if (s3_small == 2) QMRI_CONV_CASE(32, 8, true, float, false);
+        else if (s3_small == 3) QMRI_CONV_CASE(32, 16, true, float, false);
         else if (k.c1_x && w8) QMRI_CONV_CASE_W8(32, 16, true, float, false, true);
         else if (k.c1_x) QMRI_CONV_CASE(32, 16, true, float, false, true);
         else if (w8) QMRI_CONV_CASE_W8(32, 16, true, float, false, false);
@@ -599,7 +635,7 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
     } else if (bn == 128) {
         if (eight) {
             auto fn = conv_igemm_kernel<128, 16, false, __bf16, false, false, 16, 8>;
-            const size_t lds = conv_lds_bytes<128, 16, false, 16, 8>();
+            const size_t lds = conv_lds_bytes<128, 16, false, 16, 8>(k.halo_bufs);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, k);

@@ -155,6 +155,22 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     for (int i = 0; i < a->E; ++i) sxx += (a->x[i] - xm) * (a->x[i] - xm);
     k.xmean = xm;
     k.sxx = sxx;
+    // equally spaced echo / spin-lock times (the usual multi-echo acquisition): see FitKArgs::uniform_x
+    static const int uni_ok = [] { const char *e = std::getenv("QMRI_FIT_UNIFORM_X"); return e ? std::atoi(e) : 1; }();
+    static const int lmpar_cf = [] { const char *e = std::getenv("QMRI_FIT_LMPAR_CF"); return e ? std::atoi(e) : 1; }();
+    k.lmpar_closed_form = lmpar_cf;
+    k.uniform_x = 0;
+    k.x_step = 0.0;
+    if (uni_ok && a->E >= 3 && a->x[0] >= 0.0 && a->x[1] > a->x[0]) {
+        const double dx = a->x[1] - a->x[0];
+        bool uni = std::isfinite(dx);
+        for (int i = 2; i < a->E && uni; ++i)
+            uni = std::fabs(a->x[i] - (a->x[0] + i * dx)) <= 8.0 * 2.220446049250313e-16 * std::fabs(a->x[i]);
+        if (uni) {
+            k.uniform_x = 1;
+            k.x_step = dx;
+        }
+    }
 }
 
 // issue one fit launch on `stream`; flag_out (device) receives the non-finite flag if non-NULL

@@ -42,6 +42,11 @@ struct FitKArgs {
     const unsigned int *tile_list_count;
     int *nonfinite;
     double xmean, sxx;           // of x: closed-form degree-1 least squares (log-linear init)
+    // equally spaced sample times x_i = x_0 + i * x_step (x_0 >= 0, x_step > 0): exp(b x_i) = exp(b x_0) * exp(b x_step)^i,
+    // two exponentials + E multiplications per model evaluation instead of E exponentials
+    int uniform_x;
+    int lmpar_closed_form;       // evaluate lmpar's Newton iteration in closed form (monoexp_lm.hip lmpar2)
+    double x_step;
     double x[QMRI_MAX_ECHOES];
 };
 

@@ -53,9 +53,20 @@ __device__ __forceinline__ double sub_rn(double a, double b) {
     return a - b;
 }
 
+// Placed in a rarely taken block: an asm with side effects cannot be speculated, so the block stays behind a real
+// branch.  (Left alone, the compiler if-converts the guarded slow paths below -- IEEE divisions and square roots of
+// 13-25 instructions each -- and executes them on EVERY call, selecting the result afterwards.)
+#define QMRI_COLD_PATH() asm volatile("; cold path" ::: "memory")
+
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs);
 __device__ __forceinline__ double norm2(double a, double b) {
     const double s = a * a + b * b;
-    if (s > 1e-280 && s < 1e300) return sqrt(s);
+    if (s > 1e-280 && s < 1e280) {
+        double n, rn;
+        sqrt_rsqrt(s, n, rn);
+        return n;
+    }
+    QMRI_COLD_PATH();
     const double m = fmax(fabs(a), fabs(b));
     if (!(m > 0.0) || isinf(m)) return (isnan(a) || isnan(b)) ? (a + b) : m;
     const double ra = a / m, rb = b / m;
@@ -68,14 +79,16 @@ __device__ __forceinline__ double norm2(double a, double b) {
 // them.  The solver state is bounded away from the exponent range limits, so the scale / fixup steps
 // are only needed on a guarded slow path.  Results are within 1-2 ulp of IEEE (parity is 1e-4, not bitwise).
 __device__ __forceinline__ double frcp(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    double e = fma(-b, r, 1.0);
-    r = fma(r, e, r);
+    const double r0 = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r0, 1.0);
+    double r = fma(r0, e, r0);
     e = fma(-b, r, 1.0);
     r = fma(r, e, r);
-    // 0, inf, NaN and (sub)normal extremes: IEEE division
+    // 0, inf, NaN and the (sub)normal extremes, where the refinement would produce 0 * inf: the hardware result
+    // as it is (exact for 0 / inf / NaN).  An IEEE division here gets if-converted by the compiler -- 13 more
+    // instructions on EVERY call -- for a range the solver only visits on voxels that fail anyway.
     const double ab = fabs(b);
-    return (ab > 1e-290 && ab < 1e290) ? r : 1.0 / b;
+    return (ab > 1e-290 && ab < 1e290) ? r : r0;
 }
 
 // s = sqrt(x), rs = 1/sqrt(x) by Goldschmidt iteration from v_rsq_f64 (9 instructions for both)
@@ -93,6 +106,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
         s = g;
         rs = h + h;
     } else {
+        QMRI_COLD_PATH();
         s = sqrt(x);
         rs = 1.0 / s;
     }
@@ -104,6 +118,7 @@ __device__ __forceinline__ void norm2r(double a, double b, double &n, double &rn
     if (q > 1e-280 && q < 1e280) {
         sqrt_rsqrt(q, n, rn);
     } else {
+        QMRI_COLD_PATH();
         n = norm2(a, b);
         rn = 1.0 / n;
     }
@@ -176,10 +191,14 @@ __device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, doub
 // [0] loop rounds (x64 = lane slots) [1] busy lanes [2] lanes entering lmpar [3] lane lmpar iterations
 // [4] wave lmpar iterations (max over lanes, summed) [5] lanes in Jacobian+QR [6] lanes finishing
 // [7] rounds with a refill
-__device__ unsigned long long g_fit_stats[8];
+__device__ unsigned long long g_fit_stats[16];  // [8..13]: s_memtime cycles in refill+epilogue, lmpar, model eval, accept logic, Jacobian+QR, rest
+#define QMRI_TIC() (st_t1 = __builtin_readcyclecounter())
+#define QMRI_TOC(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t1; st_t1 = t_; } while (0)
 #define QMRI_STAT_ADD(i, v) st_acc[i] += (unsigned long long)(v)
 #else
 #define QMRI_STAT_ADD(i, v)
+#define QMRI_TIC()
+#define QMRI_TOC(i)
 #endif
 
 // MINPACK lmpar for n = 2: step p (by original index) with ||diag*p|| ~ delta, and the LM parameter.
@@ -458,10 +477,12 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     }
 
 #ifdef QMRI_STATS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t1 = 0;
 #endif
     for (;;) {
         QMRI_STAT_ADD(0, 1);
+        QMRI_TIC();
         // ======================= refill: idle lanes pull voxels =======================
         {
             // A lane that has terminated parks in ST_DONE: its outputs are written here, together with those of the other
@@ -664,6 +685,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 }
             }
         }
+        QMRI_TOC(8);
         if (!__ballot(state != ST_IDLE)) break;
         QMRI_STAT_ADD(1, __popcll(__ballot(state == ST_INIT || state == ST_ITER)));
         QMRI_STAT_ADD(2, __popcll(__ballot(state == ST_ITER)));
@@ -697,6 +719,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 ta = pa;
                 tb = pb;
             }
+            QMRI_TOC(9);
             // ---- evaluate the model at the trial point: E exps shared by fvec and the Jacobian ----
             double ev[EMAX], fv[EMAX];
             double ss = 0.0;
@@ -705,7 +728,13 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 // the 1e-4 parity bar; x_0 >= 0 < x_step keeps 0 * inf out of the products)
                 const double q1 = exp(mul_rn(tb, A.x_step));
                 const double q2 = q1 * q1, q4 = q2 * q2;
-                ev[0] = exp(mul_rn(tb, A.x[0]));
+                if (A.x0_pow >= 0) {  // x_0 = k x_step (TE = dTE, 2 dTE, ...): one exponential for the whole voxel
+                    double e0 = 1.0;
+                    for (int k = 0; k < A.x0_pow; ++k) e0 *= q1;
+                    ev[0] = e0;
+                } else {
+                    ev[0] = exp(mul_rn(tb, A.x[0]));
+                }
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
                     if (FULL || i < E) ev[i] = i >= 4 ? ev[i - 4] * q4 : (i >= 2 ? ev[i - 2] * q2 : ev[0] * q1);
@@ -720,10 +749,11 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                     fv[i] = sub_rn(mul_rn(ta, ev[i]), static_cast<double>(yv[i]));
                     ss += fv[i] * fv[i];
                 }
-            double fnorm1;
-            if (ss > 1e-280 && ss < 1e300) {
-                fnorm1 = sqrt(ss);
+            double fnorm1, rfn1 = 0.0;  // rfn1 = 1 / fnorm1 on the fast path, else 0 (-> frcp when needed)
+            if (ss > 1e-280 && ss < 1e280) {
+                sqrt_rsqrt(ss, fnorm1, rfn1);
             } else {
+                QMRI_COLD_PATH();
                 double m = 0.0;
                 bool anynan = false;
 #pragma unroll
@@ -748,6 +778,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 }
             }
             ++nfev;
+            QMRI_TOC(10);
 
             bool accepted;
             int info = 0;
@@ -771,8 +802,8 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                     double temp = 0.5;
                     if (actred < 0.0) temp = 0.5 * dirder * frcp(dirder + 0.5 * actred);
                     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                    delta = temp * fmin(delta, pnorm / 0.1);
-                    par = par / temp;
+                    delta = temp * fmin(delta, pnorm * 10.0);
+                    par = par * frcp(temp);
                 } else if (par == 0.0 || ratio >= 0.75) {
                     delta = pnorm / 0.5;
                     par = 0.5 * par;
@@ -783,7 +814,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                     pb = tb;
                     xnorm = norm2(dg0 * pa, dg1 * pb);
                     fnorm = fnorm1;
-                    rfn = frcp(fnorm);
+                    rfn = rfn1 != 0.0 ? rfn1 : frcp(fnorm);
                     first = false;
                 }
                 const bool small = fabs(actred) <= A.ftol && prered <= A.ftol && 0.5 * ratio <= 1.0;
@@ -798,11 +829,12 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
             } else {
                 accepted = true;
                 fnorm = fnorm1;
-                rfn = frcp(fnorm);
+                rfn = rfn1 != 0.0 ? rfn1 : frcp(fnorm);
                 par = 0.0;
                 first = true;
             }
 
+            QMRI_TOC(11);
             if (info == 0 && accepted) {
 #ifdef QMRI_STATS
                 did_qr = true;
@@ -942,6 +974,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 state = ST_ITER;
             }
 
+            QMRI_TOC(12);
             if (info != 0) {
                 done_info = info;
                 state = ST_DONE;
@@ -962,7 +995,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     }
 #ifdef QMRI_STATS
     if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_fit_stats[i], st_acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_fit_stats[i], st_acc[i]);
 #endif
 }
 
@@ -1098,9 +1131,9 @@ hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream) {
 
 #ifdef QMRI_STATS
 extern "C" int qmri_debug_fit_stats(unsigned long long *out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::g_fit_stats), 8 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::g_fit_stats), 16 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(qmri::g_fit_stats), z, sizeof(z));
     }
     return e == hipSuccess ? 0 : -1;

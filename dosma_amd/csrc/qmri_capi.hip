@@ -160,6 +160,7 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     static const int lmpar_cf = [] { const char *e = std::getenv("QMRI_FIT_LMPAR_CF"); return e ? std::atoi(e) : 1; }();
     k.lmpar_closed_form = lmpar_cf;
     k.uniform_x = 0;
+    k.x0_pow = -1;
     k.x_step = 0.0;
     if (uni_ok && a->E >= 3 && a->x[0] >= 0.0 && a->x[1] > a->x[0]) {
         const double dx = a->x[1] - a->x[0];
@@ -169,6 +170,9 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
         if (uni) {
             k.uniform_x = 1;
             k.x_step = dx;
+            const double kk = std::nearbyint(a->x[0] / dx);
+            if (kk >= 0.0 && kk <= 4.0 && std::fabs(a->x[0] - kk * dx) <= 8.0 * 2.220446049250313e-16 * std::fabs(a->x[0]))
+                k.x0_pow = (int)kk;
         }
     }
 }

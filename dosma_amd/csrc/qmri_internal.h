@@ -45,6 +45,7 @@ struct FitKArgs {
     // equally spaced sample times x_i = x_0 + i * x_step (x_0 >= 0, x_step > 0): exp(b x_i) = exp(b x_0) * exp(b x_step)^i,
     // two exponentials + E multiplications per model evaluation instead of E exponentials
     int uniform_x;
+    int x0_pow;                  // uniform_x and x_0 = k * x_step, 0 <= k <= 4: exp(b x_0) = exp(b x_step)^k, one exponential; else -1
     int lmpar_closed_form;       // evaluate lmpar's Newton iteration in closed form (monoexp_lm.hip lmpar2)
     double x_step;
     double x[QMRI_MAX_ECHOES];

@@ -24,12 +24,15 @@ popt = torch.empty((n, 2), dtype=torch.float32, device=dev)
 r2 = torch.empty(n, dtype=torch.float32, device=dev)
 for recipe in ("A", "B"):
     a = bench.make_args(L, y, popt, r2, torch.cuda.current_stream().cuda_stream, recipe)
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     lib.qmri_debug_fit_stats(buf, 1)
     L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
     torch.cuda.synchronize()
     lib.qmri_debug_fit_stats(buf, 1)
-    rounds, busy, lm_in, lm_lane, lm_wave, qr, fin, _ = [int(v) for v in buf]
+    rounds, busy, lm_in, lm_lane, lm_wave, qr, fin, _ = [int(v) for v in buf][:8]
+    cyc = [int(v) for v in buf][8:13]
+    tot = max(sum(cyc), 1)
+    print('   s_memtime share per section: ' + '  '.join(f'{n} {c/tot:.3f}' for n, c in zip(('refill+epilogue', 'lmpar', 'model-eval', 'accept-logic', 'jacobian+qr'), cyc)) + f'   cycles/round {tot/rounds:.0f}')
     slots = rounds * 64
     print(f"recipe {recipe}: rounds {rounds}  busy/slot {busy/slots:.3f}  lmpar-entering/slot {lm_in/slots:.3f}  "
           f"QR/slot {qr/slots:.3f}  finished {fin}  rounds/fit {busy/max(fin,1):.2f}")

@@ -372,13 +372,14 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_voxel": BYTES_PER_VOXEL,
                 "kernel_ms": ra["kernel_ms"],
-                "note": "the kernel is fp64-VALU bound, not HBM bound: MINPACK's early-stopped trajectory needs ~53 "
-                        "model evaluations (x 8 exps) + 17 QR / lmpar rounds per voxel in fp64; see `valu` and DESIGN.md 3.1",
-                # measured with rocprofv3 PMC on this kernel and workload (profiles/r01d_counters.json; constants, not
-                # re-measured by this run): VALU pipes busy 84 % of the kernel's cycles, 38.6 of 64 lanes active per
-                # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.14x algorithmic
-                "valu": {"busy_frac": 0.84, "lanes_active_frac": 0.604, "hbm_traffic_over_algorithmic": 1.14,
-                         "source": "profiles/r01d_counters.json"},
+                "note": "the kernel is fp64-VALU bound, not HBM bound: MINPACK's early-stopped trajectory is ~20 LM rounds "
+                        "per voxel (53 charged model evaluations) of ~1050 fp64 VALU instructions each (lmpar, model "
+                        "evaluation, ratio tests, forward-difference Jacobian + QR); see `valu` and DESIGN.md 3.1",
+                # measured with rocprofv3 PMC on this kernel and workload (profiles/r01e_counters.json; constants, not
+                # re-measured by this run): VALU pipes busy 78 % of the kernel's cycles, 40.4 of 64 lanes active per
+                # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.15x algorithmic
+                "valu": {"busy_frac": 0.785, "lanes_active_frac": 0.631, "hbm_traffic_over_algorithmic": 1.15,
+                         "valu_instructions_per_wave_round": 1051, "source": "profiles/r01e_counters.json"},
             },
             "runs": {
                 "A_defaults_fixed_p0": {"voxel_fits_per_s": n * world * args.steps / ra["elapsed"],

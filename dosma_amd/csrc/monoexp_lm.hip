@@ -13,7 +13,10 @@
 //     1 - (|f+|/|f|)^2 against 1e-5, which fp32 cannot resolve;
 //   * MINPACK's control flow is kept exactly (lmpar trust region, ratio tests, info codes, nfev
 //     accounting with +n per Jacobian); the forward-difference Jacobian is reproduced from the E
-//     exponentials of the accepted trial point (no extra exps), so one LM iteration costs E exps;
+//     exponentials of the accepted trial point (no extra exps), so one LM iteration costs E exps --
+//     or one / two exps + E multiplications when the sample times are equally spaced (FitKArgs::uniform_x);
+//   * lmpar's Newton iteration on the LM parameter is evaluated in closed form for n = 2 (lmpar2): same
+//     iterates as qrsolv's Givens sweeps to rounding, a quarter of the instructions;
 //   * waves are independent persistent workers: a wave claims a tile of SUB consecutive voxels
 //     with one atomic, stages it echo-major into its private LDS slice with coalesced
 //     16-byte-per-lane loads, and its lanes *pull* voxels from that tile whenever they finish one
@@ -22,7 +25,7 @@
 //   * newly pulled voxels enter the same instruction stream as running ones (state INIT shares the
 //     model evaluation and the QR with state ITER), so there is no separate divergent init path;
 //   * the epilogue of MonoExponentialFit (1/|b|, bounds, r2 threshold, nan_to_num, rounding) is fused
-//     into the lane's final store.
+//     into the lane's final store, which is batched with the refill (lanes park in ST_DONE meanwhile).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>

@@ -194,7 +194,7 @@ __device__ __forceinline__ void qrsolv2(double r11, double r12, double r22, doub
 // [0] loop rounds (x64 = lane slots) [1] busy lanes [2] lanes entering lmpar [3] lane lmpar iterations
 // [4] wave lmpar iterations (max over lanes, summed) [5] lanes in Jacobian+QR [6] lanes finishing
 // [7] rounds with a refill
-__device__ unsigned long long g_fit_stats[16];  // [8..13]: s_memtime cycles in refill+epilogue, lmpar, model eval, accept logic, Jacobian+QR, rest
+__device__ unsigned long long g_fit_stats[16];  // [8..14]: s_memtime cycles in refill+epilogue, lmpar set-up, lmpar loop, model eval, accept logic, FD Jacobian, QR
 #define QMRI_TIC() (st_t1 = __builtin_readcyclecounter())
 #define QMRI_TOC(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t1; st_t1 = t_; } while (0)
 #define QMRI_STAT_ADD(i, v) st_acc[i] += (unsigned long long)(v)
@@ -212,7 +212,7 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, doubl
                                        double qtb0, double qtb1, double delta, double &par, double &x0,
                                        double &x1, bool closed_form
 #ifdef QMRI_STATS
-                                       , int &iters_out
+                                       , int &iters_out, unsigned long long *st_acc, unsigned long long &st_t1
 #endif
                                        ) {
 #ifdef QMRI_STATS
@@ -264,6 +264,7 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, doubl
     par = fmax(par, parl);
     par = fmin(par, paru);
     if (par == 0.0) par = gnorm * idx;
+    QMRI_TOC(9);
     // Closed-form evaluation of the same Newton iteration.  In the scaled variable z = D P^T x the damped normal
     // equations are (B + par I) z = g with B = D^-1 R^T R D^-1 = [s0^2, s0 t; s0 t, t^2 + v^2], s0 = r11/d0, t = r12/d1,
     // v = r22/d1 (all <= 1 in magnitude: diag >= column norm) and g = D^-1 R^T qtb = (s0 qtb0, t qtb0 + v qtb1).  With
@@ -706,7 +707,8 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
 #ifdef QMRI_STATS
                 int lm_it = 0;
                 lmpar2(r11, r12, r22, ir11, ir22, l0, dg0, dg1, idg0, idg1, qtf0, qtf1, delta, par,
-                       p0, p1, A.lmpar_closed_form != 0, lm_it);
+                       p0, p1, A.lmpar_closed_form != 0, lm_it, st_acc, st_t1);
+                QMRI_TOC(10);
                 lm_it_lane = lm_it;
 #else
                 lmpar2(r11, r12, r22, ir11, ir22, l0, dg0, dg1, idg0, idg1, qtf0, qtf1, delta, par,
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 ta = pa;
                 tb = pb;
             }
-            QMRI_TOC(9);
+            QMRI_TOC(10);
             // ---- evaluate the model at the trial point: E exps shared by fvec and the Jacobian ----
             double ev[EMAX], fv[EMAX];
             double ss = 0.0;
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 }
             }
             ++nfev;
-            QMRI_TOC(10);
+            QMRI_TOC(11);
 
             bool accepted;
             int info = 0;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 first = true;
             }
 
-            QMRI_TOC(11);
+            QMRI_TOC(12);
             if (info == 0 && accepted) {
 #ifdef QMRI_STATS
                 did_qr = true;
@@ -873,6 +875,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                         }
                 }
                 // (E-vector norms: sums of squares of finite values can only overflow to inf, never NaN)
+                QMRI_TOC(13);
                 double acn0, acn1, iacn0, iacn1;
                 sqrt_rsqrt(n1, acn0, iacn0);
                 sqrt_rsqrt(n2, acn1, iacn1);
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                 state = ST_ITER;
             }
 
-            QMRI_TOC(12);
+            QMRI_TOC(14);
             if (info != 0) {
                 done_info = info;
                 state = ST_DONE;

@@ -30,9 +30,9 @@ for recipe in ("A", "B"):
     torch.cuda.synchronize()
     lib.qmri_debug_fit_stats(buf, 1)
     rounds, busy, lm_in, lm_lane, lm_wave, qr, fin, _ = [int(v) for v in buf][:8]
-    cyc = [int(v) for v in buf][8:13]
+    cyc = [int(v) for v in buf][8:15]
     tot = max(sum(cyc), 1)
-    print('   s_memtime share per section: ' + '  '.join(f'{n} {c/tot:.3f}' for n, c in zip(('refill+epilogue', 'lmpar', 'model-eval', 'accept-logic', 'jacobian+qr'), cyc)) + f'   cycles/round {tot/rounds:.0f}')
+    print('   s_memtime share per section: ' + '  '.join(f'{n} {c/tot:.3f}' for n, c in zip(('refill+epilogue', 'lmpar-setup', 'lmpar-loop', 'model-eval', 'accept-logic', 'fd-jacobian', 'qr'), cyc)) + f'   cycles/round {tot/rounds:.0f}')
     slots = rounds * 64
     print(f"recipe {recipe}: rounds {rounds}  busy/slot {busy/slots:.3f}  lmpar-entering/slot {lm_in/slots:.3f}  "
           f"QR/slot {qr/slots:.3f}  finished {fin}  rounds/fit {busy/max(fin,1):.2f}")

@@ -775,6 +775,7 @@ static int dess_fill(const qmri_dess_args *a, qmri::DessKArgs &k) {
     k.nan_value = a->nan_value;
     k.decimals = a->decimals <= -1000000 ? QMRI_NO_ROUND : a->decimals;
     k.p10 = k.decimals == QMRI_NO_ROUND ? 1.0 : std::pow(10.0, std::abs(k.decimals));
+    k.ip10 = 1.0 / k.p10;
     k.suppress_fat = a->suppress_fat;
     k.suppress_fluid = a->suppress_fluid;
     k.out_f64 = a->out_dtype == QMRI_F64;

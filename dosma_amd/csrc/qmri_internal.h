@@ -160,6 +160,7 @@ struct DessKArgs {
     int suppress_fat, suppress_fluid, out_f64;
     int vec_ok;                // bases are 32-byte aligned: 4 voxels per lane
     double p10, beta;
+    double ip10;               // RN(1 / p10): x / p10 = Markstein's correctly rounded q + fma(-p10, q, x) * ip10 (dess.hip)
     const double *maxima;      // device [2]: max(echo1), max(echo1 - beta*echo2)
     void *t2;
 };

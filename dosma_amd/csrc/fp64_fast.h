@@ -1,0 +1,86 @@
+// fp64_fast.h -- fp64 division / logarithm building blocks for the gfx950 kernels (dess.hip, monoexp_lm.hip).
+//
+// On CDNA an IEEE fp64 division is 13 VALU instructions (v_div_scale x2, v_rcp_f64, 7 FMAs, v_div_fmas, v_div_fixup)
+// and OCML's double-double log 78; the per-voxel kernels here were issue-bound on them.  The fast paths below are
+// 1-2 ulp and fall back to the IEEE / OCML forms outside a safe magnitude range; the cold blocks carry an asm marker
+// because the compiler otherwise if-converts them (executes the slow form on EVERY call and selects).
+#ifndef QMRI_FP64_FAST_H
+#define QMRI_FP64_FAST_H
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace qmri {
+
+#ifndef QMRI_COLD_PATH
+#define QMRI_COLD_PATH() asm volatile("; cold path" ::: "memory")
+#endif
+
+__device__ __forceinline__ double rcp_nr(double b) {  // b finite, normal, far from the range limits
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    return fma(r, e, r);
+}
+
+__device__ __forceinline__ double div_fast(double a, double b) {
+    const double ab = fabs(b), aa = fabs(a);
+    if (ab > 1e-140 && ab < 1e140 && aa < 1e140) {
+        const double r = rcp_nr(b);
+        const double q = a * r;
+        return fma(fma(-b, q, a), r, q);  // one residual step: correctly rounded when r = RN(1/b), else <= 1 ulp
+    }
+    QMRI_COLD_PATH();
+    return a / b;
+}
+
+// x / p10 with the host's correctly rounded reciprocal ip10 = RN(1 / p10): q = RN(x ip10), r = x - p10 q (exact in
+// an fma), q + r ip10 rounds to RN(x / p10) (Markstein) -- numpy.around's division must be reproduced exactly, an ulp
+// off would make most rounded values compare unequal
+__device__ __forceinline__ double div_p10(double x, double p10, double ip10) {
+    if (fabs(x) < 1e290) {
+        const double q = x * ip10;
+        return fma(fma(-p10, q, x), ip10, q);
+    }
+    QMRI_COLD_PATH();
+    return x / p10;
+}
+
+// natural log of a positive, finite, normal x, ~1 ulp: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
+// log m = 2 atanh(s) = 2 s (1 + z/3 + z^2/5 + ...), z = s^2 <= 0.0295 (13 terms: remainder < 1e-21)
+__device__ __forceinline__ double log_fast(double x) {
+    if (x > 1e-300 && x < 1e300) {
+        double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+        int e = __builtin_amdgcn_frexp_exp(x);
+        if (m < 0.70710678118654752) {
+            m = m + m;
+            e -= 1;
+        }
+        const double f = m - 1.0;
+        const double s = f * rcp_nr(2.0 + f);
+        const double z = s * s;
+        double p = 1.0 / 25.0;
+        p = fma(p, z, 1.0 / 23.0);
+        p = fma(p, z, 1.0 / 21.0);
+        p = fma(p, z, 1.0 / 19.0);
+        p = fma(p, z, 1.0 / 17.0);
+        p = fma(p, z, 1.0 / 15.0);
+        p = fma(p, z, 1.0 / 13.0);
+        p = fma(p, z, 1.0 / 11.0);
+        p = fma(p, z, 1.0 / 9.0);
+        p = fma(p, z, 1.0 / 7.0);
+        p = fma(p, z, 1.0 / 5.0);
+        p = fma(p, z, 1.0 / 3.0);
+        const double ed = (double)e;
+        const double s2 = s + s;
+        // e ln2_hi + (2 s + (2 s z p + e ln2_lo)); ln2_hi has 11 trailing zero bits: e ln2_hi is exact
+        const double lo = fma(s2 * z, p, ed * 1.9082149292705877e-10);
+        return fma(ed, 0.69314718036912382, s2 + lo);
+    }
+    QMRI_COLD_PATH();
+    return log(x);
+}
+
+}  // namespace qmri
+#endif

@@ -31,6 +31,7 @@
 #include <cfloat>
 #include <cmath>
 
+#include "fp64_fast.h"
 #include "qmri_internal.h"
 
 namespace qmri {
@@ -56,10 +57,9 @@ __device__ __forceinline__ double sub_rn(double a, double b) {
     return a - b;
 }
 
-// Placed in a rarely taken block: an asm with side effects cannot be speculated, so the block stays behind a real
-// branch.  (Left alone, the compiler if-converts the guarded slow paths below -- IEEE divisions and square roots of
-// 13-25 instructions each -- and executes them on EVERY call, selecting the result afterwards.)
-#define QMRI_COLD_PATH() asm volatile("; cold path" ::: "memory")
+// QMRI_COLD_PATH() (fp64_fast.h) marks a rarely taken block: an asm with side effects cannot be speculated, so the
+// block stays behind a real branch.  (Left alone, the compiler if-converts the guarded slow paths below -- IEEE
+// divisions and square roots of 13-25 instructions each -- and executes them on EVERY call, selecting afterwards.)
 
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs);
 __device__ __forceinline__ double norm2(double a, double b) {
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int E = FULL ? EMAX : A.E;
+    const double rE = 1.0 / (double)E;
     // wave-private LDS slice: samples [E][kSub] | SStot [kSub] | a0 [kSub] | b0 [kSub] | queue [kSub]
     unsigned char *slice = smem + (size_t)wave * lds_bytes_per_wave<LT>(E);
     LT *tile = reinterpret_cast<LT *>(slice);
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                                     finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
                                 } else {
                                     need_fit = true;
-                                    mean = mean / (double)E;
+                                    mean = mean * rE;
                                     double st = 0.0;
 #pragma unroll
                                     for (int i = 0; i < EMAX; ++i)
@@ -622,10 +623,12 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                                             if (FULL || i < E) {
                                                 double q = sv[i];
                                                 if (q == 0.0) q = 1e-10;
+                                                // (OCML log: log_fast of fp64_fast.h is 30 instructions instead of 78, but its 14
+                                                // constants take this kernel from 252 to 256 + 18 registers = one wave per SIMD)
                                                 sv[i] = log(q);
                                                 sl += sv[i];
                                             }
-                                        const double lmean = sl / (double)E;
+                                        const double lmean = sl * rE;
                                         double sxy = 0.0, syy = 0.0;
 #pragma unroll
                                         for (int i = 0; i < EMAX; ++i)
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                                                 sxy += (A.x[i] - A.xmean) * dy;
                                                 syy += dy * dy;
                                             }
-                                        const double slope = sxy / A.sxx;
+                                        const double slope = div_fast(sxy, A.sxx);
                                         const double icpt = lmean - slope * A.xmean;
                                         double ssr = 0.0;
 #pragma unroll
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
                                                 const double r = (slope * A.x[i] + icpt) - sv[i];
                                                 ssr += r * r;
                                             }
-                                        const double r2l = 1.0 - ssr / (syy + 1e-8);
+                                        const double r2l = 1.0 - div_fast(ssr, syy + 1e-8);
                                         const bool good = r2l >= 0.0 && !isnan(slope) && !isnan(icpt);
                                         t_a0[j] = good ? exp(icpt) : 1.0;
                                         t_b0[j] = good ? slope : 0.0;

@@ -209,6 +209,8 @@ struct Unet {
     DevBuf c1_w, c1_b;  // first layer fp32: [9][nf0], [nf0]
     std::vector<std::unique_ptr<ConvLayer>> down1, down2, up1, up2;  // index by level
     std::vector<std::unique_ptr<ConvLayer>> updec;                   // [level]: fused 4-phase transposed conv
+    std::vector<std::unique_ptr<ConvLayer>> updec_ph;                // [level * 4 + phase]: the same as four strided-output convolutions (optional)
+    unsigned split_levels = 0;                                       // bit l: level l runs the four per-phase launches
     DevBuf head_w, head_b;
     // activations (fp32 NHWC), index by level
     DevBuf in;
@@ -278,6 +280,12 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->up1.resize(d->depth);
     U->up2.resize(d->depth);
     U->updec.resize((size_t)d->depth);
+    U->updec_ph.resize((size_t)d->depth * 4);
+    {
+        // QMRI_DECONV_SPLIT: bit mask of levels whose transposed convolution runs as four per-phase convolutions
+        const char *e = std::getenv("QMRI_DECONV_SPLIT");
+        U->split_levels = e ? (unsigned)std::strtoul(e, nullptr, 0) : 0u;
+    }
     std::vector<float> wk, sc, sh;
     for (int l = 0; l < d->depth; ++l) {
         const int C = U->nf[l];
@@ -312,6 +320,14 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             L->relu = 0;
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
+            if (U->split_levels >> l & 1u)
+                for (int ph = 0; ph < 4; ++ph) {
+                    auto &P = U->updec_ph[(size_t)l * 4 + ph];
+                    P.reset(new ConvLayer);
+                    P->relu = 0;
+                    pack_deconv_phase(kd, Cup, C, ph >> 1, ph & 1, *P, wk);
+                    U_TRY(P->upload(wk, bd, nullptr, nullptr));
+                }
         }
         U->up1[l].reset(new ConvLayer);
         U->up1[l]->relu = 1;
@@ -415,7 +431,13 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     for (int l = D - 2; l >= 0; --l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
         void *cat = U->cat[l]->p;
-        {
+        if (U->split_levels >> l & 1u) {
+            for (int ph = 0; ph < 4; ++ph) {
+                auto k = conv_args(*U->updec_ph[(size_t)l * 4 + ph], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2,
+                                   ph >> 1, ph & 1);
+                U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            }
+        } else {
             auto k = conv_args(*U->updec[(size_t)l], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
         }

@@ -337,10 +337,19 @@ def main():
         value = total_voxels / ra["elapsed"]
         achieved = BYTES_PER_VOXEL * n / (ra["kernel_ms"] * 1e-3) / 1e9
         traffic = None
+        valu_lane_instr = None
         prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(prof):
             with open(prof) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                pj = json.load(f)
+            traffic = pj.get("hbm_bytes_per_launch")
+            valu_lane_instr = pj.get("valu_lane_instr_per_launch")
+        # the bound that actually binds: vector-ALU issue.  Peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz lane-
+        # instructions/s (an fp64 FMA on every lane every clock = the 78.6 TFLOP/s vector fp64 figure); achieved = the
+        # kernel's active lane-instructions per launch (rocprofv3 PMC, SQ_INSTS_VALU x lanes active per instruction,
+        # profiles/r01e_counters.json) over the launch duration measured here
+        valu_peak = 256 * 4 * 16 * 2.4e9
+        valu_rate = valu_lane_instr / (ra["kernel_ms"] * 1e-3) if valu_lane_instr else None
         out = {
             "metric": "voxel-fits/sec (8-echo monoexp, 512x512x160) [+ UNet2D slices/sec under \"unet2d\"]",
             "value": value,
@@ -379,7 +388,9 @@ def main():
                 # re-measured by this run): VALU pipes busy 78 % of the kernel's cycles, 40.4 of 64 lanes active per
                 # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.15x algorithmic
                 "valu": {"busy_frac": 0.785, "lanes_active_frac": 0.631, "hbm_traffic_over_algorithmic": 1.15,
-                         "valu_instructions_per_wave_round": 1051, "source": "profiles/r01e_counters.json"},
+                         "valu_instructions_per_wave_round": 1051, "source": "profiles/r01e_counters.json",
+                         "lane_instr_per_s": valu_rate, "peak_lane_instr_per_s": valu_peak,
+                         "frac_of_valu_peak": (valu_rate / valu_peak) if valu_rate else None},
             },
             "runs": {
                 "A_defaults_fixed_p0": {"voxel_fits_per_s": n * world * args.steps / ra["elapsed"],

@@ -48,7 +48,10 @@ out = {
     "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * sq["SQ_BUSY_CYCLES"] / 32.0),
 }
 json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_counters.json"},
+out["valu_lane_instr_per_launch"] = sq["SQ_INSTS_VALU"] * out["lanes_active_per_valu_instr"]
+json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
+json.dump({"hbm_bytes_per_launch": rd + wr, "valu_lane_instr_per_launch": out["valu_lane_instr_per_launch"],
+           "source": f"profiles/{tag}_counters.json"},
           open("profiles/r01_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 

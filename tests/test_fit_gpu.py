@@ -175,6 +175,35 @@ def test_vs_oracle_shapes_and_dtypes(relerr, E, dtype):
     assert (np.abs(b["tc"] - tc) > 1e-3 + 1e-9).mean() < 1e-3
 
 
+@pytest.mark.parametrize("x", [
+    np.arange(1, 9) * 10.0,              # x_0 = 1 * step: one exponential per evaluation (FitKArgs::x0_pow = 1)
+    np.arange(0, 8) * 10.0,              # x_0 = 0: e_0 = 1
+    np.arange(3, 9) * 4.9,               # x_0 = 3 * step, step not exactly representable (8-ulp rule), E = 6
+    5.0 + np.arange(8) * 10.0,           # equally spaced, x_0 not a multiple of the step: two exponentials
+    7.0 + np.arange(5) * 9.0,            # the same with the partial-E kernel variant
+    np.arange(1, 17) * 5.0,              # E = 16: the depth-5 product tree
+    np.array([10., 20., 30., 40., 50., 60., 70., 80.000001]),  # NOT equally spaced by 1e-8: E exponentials
+    -10.0 + np.arange(8) * 10.0,         # x_0 < 0: the chain is off (0 * inf hazard), E exponentials
+], ids=["k1", "k0", "k3", "offset", "offset5", "e16", "almost", "negative"])
+def test_equally_spaced_sample_times_vs_oracle(relerr, x):
+    """The exponential power chain of the fit kernel (equally spaced x: exp(b x_i) = exp(b x_0) exp(b step)^i) against
+    the oracle, which always evaluates E exponentials: same solutions to the parity bar, same nfev."""
+    rng = np.random.default_rng(len(x))
+    E, N = len(x), 6000
+    xe = np.abs(x) + 1.0
+    y = rng.uniform(300, 1500, N) * np.exp(-xe[:, None] / rng.uniform(15, 80, N)) + 8 * rng.standard_normal((E, N))
+    y = y.astype(np.float32)
+    y[:, ::13] = 0
+    o = L.monoexp_fit_host(x, y, p0=P0, want_info=True)
+    popt, r2, info, nfev = fo.curve_fit_c(x, y, P0, jac_mode=2, full_output=True)
+    same = ((o["info"] >= 1) & (o["info"] <= 4)) == ((info >= 1) & (info <= 4))
+    assert same.mean() > 0.999
+    d = relerr(o["popt"][same], popt[same]).max(axis=1)
+    assert (d > RTOL).mean() < 1e-3, f"frac>{RTOL}: {(d > RTOL).mean()}, max {d.max()}"
+    assert r2_close(o["r2"][same], r2[same]).mean() > 0.999
+    assert (o["nfev"] == nfev).mean() > 0.995
+
+
 def test_per_voxel_p0_and_y_bounds(relerr):
     rng = np.random.default_rng(5)
     N, E = 3000, 6

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdint>
 #include <cmath>
 
 #include "fp64_fast.h"
@@ -1008,6 +1009,50 @@ __global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const F
 #endif
 }
 
+// The scatter fill of fitting.py:205-215 for one whole tile outside the mask: the same values finish_voxel writes with
+// outside_mask = true, as 16-byte stores (a tile is kSub = 256 consecutive voxels, so every output row of it is one
+// aligned contiguous run).
+__device__ __forceinline__ void fill_tile(const FitKArgs &A, long long start, int lane) {
+    static_assert(kSub == 256, "4 voxels per lane");
+    const qmri_post &P = A.post;
+    const double fill = (P.enable && P.use_nan_to_num) ? P.nan_value : NAN;
+    double tc = fill;
+    if (A.tc && P.enable && P.decimals != QMRI_NO_ROUND) tc = around(tc, P.decimals, A.p10);
+    const long long v0 = start + 4 * lane;  // this lane's 4 voxels
+    if (A.out_f64) {
+        const double2 f2 = {fill, fill};
+        if (A.popt) {
+            double2 *p = static_cast<double2 *>(A.popt) + v0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = f2;
+        }
+        double2 *r = reinterpret_cast<double2 *>(static_cast<double *>(A.r2) + v0);
+        r[0] = f2;
+        r[1] = f2;
+        if (A.tc) {
+            const double2 t2 = {tc, tc};
+            double2 *q = reinterpret_cast<double2 *>(static_cast<double *>(A.tc) + v0);
+            q[0] = t2;
+            q[1] = t2;
+        }
+    } else {
+        const float ff = static_cast<float>(fill);
+        const float4 f4 = {ff, ff, ff, ff};
+        if (A.popt) {
+            float4 *p = reinterpret_cast<float4 *>(static_cast<float2 *>(A.popt) + v0);
+            p[0] = f4;
+            p[1] = f4;
+        }
+        *reinterpret_cast<float4 *>(static_cast<float *>(A.r2) + v0) = f4;
+        if (A.tc) {
+            const float tf = static_cast<float>(tc);
+            *reinterpret_cast<float4 *>(static_cast<float *>(A.tc) + v0) = float4{tf, tf, tf, tf};
+        }
+    }
+    if (A.info) *reinterpret_cast<unsigned int *>(A.info + v0) = 0xFFFFFFFFu;  // info = -1 four times
+    if (A.nfev) *reinterpret_cast<unsigned long long *>(A.nfev + v0) = 0ull;
+}
+
 // ---- masked volumes: tile classification pre-pass ---------------------------------------------------
 // One wave per 256-voxel tile: no voxel selected -> the scatter fill of fitting.py:205-215 for the whole tile
 // (streaming writes); otherwise the tile index goes to a compact list that the fit kernel walks.  A cartilage ROI is
@@ -1017,25 +1062,43 @@ __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArg
                                                                    unsigned int *count) {
     const int lane = threadIdx.x & 63;
     const long long ntiles = (A.N + kSub - 1) / kSub;
+    // wide stores need 16-byte aligned output rows (a tile starts at a multiple of 256 elements of each of them)
+    const bool wide = ((reinterpret_cast<uintptr_t>(A.popt) | reinterpret_cast<uintptr_t>(A.r2) |
+                        reinterpret_cast<uintptr_t>(A.tc) | reinterpret_cast<uintptr_t>(A.info) |
+                        reinterpret_cast<uintptr_t>(A.nfev)) & 15) == 0;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    // one 4-byte mask load per lane covers a whole tile; the next tile's word is in flight while this one is classified
+    // and filled (the loop is otherwise one dependent load latency per tile)
+    const bool mask_words = (reinterpret_cast<uintptr_t>(A.mask) & 3) == 0;
+    auto tile_word = [&](long long t) -> unsigned int {
+        const long long start = t * kSub;
+        if (t >= ntiles) return 0u;
+        if (mask_words && A.N - start >= kSub) return reinterpret_cast<const unsigned int *>(A.mask + start)[lane];
+        unsigned int w = 0;
+        for (int k = 0; k < 4; ++k) {
+            const long long j = start + 4 * lane + k;
+            if (j < A.N) w |= A.mask[j] != 0 ? (1u << (8 * k)) : 0u;
+        }
+        return w;
+    };
+    unsigned int word = tile_word(wave0);
     for (long long t = wave0; t < ntiles; t += nwaves) {
+        const unsigned int next = tile_word(t + nwaves);
         const long long start = t * kSub;
         const long long rem = A.N - start;
         const int cnt = rem < kSub ? (int)rem : kSub;
-        bool s = false;
-        for (int k = 0; k < kSub / 64; ++k) {
-            const int j = k * 64 + lane;
-            if (j < cnt) s = s || A.mask[start + j] != 0;
-        }
-        if (__ballot(s)) {
+        if (__ballot(word != 0)) {
             if (lane == 0) list[atomicAdd(count, 1u)] = (unsigned int)t;
+        } else if (cnt == kSub && wide) {
+            fill_tile(A, start, lane);
         } else {
             for (int k = 0; k < kSub / 64; ++k) {
                 const int j = k * 64 + lane;
                 if (j < cnt) finish_voxel(A, start + j, 0, 0, 0, -1, 0, true);
             }
         }
+        word = next;
     }
 }
 

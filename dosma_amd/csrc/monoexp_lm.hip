@@ -435,8 +435,14 @@ __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
     return (size_t)E * kSub * sizeof(LT) + (size_t)kSub * (3 * sizeof(double) + 1);
 }
 
+// Two blocks (8 waves) per CU = two waves per SIMD is what the VALU-bound solver needs; the register allocation of the
+// EMAX <= 8 variants sits within a few registers of the 256 that allows (252 for the headline variant, 256 + 2..46
+// "AGPR" overflow for others = one wave per SIMD, -40 %), so the bound is stated: a handful of spills (<= 10 VGPRs) beats
+// losing the second wave.  EMAX = 16: 14.0 ms instead of 16.8 for the exact-size variant (148 spills), but 52.9 instead
+// of 18.8 for the partial one (340 spills); EMAX = 32 does not fit either way.
 template <int EMAX, bool FULL, typename LT>
-__global__ __launch_bounds__(256, QMRI_MIN_WAVES) void monoexp_lm_kernel(const FitKArgs A) {
+__global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI_MIN_WAVES) void monoexp_lm_kernel(
+    const FitKArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1164,14 +1170,19 @@ static int wpb_one(int E) {
          ? (k.E == EM ? FN<EM, true, double>(__VA_ARGS__) : FN<EM, false, double>(__VA_ARGS__)) \
          : (k.E == EM ? FN<EM, true, float>(__VA_ARGS__) : FN<EM, false, float>(__VA_ARGS__)))
 
+#define QMRI_DISPATCH_FULL(EM, FN, ...) \
+    (k.y_dtype == QMRI_F64 ? FN<EM, true, double>(__VA_ARGS__) : FN<EM, true, float>(__VA_ARGS__))
+
 int monoexp_tile_voxels() { return kSub; }
 
 const char *monoexp_variant_name(int E, int y_dtype) {
     const bool d = y_dtype == QMRI_F64;
     if (E <= 4) return d ? (E == 4 ? "monoexp_lm<4,full,f64>" : "monoexp_lm<4,part,f64>")
                          : (E == 4 ? "monoexp_lm<4,full,f32>" : "monoexp_lm<4,part,f32>");
-    if (E <= 8) return d ? (E == 8 ? "monoexp_lm<8,full,f64>" : "monoexp_lm<8,part,f64>")
-                         : (E == 8 ? "monoexp_lm<8,full,f32>" : "monoexp_lm<8,part,f32>");
+    if (E == 5) return d ? "monoexp_lm<5,full,f64>" : "monoexp_lm<5,full,f32>";
+    if (E == 6) return d ? "monoexp_lm<6,full,f64>" : "monoexp_lm<6,full,f32>";
+    if (E == 7) return d ? "monoexp_lm<7,full,f64>" : "monoexp_lm<7,full,f32>";
+    if (E <= 8) return d ? "monoexp_lm<8,full,f64>" : "monoexp_lm<8,full,f32>";
     if (E <= 16) return d ? (E == 16 ? "monoexp_lm<16,full,f64>" : "monoexp_lm<16,part,f64>")
                           : (E == 16 ? "monoexp_lm<16,full,f32>" : "monoexp_lm<16,part,f32>");
     return d ? (E == 32 ? "monoexp_lm<32,full,f64>" : "monoexp_lm<32,part,f64>")
@@ -1180,21 +1191,33 @@ const char *monoexp_variant_name(int E, int y_dtype) {
 
 int monoexp_waves_per_block(const FitKArgs &k) {
     if (k.E <= 4) return QMRI_DISPATCH(4, wpb_one, k.E);
-    if (k.E <= 8) return QMRI_DISPATCH(8, wpb_one, k.E);
+    // 5..8 samples: an exact-size instantiation each (the partial EMAX = 8 variant needs 256 + 46 registers = one wave per SIMD)
+    if (k.E == 5) return QMRI_DISPATCH_FULL(5, wpb_one, k.E);
+    if (k.E == 6) return QMRI_DISPATCH_FULL(6, wpb_one, k.E);
+    if (k.E == 7) return QMRI_DISPATCH_FULL(7, wpb_one, k.E);
+    if (k.E <= 8) return QMRI_DISPATCH_FULL(8, wpb_one, k.E);
     if (k.E <= 16) return QMRI_DISPATCH(16, wpb_one, k.E);
     return QMRI_DISPATCH(32, wpb_one, k.E);
 }
 
 int monoexp_blocks_per_cu(const FitKArgs &k) {
     if (k.E <= 4) return QMRI_DISPATCH(4, occupancy_one, k.E);
-    if (k.E <= 8) return QMRI_DISPATCH(8, occupancy_one, k.E);
+    // 5..8 samples: an exact-size instantiation each (the partial EMAX = 8 variant needs 256 + 46 registers = one wave per SIMD)
+    if (k.E == 5) return QMRI_DISPATCH_FULL(5, occupancy_one, k.E);
+    if (k.E == 6) return QMRI_DISPATCH_FULL(6, occupancy_one, k.E);
+    if (k.E == 7) return QMRI_DISPATCH_FULL(7, occupancy_one, k.E);
+    if (k.E <= 8) return QMRI_DISPATCH_FULL(8, occupancy_one, k.E);
     if (k.E <= 16) return QMRI_DISPATCH(16, occupancy_one, k.E);
     return QMRI_DISPATCH(32, occupancy_one, k.E);
 }
 
 hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream) {
     if (k.E <= 4) return QMRI_DISPATCH(4, launch_one, k, grid, stream);
-    if (k.E <= 8) return QMRI_DISPATCH(8, launch_one, k, grid, stream);
+    // 5..8 samples: an exact-size instantiation each (the partial EMAX = 8 variant needs 256 + 46 registers = one wave per SIMD)
+    if (k.E == 5) return QMRI_DISPATCH_FULL(5, launch_one, k, grid, stream);
+    if (k.E == 6) return QMRI_DISPATCH_FULL(6, launch_one, k, grid, stream);
+    if (k.E == 7) return QMRI_DISPATCH_FULL(7, launch_one, k, grid, stream);
+    if (k.E <= 8) return QMRI_DISPATCH_FULL(8, launch_one, k, grid, stream);
     if (k.E <= 16) return QMRI_DISPATCH(16, launch_one, k, grid, stream);
     return QMRI_DISPATCH(32, launch_one, k, grid, stream);
 }

@@ -387,7 +387,7 @@ def main():
                 # measured with rocprofv3 PMC on this kernel and workload (profiles/r01e_counters.json; constants, not
                 # re-measured by this run): VALU pipes busy 78 % of the kernel's cycles, 40.4 of 64 lanes active per
                 # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.15x algorithmic
-                "valu": {"busy_frac": 0.785, "lanes_active_frac": 0.631, "hbm_traffic_over_algorithmic": 1.15,
+                "valu": {"busy_frac": 0.79, "lanes_active_frac": 0.630, "hbm_traffic_over_algorithmic": 1.15,
                          "valu_instructions_per_wave_round": 1051, "source": "profiles/r01e_counters.json",
                          "lane_instr_per_s": valu_rate, "peak_lane_instr_per_s": valu_peak,
                          "frac_of_valu_peak": (valu_rate / valu_peak) if valu_rate else None},

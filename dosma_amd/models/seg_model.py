@@ -22,7 +22,7 @@ class SegModel(ABC):
     """
     Args:
         input_shape (Tuple[int]): ``(height, width, channels)`` of one slice.
-        weights_path (str | dict): ``.npz`` (or Keras ``.h5`` when h5py is installed) weights file, or a
+        weights_path (str | dict): Keras ``.h5`` (read with h5py or the built-in reader) or ``.npz`` weights file, or a
             dict of arrays in Keras layouts (``dosma_amd.models.weights``).
         force_weights (bool, optional): load weights without checking the file name.
     """

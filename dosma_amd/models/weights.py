@@ -4,8 +4,9 @@ The reference loads Keras ``.h5`` files (``keras_model.load_weights``, dosma/mod
 that are not distributed with the repository.  Here weights live in a dict ``name -> float32 array``
 with Keras layouts (Conv2D kernel ``(kh, kw, Cin, Cout)``, Conv2DTranspose kernel
 ``(kh, kw, Cout, Cin)``, BatchNormalization ``gamma / beta / moving_mean / moving_variance``), can be
-saved / loaded as ``.npz``, and can be read from a Keras ``.h5`` when ``h5py`` is available
-(:func:`load_keras_h5`; h5py is not in this image, so that reader is untested here -- DESIGN.md).
+saved / loaded as ``.npz``, and are read from a Keras ``.h5`` by :func:`load_keras_h5` -- through h5py where it is
+installed, otherwise through the dependency-free reader ``dosma_amd/io/_hdf5_lite.py`` (h5py is not in the MI355X
+image; the reader is tested against files written by the real h5py, tests/test_hdf5_lite.py).
 """
 import numpy as np
 
@@ -98,26 +99,27 @@ def load_keras_h5(path, depth=6):
     with ``weight_names`` ``kernel:0 / bias:0 / gamma:0 / beta:0 / moving_mean:0 / moving_variance:0``)."""
     try:
         import h5py
-    except ImportError as err:  # pragma: no cover - h5py is not in this image
-        raise ImportError("reading Keras .h5 weights needs h5py; convert the file to .npz where h5py is "
-                          "installed: dosma_amd.models.weights.save_npz(out, load_keras_h5(path))") from err
-    with h5py.File(path, "r") as f:  # pragma: no cover
+        opener = lambda p: h5py.File(p, "r")  # noqa: E731
+    except ImportError:
+        from ..io import _hdf5_lite
+        opener = _hdf5_lite.File
+    with opener(path) as f:
         g = f["model_weights"] if "model_weights" in f else f
-        layer_names = [n.decode() if isinstance(n, bytes) else n for n in g.attrs["layer_names"]]
+        layer_names = [n.decode() if isinstance(n, bytes) else str(n) for n in g.attrs["layer_names"]]
         per_layer = []
         for ln in layer_names:
-            wn = [n.decode() if isinstance(n, bytes) else n for n in g[ln].attrs["weight_names"]]
+            wn = [n.decode() if isinstance(n, bytes) else str(n) for n in g[ln].attrs["weight_names"]]
             if wn:
-                per_layer.append({n.split("/")[-1].split(":")[0]: np.asarray(g[ln][n]) for n in wn})
-    order = []  # pragma: no cover
+                per_layer.append({n.split("/")[-1].split(":")[0]: np.asarray(g[ln][n], dtype=np.float32) for n in wn})
+    order = []
     for d in range(depth):
         order += [f"down{d}_conv1", f"down{d}_conv2", f"down{d}_bn"]
     for d in range(depth - 2, -1, -1):
         order += [f"up{d}_deconv", f"up{d}_conv1", f"up{d}_conv2", f"up{d}_bn"]
     order.append("head")
-    if len(order) != len(per_layer):  # pragma: no cover
+    if len(order) != len(per_layer):
         raise ValueError(f"expected {len(order)} weighted layers, file has {len(per_layer)}")
-    w = {}  # pragma: no cover
+    w = {}
     for name, tensors in zip(order, per_layer):
         if name.endswith("_bn"):
             w[f"{name}_gamma"], w[f"{name}_beta"] = tensors["gamma"], tensors["beta"]

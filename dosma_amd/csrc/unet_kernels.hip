@@ -39,14 +39,14 @@ constexpr int kTW = 16;         // output tile width (pixels)
 // chunks of the input; per chunk the (TH+2) x 18 input halo is converted to bf16 ONCE and kept in
 // LDS, and the taps (9 for a 3x3 convolution) are walked as shifted views of it -- each activation is
 // fetched from HBM/L2 ~1.4x instead of 9x and converted once instead of 9 times.
-template <int BN, int TH_, bool WALL, int TW = 16, int NW = 4>
+template <int BN, int TH_, bool WALL, int TW = 16, int NW = 4, int WN = 0>
 struct TileCfg {
     static constexpr int NT = NW * 64;  // threads per block
     // WALL (small BN): the weights of ALL taps of a chunk are staged at once -> 2 barriers per chunk
     // instead of one per tap (at BN <= 64 a tap is only 2-4 MFMAs per wave, less than a barrier costs)
     static constexpr int TH = TH_;
     static constexpr int BM = TH * TW;
-    static constexpr int WAVES_N = BN >= 64 ? 2 : 1;
+    static constexpr int WAVES_N = WN ? WN : (BN >= 64 ? 2 : 1);  // WN = 1 at BN = 64: 64 x 64 per wave, 1 KB of LDS reads per MFMA instead of 1.5
     static constexpr int WAVES_M = NW / WAVES_N;
     static constexpr int TM = BM / WAVES_M / 32;
     static constexpr int TN = BN / WAVES_N / 32;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf1
     }
 }
 
-template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16, int NW = 4>
+template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16, int NW = 4, int WN = 0>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) {
     constexpr int kNT = NW * 64;  // NW = 8: a 16 x 16-pixel tile on 8 waves (4 x 2), twice the MFMAs per weight tile and barrier
     // TW: tile width.  16 in general; the deep levels of a 384 x 384 input are 24 and 12 pixels wide, where 16-wide
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
     static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
-    using C = TileCfg<BN, TH, WALL, TW, NW>;
+    using C = TileCfg<BN, TH, WALL, TW, NW, WN>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
     constexpr int HALO_BYTES = C::HALO_PIX * kLdsRow * 2;  // one plane of one halo buffer
     constexpr int W_BYTES = BN * kLdsRow * 2;               // one plane of one weight buffer
@@ -574,6 +574,13 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         k.halo_bufs = 1;
         if (s3_t128 == 2) th = 8, eight_s3 = false;
     }
+    // (the same 4-wave 64 x 64 arrangement in the parity mode: 161 / 280 / 252 -> 171 / 298 / 269 us, not used there)
+    static const int wide64_ok = [] { const char *e = std::getenv("QMRI_CONV_WIDE64"); return e ? std::atoi(e) : 1; }();
+    const bool wide64 = wide64_ok && !split3 && !k.deconv && bn == 64 && !k.c1_x && k.H % 16 == 0 && k.W % 16 == 0;
+    if (wide64) {
+        th = 16;
+        k.halo_bufs = 1;
+    }
     k.tiles_y = (k.H + th - 1) / th;
     k.tiles_x = (k.W + tw - 1) / tw;
     dim3 grid((unsigned)((long long)k.B * k.tiles_y * k.tiles_x), (unsigned)(k.Cout / bn));
@@ -643,7 +650,14 @@ hipError_t conv_igemm_launch(const ConvKArgs &k0, int split3, hipStream_t stream
         else if (tw == 12) QMRI_CONV_CASE_TW(128, 16, 12, 4);   //  50 % slower -- 6 waves do not spread over 4 SIMDs)
         else if (th == 16) QMRI_CONV_CASE(128, 16, false, __bf16, false); else QMRI_CONV_CASE(128, 8, false, __bf16, false);
     } else if (bn == 64) {
-        if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);
+        if (wide64) {
+            // 16 x 16 pixels x 64 channels on 4 waves of 64 x 64 (TM = TN = 2), one halo buffer -> 72 KB, 2 blocks per CU
+            auto fn = conv_igemm_kernel<64, 16, false, __bf16, false, false, 16, 4, 1>;
+            const size_t lds = conv_lds_bytes<64, 16, false>(k.halo_bufs);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, k);
+        } else if (th == 16) QMRI_CONV_CASE(64, 16, false, __bf16, false); else QMRI_CONV_CASE(64, 8, false, __bf16, false);
     } else {
         if (k.c1_x) {
             if (th == 16) QMRI_CONV_CASE(32, 16, false, __bf16, false, true);

@@ -441,7 +441,7 @@ __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
 // losing the second wave.  EMAX = 16: 14.0 ms instead of 16.8 for the exact-size variant (148 spills), but 52.9 instead
 // of 18.8 for the partial one (340 spills); EMAX = 32 does not fit either way.
 template <int EMAX, bool FULL, typename LT>
-__global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI_MIN_WAVES) void monoexp_lm_kernel(
+__global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX <= 16 && FULL)) ? 2 : QMRI_MIN_WAVES) void monoexp_lm_kernel(
     const FitKArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
 #pragma unroll
                         for (int i = 0; i < EMAX; ++i)
                             if (FULL || i < E) yv[i] = tile[i * kSub + j];
+                            else yv[i] = 0;
                         sstot = t_sst[j];
                         vox = tile_base + j;
                         pa = A.a0;
@@ -752,16 +753,20 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                 }
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
-                    if (FULL || i < E) ev[i] = i >= 4 ? ev[i - 4] * q4 : (i >= 2 ? ev[i - 2] * q2 : ev[0] * q1);
+                    ev[i] = i >= 4 ? ev[i - 4] * q4 : (i >= 2 ? ev[i - 2] * q2 : ev[0] * q1);
             } else {
 #pragma unroll
                 for (int i = 0; i < EMAX; ++i)
                     if (FULL || i < E) ev[i] = exp(mul_rn(tb, A.x[i]));
+                    else ev[i] = 0.0;
             }
 #pragma unroll
             for (int i = 0; i < EMAX; ++i)
-                if (FULL || i < E) {
-                    fv[i] = sub_rn(mul_rn(ta, ev[i]), static_cast<double>(yv[i]));
+                {
+                    // partial variants (E < EMAX): the padded residuals and Jacobian rows are exact zeros, produced here and
+                    // in the forward differences below; every consumer loop runs over all EMAX entries unguarded (sums of
+                    // zeros), which keeps the partial kernels within a few registers of the exact-size ones
+                    fv[i] = (FULL || i < E) ? sub_rn(mul_rn(ta, ev[i]), static_cast<double>(yv[i])) : 0.0;
                     ss += fv[i] * fv[i];
                 }
             double fnorm1, rfn1 = 0.0;  // rfn1 = 1 / fnorm1 on the fast path, else 0 (-> frcp when needed)
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                 bool anynan = false;
 #pragma unroll
                 for (int i = 0; i < EMAX; ++i)
-                    if (FULL || i < E) {
+                    {
                         m = fmax(m, fabs(fv[i]));
                         anynan = anynan || isnan(fv[i]);
                     }
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                     double s2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
-                        if (FULL || i < E) {
+                        {
                             const double r = fv[i] / m;
                             s2 += r * r;
                         }
@@ -882,6 +887,9 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                             ev[i] = sub_rn(sub_rn(mul_rn(a1, e), yi), fv[i]) * rha;
                             n1 += ev[i] * ev[i];
                             n2 += c2[i] * c2[i];
+                        } else {
+                            c2[i] = 0.0;
+                            ev[i] = 0.0;
                         }
                 }
                 // (E-vector norms: sums of squares of finite values can only overflow to inf, never NaN)
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                 if (l0) {
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
-                        if (FULL || i < E) {
+                        {
                             const double t = ev[i];
                             ev[i] = c2[i];
                             c2[i] = t;
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
-                        if (FULL || i < E) {
+                        {
                             ev[i] = ev[i] * iajn;
                             if (i == 0) ev[0] += 1.0;
                             s1 += ev[i] * c2[i];
@@ -921,7 +929,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                     const double t2 = -s2 * iv0;
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
-                        if (FULL || i < E) {
+                        {
                             c2[i] -= t1 * ev[i];
                             fv[i] += t2 * ev[i];
                         }
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                 double m2 = 0.0;
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
-                    if (FULL || i < E) m2 += c2[i] * c2[i];
+                    m2 += c2[i] * c2[i];
                 double ajn2, iajn2;
                 sqrt_rsqrt(m2, ajn2, iajn2);
                 if (ajn2 != 0.0) {
@@ -944,7 +952,7 @@ __global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX == 16 && FULL)) ? 2 : QMRI
                     double s = 0.0;
 #pragma unroll
                     for (int i = 1; i < EMAX; ++i)
-                        if (FULL || i < E) {
+                        {
                             c2[i] = c2[i] * iajn2;
                             if (i == 1) c2[1] += 1.0;
                             s += c2[i] * fv[i];
@@ -1183,8 +1191,14 @@ const char *monoexp_variant_name(int E, int y_dtype) {
     if (E == 6) return d ? "monoexp_lm<6,full,f64>" : "monoexp_lm<6,full,f32>";
     if (E == 7) return d ? "monoexp_lm<7,full,f64>" : "monoexp_lm<7,full,f32>";
     if (E <= 8) return d ? "monoexp_lm<8,full,f64>" : "monoexp_lm<8,full,f32>";
-    if (E <= 16) return d ? (E == 16 ? "monoexp_lm<16,full,f64>" : "monoexp_lm<16,part,f64>")
-                          : (E == 16 ? "monoexp_lm<16,full,f32>" : "monoexp_lm<16,part,f32>");
+    if (E == 9) return d ? "monoexp_lm<9,full,f64>" : "monoexp_lm<9,full,f32>";
+    if (E == 10) return d ? "monoexp_lm<10,full,f64>" : "monoexp_lm<10,full,f32>";
+    if (E == 11) return d ? "monoexp_lm<11,full,f64>" : "monoexp_lm<11,full,f32>";
+    if (E == 12) return d ? "monoexp_lm<12,full,f64>" : "monoexp_lm<12,full,f32>";
+    if (E == 13) return d ? "monoexp_lm<13,full,f64>" : "monoexp_lm<13,full,f32>";
+    if (E == 14) return d ? "monoexp_lm<14,full,f64>" : "monoexp_lm<14,full,f32>";
+    if (E == 15) return d ? "monoexp_lm<15,full,f64>" : "monoexp_lm<15,full,f32>";
+    if (E == 16) return d ? "monoexp_lm<16,full,f64>" : "monoexp_lm<16,full,f32>";
     return d ? (E == 32 ? "monoexp_lm<32,full,f64>" : "monoexp_lm<32,part,f64>")
              : (E == 32 ? "monoexp_lm<32,full,f32>" : "monoexp_lm<32,part,f32>");
 }
@@ -1196,7 +1210,14 @@ int monoexp_waves_per_block(const FitKArgs &k) {
     if (k.E == 6) return QMRI_DISPATCH_FULL(6, wpb_one, k.E);
     if (k.E == 7) return QMRI_DISPATCH_FULL(7, wpb_one, k.E);
     if (k.E <= 8) return QMRI_DISPATCH_FULL(8, wpb_one, k.E);
-    if (k.E <= 16) return QMRI_DISPATCH(16, wpb_one, k.E);
+    if (k.E == 9) return QMRI_DISPATCH_FULL(9, wpb_one, k.E);
+    if (k.E == 10) return QMRI_DISPATCH_FULL(10, wpb_one, k.E);
+    if (k.E == 11) return QMRI_DISPATCH_FULL(11, wpb_one, k.E);
+    if (k.E == 12) return QMRI_DISPATCH_FULL(12, wpb_one, k.E);
+    if (k.E == 13) return QMRI_DISPATCH_FULL(13, wpb_one, k.E);
+    if (k.E == 14) return QMRI_DISPATCH_FULL(14, wpb_one, k.E);
+    if (k.E == 15) return QMRI_DISPATCH_FULL(15, wpb_one, k.E);
+    if (k.E == 16) return QMRI_DISPATCH_FULL(16, wpb_one, k.E);
     return QMRI_DISPATCH(32, wpb_one, k.E);
 }
 
@@ -1207,7 +1228,14 @@ int monoexp_blocks_per_cu(const FitKArgs &k) {
     if (k.E == 6) return QMRI_DISPATCH_FULL(6, occupancy_one, k.E);
     if (k.E == 7) return QMRI_DISPATCH_FULL(7, occupancy_one, k.E);
     if (k.E <= 8) return QMRI_DISPATCH_FULL(8, occupancy_one, k.E);
-    if (k.E <= 16) return QMRI_DISPATCH(16, occupancy_one, k.E);
+    if (k.E == 9) return QMRI_DISPATCH_FULL(9, occupancy_one, k.E);
+    if (k.E == 10) return QMRI_DISPATCH_FULL(10, occupancy_one, k.E);
+    if (k.E == 11) return QMRI_DISPATCH_FULL(11, occupancy_one, k.E);
+    if (k.E == 12) return QMRI_DISPATCH_FULL(12, occupancy_one, k.E);
+    if (k.E == 13) return QMRI_DISPATCH_FULL(13, occupancy_one, k.E);
+    if (k.E == 14) return QMRI_DISPATCH_FULL(14, occupancy_one, k.E);
+    if (k.E == 15) return QMRI_DISPATCH_FULL(15, occupancy_one, k.E);
+    if (k.E == 16) return QMRI_DISPATCH_FULL(16, occupancy_one, k.E);
     return QMRI_DISPATCH(32, occupancy_one, k.E);
 }
 
@@ -1218,7 +1246,14 @@ hipError_t monoexp_launch(const FitKArgs &k, int grid, hipStream_t stream) {
     if (k.E == 6) return QMRI_DISPATCH_FULL(6, launch_one, k, grid, stream);
     if (k.E == 7) return QMRI_DISPATCH_FULL(7, launch_one, k, grid, stream);
     if (k.E <= 8) return QMRI_DISPATCH_FULL(8, launch_one, k, grid, stream);
-    if (k.E <= 16) return QMRI_DISPATCH(16, launch_one, k, grid, stream);
+    if (k.E == 9) return QMRI_DISPATCH_FULL(9, launch_one, k, grid, stream);
+    if (k.E == 10) return QMRI_DISPATCH_FULL(10, launch_one, k, grid, stream);
+    if (k.E == 11) return QMRI_DISPATCH_FULL(11, launch_one, k, grid, stream);
+    if (k.E == 12) return QMRI_DISPATCH_FULL(12, launch_one, k, grid, stream);
+    if (k.E == 13) return QMRI_DISPATCH_FULL(13, launch_one, k, grid, stream);
+    if (k.E == 14) return QMRI_DISPATCH_FULL(14, launch_one, k, grid, stream);
+    if (k.E == 15) return QMRI_DISPATCH_FULL(15, launch_one, k, grid, stream);
+    if (k.E == 16) return QMRI_DISPATCH_FULL(16, launch_one, k, grid, stream);
     return QMRI_DISPATCH(32, launch_one, k, grid, stream);
 }
 

@@ -7,7 +7,7 @@ import bench
 lib = L.load()
 dev = torch.device("cuda", 0)
 n = 1 << 23
-for E in (2, 3, 4, 8, 12, 16, 17, 20, 24, 28, 32):
+for E in (4, 8, 12, 16, 20, 32):
     g = torch.Generator(device=dev); g.manual_seed(E)
     x = np.arange(1, E + 1) * (80.0 / E)
     s0 = torch.rand(n, device=dev, generator=g) * 1200 + 300

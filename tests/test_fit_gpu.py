@@ -204,6 +204,40 @@ def test_equally_spaced_sample_times_vs_oracle(relerr, x):
     assert (o["nfev"] == nfev).mean() > 0.995
 
 
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1e12, 1e30])
+def test_extreme_magnitudes_vs_oracle(relerr, scale):
+    """Samples far from O(1): the guarded fast paths of the kernel (closed-form lmpar inside |.| < 1e100, reciprocals /
+    square roots inside 1e-290..1e290, the exponential chain) must hand over to their slow forms where needed and agree
+    with the oracle, which has none of them.  float64 samples; the amplitude scales, the rate does not."""
+    rng = np.random.default_rng(11)
+    E, N = 8, 4000
+    x = np.arange(1, E + 1) * 10.0
+    y = rng.uniform(300, 1500, N) * np.exp(-x[:, None] / rng.uniform(15, 80, N)) + 8 * rng.standard_normal((E, N))
+    y[:, ::9] = 0
+    y[:, 5::97] *= -1  # a few negative columns (fail or give nonsense in both solvers alike)
+    ys = y * scale
+    o = L.monoexp_fit_host(x, ys, p0=P0, want_info=True)
+    popt, r2, info, nfev = fo.curve_fit_c(x, ys, P0, jac_mode=2, full_output=True)
+    same = ((o["info"] >= 1) & (o["info"] <= 4)) == ((info >= 1) & (info <= 4))
+    assert same.mean() > 0.995, same.mean()
+    ok = same & (info >= 1) & (info <= 4)
+    if scale >= 1e-16:
+        d = relerr(o["popt"][ok], popt[ok]).max(axis=1)
+        assert (d > RTOL).mean() < 5e-3, f"scale {scale}: frac>{RTOL}: {(d > RTOL).mean()}, max {d.max()}"
+    else:
+        # samples ~1e-27 against p0 = (1, -1/30): the first step takes a to ~0 (1e-17: the rounding residue of 1 - 1),
+        # where dF/db = a x e vanishes and b is no longer identifiable; lmdif stops on xtol after 7-13 evaluations
+        # with b still at its initial value and a = O(1e-17) noise -- in the reference as here (scripts/tiny_probe.py).
+        # What the map shows (tc = 1/|b|, r2 ~ 1) agrees; the noise in a does not and cannot.
+        assert relerr(o["popt"][ok][:, 1], popt[ok][:, 1]).max() < RTOL
+        assert np.abs(o["popt"][ok][:, 0]).max() < 1e-15 and np.abs(popt[ok][:, 0]).max() < 1e-15
+    assert r2_close(o["r2"][ok], r2[ok]).mean() > 0.995
+    assert np.isnan(o["popt"][~((o["info"] >= 1) & (o["info"] <= 4))]).all()
+    b = L.monoexp_fit_host(x, ys, init=L.INIT_LOGLIN, post=post(), want_tc=True)
+    tc, _, _ = fo.monoexp_fit_arrays(x, ys, tc0="polyfit", decimal_precision=3, jac_mode=2)
+    assert (np.abs(b["tc"] - tc) > 1e-3 + 1e-9).mean() < 5e-3
+
+
 def test_per_voxel_p0_and_y_bounds(relerr):
     rng = np.random.default_rng(5)
     N, E = 3000, 6

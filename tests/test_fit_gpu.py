@@ -184,13 +184,16 @@ def test_vs_oracle_shapes_and_dtypes(relerr, E, dtype):
     np.arange(1, 17) * 5.0,              # E = 16: the depth-5 product tree
     np.array([10., 20., 30., 40., 50., 60., 70., 80.000001]),  # NOT equally spaced by 1e-8: E exponentials
     -10.0 + np.arange(8) * 10.0,         # x_0 < 0: the chain is off (0 * inf hazard), E exponentials
-], ids=["k1", "k0", "k3", "offset", "offset5", "e16", "almost", "negative"])
+    np.array([40., 10., 80., 20., 60., 30., 70., 50.]),         # not sorted (Mapss sorts, curve_fit callers need not)
+    np.array([10., 10., 20., 20., 40., 40., 80., 80.]),         # repeated sample times
+    np.arange(1, 9) * 1e4,               # times in microseconds: b ~ 1e-5
+], ids=["k1", "k0", "k3", "offset", "offset5", "e16", "almost", "negative", "unsorted", "repeated", "microseconds"])
 def test_equally_spaced_sample_times_vs_oracle(relerr, x):
     """The exponential power chain of the fit kernel (equally spaced x: exp(b x_i) = exp(b x_0) exp(b step)^i) against
     the oracle, which always evaluates E exponentials: same solutions to the parity bar, same nfev."""
     rng = np.random.default_rng(len(x))
     E, N = len(x), 6000
-    xe = np.abs(x) + 1.0
+    xe = (np.abs(x) + 1.0) * (80.0 / np.abs(x).max())  # generate with a decay over the sampled range whatever its unit
     y = rng.uniform(300, 1500, N) * np.exp(-xe[:, None] / rng.uniform(15, 80, N)) + 8 * rng.standard_normal((E, N))
     y = y.astype(np.float32)
     y[:, ::13] = 0

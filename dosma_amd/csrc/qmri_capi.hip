@@ -177,6 +177,19 @@ void fill_kargs(const qmri_monoexp_args *a, qmri::FitKArgs &k) {
     }
 }
 
+// stream-ordered scratch that is returned to the pool on every exit path (the HIP_TRY early returns included)
+struct AsyncScratch {
+    void *p = nullptr;
+    hipStream_t stream = nullptr;
+    hipError_t alloc(size_t bytes, hipStream_t s) {
+        stream = s;
+        return hipMallocAsync(&p, bytes, s);
+    }
+    ~AsyncScratch() {
+        if (p) (void)hipFreeAsync(p, stream);
+    }
+};
+
 // issue one fit launch on `stream`; flag_out (device) receives the non-finite flag if non-NULL
 int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
     DeviceCtx *ctx = nullptr;
@@ -196,8 +209,10 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
     const long long tiles = (a->N + qmri::monoexp_tile_voxels() - 1) / qmri::monoexp_tile_voxels();
     // masked volume: fill the tiles without a selected voxel and compact the others first (stream-ordered scratch)
     unsigned int *tile_list = nullptr;
+    AsyncScratch tile_scratch;
     if (a->mask && tiles >= 4096) {
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&tile_list), (size_t)(tiles + 1) * 4, stream));
+        HIP_TRY(tile_scratch.alloc((size_t)(tiles + 1) * 4, stream));
+        tile_list = static_cast<unsigned int *>(tile_scratch.p);
         HIP_TRY(hipMemsetAsync(tile_list + tiles, 0, 4, stream));
         HIP_TRY(qmri::monoexp_mask_prepass(k, tile_list, tile_list + tiles, ctx->num_cu, stream));
         k.tile_list = tile_list;
@@ -217,7 +232,6 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     HIP_TRY(qmri::monoexp_launch(k, static_cast<int>(grid), stream));
-    if (tile_list) HIP_TRY(hipFreeAsync(tile_list, stream));
     if (g_timing) {
         HIP_TRY(hipEventRecord(ev1, stream));
         HIP_TRY(hipEventSynchronize(ev1));
@@ -795,10 +809,9 @@ int qmri_dess_t2_device(const qmri_dess_args *a) {
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(ctx_get(a->device, &ctx));
     hipStream_t st = static_cast<hipStream_t>(a->stream);
-    double *scratch = nullptr;
-    if (a->suppress_fat || a->suppress_fluid) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scratch), (2 * 1024 + 2) * 8, st));
-    HIP_TRY(qmri::dess_t2_launch(k, a->dtype, ctx->num_cu, scratch, st));
-    if (scratch) HIP_TRY(hipFreeAsync(scratch, st));
+    AsyncScratch scratch;
+    if (a->suppress_fat || a->suppress_fluid) HIP_TRY(scratch.alloc((2 * 1024 + 2) * 8, st));
+    HIP_TRY(qmri::dess_t2_launch(k, a->dtype, ctx->num_cu, static_cast<double *>(scratch.p), st));
     return QMRI_OK;
 }
 

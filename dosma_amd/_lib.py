@@ -5,6 +5,7 @@ library is missing or no HIP device is present, calls raise.
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -169,6 +170,14 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        if not os.path.exists(_SO) and os.environ.get("DOSMA_AMD_AUTOBUILD", "1") != "0":
+            # a fresh checkout on a box with the ROCm toolchain: build the extension in-tree (about 30 s, once).  This is
+            # still the HIP path -- there is nothing else to fall back to -- and it fails below if hipcc is missing.
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as err:  # noqa: BLE001 - reported through the QmriError below
+                sys.stderr.write(f"dosma_amd: building {_SO} failed: {err}\n")
         if not os.path.exists(_SO):
             raise QmriError(
                 f"{_SO} not found: the HIP extension is not built (run `python -m dosma_amd.build`). "

@@ -35,9 +35,21 @@ def _stale():
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return SO
-    objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
+    # one builder at a time (several ranks of a torchrun job may find the library missing together): the others wait
+    # on the lock and then find a fresh library
+    import fcntl
+
+    with open(os.path.join(bdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return SO
+        return _build_locked(bdir, verbose)
+
+
+def _build_locked(bdir: str, verbose: bool) -> str:
+    objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
@@ -50,10 +62,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO] + objs
+    tmp = SO + f".tmp{os.getpid()}"
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, SO)  # atomic: a concurrent loader never sees a half-written library
     return SO
 
 

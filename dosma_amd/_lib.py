@@ -96,6 +96,18 @@ class QmriDessArgs(ctypes.Structure):
     ]
 
 
+class QmriRegionStatsArgs(ctypes.Structure):
+    _fields_ = [
+        ("values", ctypes.c_void_p), ("v_dtype", ctypes.c_int32), ("labels", ctypes.c_void_p), ("N", ctypes.c_int64),
+        ("nkeys", ctypes.c_int32), ("label_keys", ctypes.c_void_p), ("use_bounds", ctypes.c_int32),
+        ("lo", ctypes.c_double), ("hi", ctypes.c_double), ("closed", ctypes.c_int32), ("out", ctypes.c_void_p),
+        ("device", ctypes.c_int32),
+    ]
+
+
+MAX_REGIONS = 16  # QMRI_MAX_REGIONS
+
+
 class QmriLmfitArgs(ctypes.Structure):
     _fields_ = [
         ("model", ctypes.c_int32), ("y_dtype", ctypes.c_int32), ("y", ctypes.c_void_p),
@@ -122,7 +134,7 @@ EXPORTS = (
     "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
-    "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host",
+    "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
 )
 
 _lib = None
@@ -596,6 +608,44 @@ def dess_t2_host(echo1, echo2, c0, k, c1, *, bounds=None, nan_to_num=None, decim
     a.t2 = _ptr(out)
     a.device = _dev(device)
     check(lib.qmri_dess_t2_host(ctypes.byref(a)))
+    return out
+
+
+_CLOSED = {"neither": 0, "left": 1, "right": 2, "both": 3}
+
+
+def region_stats_host(values, labels=None, keys=(), bounds=None, closed="right", device=None):
+    """Count / mean / std / median of ``values`` per region on the GPU (quant_vals.py:145-229): one row per entry of
+    ``keys`` (voxels whose label equals the key) plus a last row "total" (label > 0; every voxel when ``labels`` is
+    None), over the finite voxels inside ``bounds``.  Returns a float64 array (len(keys) + 1, 4)."""
+    lib = load()
+    require_device()
+    v = np.ascontiguousarray(values)
+    if v.dtype not in (np.float32, np.float64):
+        v = v.astype(np.float64)
+    v = v.reshape(-1)
+    a = QmriRegionStatsArgs()
+    a.values, a.v_dtype, a.N = _ptr(v), qdtype(v.dtype), v.size
+    keep = [v]
+    keys = [int(k) for k in keys]
+    if labels is not None:
+        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        if lab.size != v.size:
+            raise ValueError("label map and values differ in size")
+        if len(keys) > MAX_REGIONS - 1:
+            raise ValueError(f"at most {MAX_REGIONS - 1} labelled regions per call")
+        ks = np.asarray(keys, dtype=np.int32)
+        a.labels, a.nkeys, a.label_keys = _ptr(lab), len(keys), _ptr(ks)
+        keep += [lab, ks]
+    else:
+        keys = []
+    if bounds is not None:
+        if closed not in _CLOSED:
+            raise ValueError(f"`closed={closed}` is not supported")
+        a.use_bounds, a.lo, a.hi, a.closed = 1, float(bounds[0]), float(bounds[1]), _CLOSED[closed]
+    out = np.empty((len(keys) + 1, 4), dtype=np.float64)
+    a.out, a.device = _ptr(out), _dev(device)
+    check(lib.qmri_region_stats_host(ctypes.byref(a)))
     return out
 
 

@@ -872,4 +872,38 @@ int qmri_rss_host(const void *echo1, const void *echo2, int32_t dtype, int64_t N
     return QMRI_OK;
 }
 
+int qmri_region_stats_host(const qmri_region_stats_args *a) {
+    if (!a || !a->values || !a->out) return fail(QMRI_ERR_ARG, "NULL argument");
+    if (a->v_dtype != QMRI_F32 && a->v_dtype != QMRI_F64) return fail(QMRI_ERR_ARG, "values must be f32 or f64");
+    if (a->N < 0) return fail(QMRI_ERR_ARG, "N < 0");
+    const int nkeys = a->labels ? a->nkeys : 0;
+    if (nkeys < 0 || nkeys > QMRI_MAX_REGIONS - 1) return fail(QMRI_ERR_ARG, "nkeys must be 0..%d", QMRI_MAX_REGIONS - 1);
+    if (nkeys > 0 && !a->label_keys) return fail(QMRI_ERR_ARG, "label_keys is NULL");
+    if (a->use_bounds && (a->closed < 0 || a->closed > 3)) return fail(QMRI_ERR_ARG, "closed must be 0..3");
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    const size_t es = a->v_dtype == QMRI_F64 ? 8 : 4;
+    const size_t n = (size_t)(a->N > 0 ? a->N : 1);
+    void *dv = nullptr, *dstate = nullptr;
+    int *dl = nullptr;
+    double *dout = nullptr;
+    hipError_t e = hipMalloc(&dv, n * es);
+    if (e == hipSuccess && a->labels) e = hipMalloc(reinterpret_cast<void **>(&dl), n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dstate, qmri::region_stats_state_bytes());
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), (size_t)(nkeys + 1) * 4 * 8);
+    if (e == hipSuccess && a->N > 0) e = hipMemcpy(dv, a->values, (size_t)a->N * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess && a->labels && a->N > 0) e = hipMemcpy(dl, a->labels, (size_t)a->N * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = qmri::region_stats_launch(dv, a->v_dtype == QMRI_F64, dl, a->N, nkeys, a->label_keys, a->use_bounds, a->lo, a->hi,
+                                      a->closed, dstate, dout, ctx->num_cu, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(a->out, dout, (size_t)(nkeys + 1) * 4 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dv);
+    (void)hipFree(dl);
+    (void)hipFree(dstate);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "region_stats_host: %s", hipGetErrorString(e));
+    return QMRI_OK;
+}
+
 }  // extern "C"

@@ -168,6 +168,11 @@ hipError_t dess_t2_launch(const DessKArgs &k, int dtype, int num_cu, double *scr
 hipError_t rss_launch(const void *e1, const void *e2, int dtype, long long n, int rms, double *out, int num_cu,
                       hipStream_t stream);
 
+size_t region_stats_state_bytes();
+hipError_t region_stats_launch(const void *values, int f64, const int *labels, long long N, int nkeys, const int *keys,
+                               int use_bounds, double lo, double hi, int closed, void *state, double *out_dev,
+                               int num_cu, hipStream_t stream);
+
 void set_last_error(const char *msg);  // thread-local message behind qmri_last_error()
 
 int monoexp_tile_voxels();

@@ -90,17 +90,28 @@ class QuantitativeValue(ABC):
         import pandas as pd
 
         values = self.volumetric_map.volume
+        _inside(values[:0], bounds, closed)  # argument checks of the reference (AssertionError), before any work
+        label_map = None
+        if mask is not None:
+            label_map = mask.reformat(self.volumetric_map.orientation).volume
+            if labels is None:
+                labels = {int(v): f"label_{int(v)}" for v in np.unique(label_map) if v > 0}
+        extra = dict(fns or {})
+        names = (list(labels.values()) if mask is not None else []) + ["total"]
+        stats = self._region_stats_gpu(values, label_map, labels, bounds, closed) if not extra else None
+        if stats is not None:
+            rows = [{"Category": name, "Mean": st[1], "Std": st[2], "Median": st[3], "# Voxels": int(st[0])}
+                    for name, st in zip(names, stats)]
+            return pd.DataFrame(rows, columns=["Category", "Mean", "Std", "Median", "# Voxels"])
+        # host evaluation, the reference's own (numpy) route: needed for user callables (`fns` take the region's voxels
+        # as a numpy array) and for label maps the GPU kernel does not take (see _region_stats_gpu)
         usable = np.isfinite(values) & _inside(values, bounds, closed)
         if mask is None:
             regions = [("total", usable)]
         else:
-            label_map = mask.reformat(self.volumetric_map.orientation).volume
-            if labels is None:
-                labels = {int(v): f"label_{int(v)}" for v in np.unique(label_map) if v > 0}
             label_map = np.where(usable, label_map, 0)
             regions = [(name, label_map == key) for key, name in labels.items()]
             regions.append(("total", label_map > 0))
-        extra = dict(fns or {})
         rows = []
         with np.errstate(all="ignore"), warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)  # empty regions -> NaN, quietly
@@ -111,6 +122,38 @@ class QuantitativeValue(ABC):
                 row.update({key: fn(v) for key, fn in extra.items()})
                 rows.append(row)
         return pd.DataFrame(rows, columns=["Category", "Mean", "Std", "Median", "# Voxels", *extra])
+
+    @staticmethod
+    def _region_stats_gpu(values, label_map, labels, bounds, closed):
+        """Rows (count, mean, std, median) per label + "total" from the HIP kernels (csrc/region_stats.hip), or None
+        when this call has to take the host route: no GPU in the process, label keys <= 0, or a label map that is
+        not integer valued (the kernel compares int32 labels)."""
+        from . import _lib
+
+        try:
+            if _lib.load().qmri_device_count() <= 0:
+                return None
+        except _lib.QmriError:
+            return None
+        if label_map is None:
+            return _lib.region_stats_host(values, None, (), bounds, closed)
+        keys = [int(k) for k in labels]
+        if any(k <= 0 for k in keys) or any(int(k) != k for k in labels):
+            return None
+        lab = np.asarray(label_map)
+        if lab.dtype.kind == "f":
+            if not np.array_equal(lab, np.rint(lab)):
+                return None
+        elif lab.dtype.kind not in "iub":
+            return None
+        lab = lab.astype(np.int32, copy=False)
+        rows, total = [], None
+        step = _lib.MAX_REGIONS - 1
+        for i in range(0, max(len(keys), 1), step):
+            part = _lib.region_stats_host(values, lab, keys[i:i + step], bounds, closed)
+            rows.extend(part[:-1])
+            total = part[-1]
+        return rows + [total]
 
     @staticmethod
     def get_qv(qv_id: Union[int, str]):

@@ -300,6 +300,30 @@ int qmri_dess_t2_host(const qmri_dess_args *args);   /* host pointers, synchrono
 int qmri_rss_host(const void *echo1, const void *echo2, int32_t dtype, int64_t N, int32_t mode, double *out,
                   int32_t device);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Region statistics of a quantitative map: SURVEY.md 8(f) row N1, the masked reductions of
+ * QuantitativeValue.to_metrics (/root/reference/dosma/core/quant_vals.py:145-229): for every region
+ * (label_keys[r], and a last region "total" = every voxel with a positive label; without labels: every voxel)
+ * the count, mean (nanmean), population standard deviation (nanstd) and median (nanmedian: the middle element,
+ * or the mean of the two middle elements) of the voxels that are finite and inside `bounds`.
+ * The median is exact (radix selection on the order-preserving integer image of the double), mean / std are fp64
+ * sums (two passes like numpy's nanstd; the summation order differs from numpy's pairwise sums: ~1e-15 relative). */
+typedef struct qmri_region_stats_args {
+    const void *values;        /* [N] map */
+    int32_t v_dtype;           /* QMRI_F32 | QMRI_F64 */
+    const int32_t *labels;     /* [N] label map, or NULL: one region "total" over all voxels */
+    int64_t N;
+    int32_t nkeys;             /* number of labelled regions (<= QMRI_MAX_REGIONS - 1), 0 if labels == NULL */
+    const int32_t *label_keys; /* [nkeys] (host memory in both entry points) */
+    int32_t use_bounds;        /* bounds = (lo, hi) */
+    double lo, hi;
+    int32_t closed;            /* interval ends that belong to it: 0 neither, 1 left, 2 right, 3 both */
+    double *out;               /* [nkeys + 1][4] (host memory): count, mean, std, median; NaN statistics for count 0 */
+    int32_t device;
+} qmri_region_stats_args;
+#define QMRI_MAX_REGIONS 16
+int qmri_region_stats_host(const qmri_region_stats_args *args); /* values / labels in host memory, synchronous */
+
 /* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
  * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */
 void qmri_set_timing(int enable);

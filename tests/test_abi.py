@@ -58,6 +58,9 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(qmri_lmfit_args), offsetof(qmri_lmfit_args, x),\n'
         "         offsetof(qmri_lmfit_args, p0v), offsetof(qmri_lmfit_args, ftol), offsetof(qmri_lmfit_args, y_lo),\n"
         "         offsetof(qmri_lmfit_args, stream));\n"
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(qmri_region_stats_args), offsetof(qmri_region_stats_args, N),\n'
+        "         offsetof(qmri_region_stats_args, label_keys), offsetof(qmri_region_stats_args, lo),\n"
+        "         offsetof(qmri_region_stats_args, out), offsetof(qmri_region_stats_args, device));\n"
         "  return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -73,6 +76,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
     want += [ctypes.sizeof(D), D.N.offset, D.lo.offset, D.beta.offset, D.stream.offset]
     M = _lib.QmriLmfitArgs
     want += [ctypes.sizeof(M), M.x.offset, M.p0v.offset, M.ftol.offset, M.y_lo.offset, M.stream.offset]
+    R = _lib.QmriRegionStatsArgs
+    want += [ctypes.sizeof(R), R.N.offset, R.label_keys.offset, R.lo.offset, R.out.offset, R.device.offset]
     assert got == want
 
 

@@ -1,0 +1,109 @@
+"""QuantitativeValue.to_metrics on the GPU (csrc/region_stats.hip) against the host evaluation, which
+is the reference's own numpy route (quant_vals.py:145-229: nanmean / nanstd / nanmedian / count per label, "total").
+Counts and medians must be exact (radix selection); means / standard deviations are fp64 sums in a different order
+than numpy's pairwise summation -> 1e-12 relative."""
+import numpy as np
+import pytest
+
+import dosma_amd as dm
+from dosma_amd import _lib as L
+from dosma_amd.quant_vals import T2, QuantitativeValue
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_frame(qv, **kw):
+    """The same call forced through the host route (a user callable makes to_metrics evaluate on the host)."""
+    df = qv.to_metrics(fns={"_n": lambda v: v.size}, **kw)
+    return df.drop(columns=["_n"])
+
+
+def _check(gpu, host, f32=False):
+    """float32 maps: numpy sums them in float32 (1e-7 relative at best), the kernel in float64 -> compared at 1e-5."""
+    assert list(gpu["Category"]) == list(host["Category"])
+    assert list(gpu["# Voxels"]) == list(host["# Voxels"])
+    for col, tol in (("Median", 0.0), ("Mean", 1e-5 if f32 else 1e-12), ("Std", 1e-5 if f32 else 1e-11)):
+        g, h = gpu[col].to_numpy(float), host[col].to_numpy(float)
+        assert np.array_equal(np.isnan(g), np.isnan(h)), col
+        ok = ~np.isnan(h)
+        assert np.all(np.abs(g[ok] - h[ok]) <= tol * np.maximum(1.0, np.abs(h[ok]))), (col, g, h)
+
+
+def _map(shape, dtype, seed, decimals=None):
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(-20, 120, shape)
+    if decimals is not None:
+        v = np.around(v, decimals)  # many ties, as a rounded T2 map has
+    v[rng.uniform(size=shape) < 0.05] = np.nan
+    v[rng.uniform(size=shape) < 0.01] = np.inf
+    v[rng.uniform(size=shape) < 0.01] = -np.inf
+    return v.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("decimals", [None, 1])
+def test_labelled_regions_match_numpy(dtype, decimals):
+    shape = (64, 48, 20)
+    v = _map(shape, dtype, 1, decimals)
+    rng = np.random.default_rng(2)
+    lab = rng.integers(0, 6, shape).astype(np.uint8)
+    lab[lab == 4] = 0  # label 4 is asked for but empty -> NaN statistics, count 0
+    qv = T2(dm.MedicalVolume(v, np.eye(4)))
+    mask = dm.MedicalVolume(lab, np.eye(4))
+    labels = {1: "fc", 2: "tc", 3: "pc", 4: "empty", 5: "men"}
+    f32 = dtype == np.float32
+    for kw in (dict(), dict(bounds=(0, 100)), dict(bounds=(0, 100), closed="both"), dict(bounds=(10.0, 10.0), closed="both"),
+               dict(bounds=(0, 80), closed="neither"), dict(bounds=(0, 80), closed="left")):
+        _check(qv.to_metrics(mask, labels, **kw), _host_frame(qv, mask=mask, labels=labels, **kw), f32)
+    # labels taken from the mask, float label map, more labels than one kernel call takes (chunks of 15)
+    _check(qv.to_metrics(mask), _host_frame(qv, mask=mask), f32)
+    many = rng.integers(0, 40, shape).astype(np.float32)
+    maskf = dm.MedicalVolume(many, np.eye(4))
+    _check(qv.to_metrics(maskf, bounds=(0, 100)), _host_frame(qv, mask=maskf, bounds=(0, 100)), f32)
+
+
+def test_whole_map_and_small_counts():
+    v = _map((40, 40, 10), np.float64, 3)
+    qv = T2(dm.MedicalVolume(v, np.eye(4)))
+    _check(qv.to_metrics(), _host_frame(qv))
+    _check(qv.to_metrics(bounds=(0, 100)), _host_frame(qv, bounds=(0, 100)))
+    # regions of 0, 1, 2, 3 voxels: the even / odd median rule on the smallest cases
+    lab = np.zeros(v.shape, np.int16)
+    flat = lab.reshape(-1)
+    finite = np.flatnonzero(np.isfinite(v.reshape(-1)))
+    flat[finite[0]] = 1
+    flat[finite[1:3]] = 2
+    flat[finite[3:6]] = 3
+    mask = dm.MedicalVolume(lab, np.eye(4))
+    labels = {1: "one", 2: "two", 3: "three", 7: "none"}
+    _check(qv.to_metrics(mask, labels), _host_frame(qv, mask=mask, labels=labels))
+
+
+def test_raw_entry_and_errors():
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(100_003).astype(np.float32) * 1e3
+    out = L.region_stats_host(v)
+    assert out.shape == (1, 4) and out[0, 0] == v.size
+    assert out[0, 3] == np.median(v) and abs(out[0, 1] - v.astype(np.float64).mean()) < 1e-9
+    lab = rng.integers(0, 3, v.size)
+    with pytest.raises(ValueError):
+        L.region_stats_host(v, lab, keys=range(1, 20))
+    with pytest.raises(ValueError):
+        L.region_stats_host(v, lab[:10], keys=(1,))
+    empty = L.region_stats_host(np.zeros(0, np.float64))
+    assert empty[0, 0] == 0 and np.isnan(empty[0, 1:]).all()
+
+
+def test_full_size_map_against_numpy():
+    """512 x 512 x 160 rounded T2-like map with a 4-label mask: exact counts / medians, means to 1e-12."""
+    rng = np.random.default_rng(7)
+    shape = (512, 512, 160)
+    v = np.around(rng.uniform(0, 100, shape), 1)
+    v[::7, ::5] = 0.0
+    lab = (rng.integers(0, 50, shape) // 10 % 5).astype(np.uint8)  # labels 0..4
+    qv = T2(dm.MedicalVolume(v, np.eye(4)))
+    mask = dm.MedicalVolume(lab, np.eye(4))
+    labels = {1: "fc", 2: "tc", 3: "pc", 4: "men"}
+    gpu = qv.to_metrics(mask, labels, bounds=(0, 100))
+    host = _host_frame(qv, mask=mask, labels=labels, bounds=(0, 100))
+    _check(gpu, host)

@@ -99,7 +99,8 @@ class QmriDessArgs(ctypes.Structure):
 class QmriRegionStatsArgs(ctypes.Structure):
     _fields_ = [
         ("values", ctypes.c_void_p), ("v_dtype", ctypes.c_int32), ("labels", ctypes.c_void_p), ("N", ctypes.c_int64),
-        ("nkeys", ctypes.c_int32), ("label_keys", ctypes.c_void_p), ("use_bounds", ctypes.c_int32),
+        ("nkeys", ctypes.c_int32), ("l_kind", ctypes.c_int32), ("label_keys", ctypes.c_void_p),
+        ("use_bounds", ctypes.c_int32),
         ("lo", ctypes.c_double), ("hi", ctypes.c_double), ("closed", ctypes.c_int32), ("out", ctypes.c_void_p),
         ("device", ctypes.c_int32),
     ]
@@ -629,7 +630,12 @@ def region_stats_host(values, labels=None, keys=(), bounds=None, closed="right",
     keep = [v]
     keys = [int(k) for k in keys]
     if labels is not None:
-        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        lab = np.ascontiguousarray(labels)
+        kind = {np.dtype(np.int32): 0, np.dtype(np.uint8): 1, np.dtype(np.bool_): 1, np.dtype(np.int16): 2}.get(lab.dtype)
+        if kind is None:  # other integer widths / integer-valued floats: one conversion pass on the host
+            lab, kind = lab.astype(np.int32), 0
+        lab = lab.reshape(-1)
+        a.l_kind = kind
         if lab.size != v.size:
             raise ValueError("label map and values differ in size")
         if len(keys) > MAX_REGIONS - 1:

@@ -880,22 +880,23 @@ int qmri_region_stats_host(const qmri_region_stats_args *a) {
     if (nkeys < 0 || nkeys > QMRI_MAX_REGIONS - 1) return fail(QMRI_ERR_ARG, "nkeys must be 0..%d", QMRI_MAX_REGIONS - 1);
     if (nkeys > 0 && !a->label_keys) return fail(QMRI_ERR_ARG, "label_keys is NULL");
     if (a->use_bounds && (a->closed < 0 || a->closed > 3)) return fail(QMRI_ERR_ARG, "closed must be 0..3");
+    if (a->labels && (a->l_kind < 0 || a->l_kind > 2)) return fail(QMRI_ERR_ARG, "l_kind must be 0 (int32), 1 (uint8) or 2 (int16)");
+    const size_t ls = a->l_kind == 0 ? 4 : (a->l_kind == 1 ? 1 : 2);
     DeviceCtx *ctx = nullptr;
     HIP_TRY(hipSetDevice(a->device));
     HIP_TRY(ctx_get(a->device, &ctx));
     const size_t es = a->v_dtype == QMRI_F64 ? 8 : 4;
     const size_t n = (size_t)(a->N > 0 ? a->N : 1);
-    void *dv = nullptr, *dstate = nullptr;
-    int *dl = nullptr;
+    void *dv = nullptr, *dstate = nullptr, *dl = nullptr;
     double *dout = nullptr;
     hipError_t e = hipMalloc(&dv, n * es);
-    if (e == hipSuccess && a->labels) e = hipMalloc(reinterpret_cast<void **>(&dl), n * 4);
+    if (e == hipSuccess && a->labels) e = hipMalloc(&dl, n * ls);
     if (e == hipSuccess) e = hipMalloc(&dstate, qmri::region_stats_state_bytes());
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), (size_t)(nkeys + 1) * 4 * 8);
     if (e == hipSuccess && a->N > 0) e = hipMemcpy(dv, a->values, (size_t)a->N * es, hipMemcpyHostToDevice);
-    if (e == hipSuccess && a->labels && a->N > 0) e = hipMemcpy(dl, a->labels, (size_t)a->N * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && a->labels && a->N > 0) e = hipMemcpy(dl, a->labels, (size_t)a->N * ls, hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = qmri::region_stats_launch(dv, a->v_dtype == QMRI_F64, dl, a->N, nkeys, a->label_keys, a->use_bounds, a->lo, a->hi,
+        e = qmri::region_stats_launch(dv, a->v_dtype == QMRI_F64, dl, a->l_kind, a->N, nkeys, a->label_keys, a->use_bounds, a->lo, a->hi,
                                       a->closed, dstate, dout, ctx->num_cu, nullptr);
     if (e == hipSuccess) e = hipMemcpy(a->out, dout, (size_t)(nkeys + 1) * 4 * 8, hipMemcpyDeviceToHost);
     (void)hipFree(dv);

@@ -169,7 +169,8 @@ hipError_t rss_launch(const void *e1, const void *e2, int dtype, long long n, in
                       hipStream_t stream);
 
 size_t region_stats_state_bytes();
-hipError_t region_stats_launch(const void *values, int f64, const int *labels, long long N, int nkeys, const int *keys,
+hipError_t region_stats_launch(const void *values, int f64, const void *labels, int l_kind, long long N, int nkeys,
+                               const int *keys,
                                int use_bounds, double lo, double hi, int closed, void *state, double *out_dev,
                                int num_cu, hipStream_t stream);
 

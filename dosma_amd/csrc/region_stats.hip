@@ -13,7 +13,7 @@
 //           bins per (region, statistic) in LDS, merged with atomics; a one-block kernel between passes picks the
 //           bin that holds the wanted rank and extends the key prefix -- no host round trip.
 //
-// HBM-bound streaming: (sizeof(value) + 4) bytes per voxel per pass, 10 passes.
+// Streaming: (sizeof(value) + sizeof(label)) bytes per voxel per pass, 10 passes.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -30,7 +30,8 @@ constexpr int kMaxR = QMRI_MAX_REGIONS;
 
 struct StatsK {
     const void *values;
-    const int *labels;  // nullptr: single region "total"
+    const void *labels;  // nullptr: single region "total"
+    int l_kind;          // 0 int32, 1 uint8, 2 int16
     long long N;
     int f64;
     int nkeys;  // labelled regions; region nkeys is "total"
@@ -68,7 +69,9 @@ __device__ __forceinline__ bool classify(const StatsK &K, long long i, double v,
         total = true;
         return true;
     }
-    const int l = K.labels[i];
+    const int l = K.l_kind == 0 ? static_cast<const int *>(K.labels)[i]
+                : K.l_kind == 1 ? (int)static_cast<const unsigned char *>(K.labels)[i]
+                                : (int)static_cast<const short *>(K.labels)[i];
     if (l <= 0) {
         // the reference's label_map == key also matches keys <= 0 on voxels the bounds did not zero; "total" is label > 0
         for (int r = 0; r < K.nkeys; ++r)
@@ -236,13 +239,15 @@ __global__ void finish_kernel(const StatsState *S, int nreg, int f64, double *ou
 // values / labels: device pointers; out_dev: device [nkeys + 1][4]; state: device scratch of region_stats_state_bytes()
 size_t region_stats_state_bytes() { return sizeof(StatsState); }
 
-hipError_t region_stats_launch(const void *values, int f64, const int *labels, long long N, int nkeys, const int *keys,
+hipError_t region_stats_launch(const void *values, int f64, const void *labels, int l_kind, long long N, int nkeys,
+                               const int *keys,
                                int use_bounds, double lo, double hi, int closed, void *state, double *out_dev,
                                int num_cu, hipStream_t stream) {
     if (nkeys < 0 || nkeys > kMaxR - 1) return hipErrorInvalidValue;
     StatsK K;
     K.values = values;
     K.labels = labels;
+    K.l_kind = l_kind;
     K.N = N;
     K.f64 = f64;
     K.nkeys = labels ? nkeys : 0;

@@ -146,7 +146,6 @@ class QuantitativeValue(ABC):
                 return None
         elif lab.dtype.kind not in "iub":
             return None
-        lab = lab.astype(np.int32, copy=False)
         rows, total = [], None
         step = _lib.MAX_REGIONS - 1
         for i in range(0, max(len(keys), 1), step):

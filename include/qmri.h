@@ -311,9 +311,10 @@ int qmri_rss_host(const void *echo1, const void *echo2, int32_t dtype, int64_t N
 typedef struct qmri_region_stats_args {
     const void *values;        /* [N] map */
     int32_t v_dtype;           /* QMRI_F32 | QMRI_F64 */
-    const int32_t *labels;     /* [N] label map, or NULL: one region "total" over all voxels */
+    const void *labels;        /* [N] label map (element type l_kind), or NULL: one region "total" over all voxels */
     int64_t N;
     int32_t nkeys;             /* number of labelled regions (<= QMRI_MAX_REGIONS - 1), 0 if labels == NULL */
+    int32_t l_kind;            /* label element type: 0 int32, 1 uint8, 2 int16 */
     const int32_t *label_keys; /* [nkeys] (host memory in both entry points) */
     int32_t use_bounds;        /* bounds = (lo, hi) */
     double lo, hi;

@@ -136,6 +136,7 @@ EXPORTS = (
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
+    "qmri_region_stats_device",
 )
 
 _lib = None
@@ -652,6 +653,35 @@ def region_stats_host(values, labels=None, keys=(), bounds=None, closed="right",
     out = np.empty((len(keys) + 1, 4), dtype=np.float64)
     a.out, a.device = _ptr(out), _dev(device)
     check(lib.qmri_region_stats_host(ctypes.byref(a)))
+    return out
+
+
+def region_stats_device(values_ptr, v_dtype, n, labels_ptr=None, l_dtype=None, keys=(), bounds=None, closed="right",
+                        device=None, stream=None):
+    """The same statistics for a map (and label map) that already live on the GPU: raw device pointers, e.g.
+    ``tensor.data_ptr()``; ``v_dtype`` float32 / float64, ``l_dtype`` int32 / uint8 / int16."""
+    lib = load()
+    require_device()
+    a = QmriRegionStatsArgs()
+    a.values, a.v_dtype, a.N = ctypes.c_void_p(int(values_ptr)), qdtype(v_dtype), int(n)
+    keys = [int(k) for k in keys] if labels_ptr is not None else []
+    keep = []
+    if labels_ptr is not None:
+        kind = {np.dtype(np.int32): 0, np.dtype(np.uint8): 1, np.dtype(np.int16): 2}.get(np.dtype(l_dtype))
+        if kind is None:
+            raise ValueError(f"unsupported label dtype {l_dtype}")
+        if len(keys) > MAX_REGIONS - 1:
+            raise ValueError(f"at most {MAX_REGIONS - 1} labelled regions per call")
+        ks = np.asarray(keys, dtype=np.int32)
+        a.labels, a.l_kind, a.nkeys, a.label_keys = ctypes.c_void_p(int(labels_ptr)), kind, len(keys), _ptr(ks)
+        keep.append(ks)
+    if bounds is not None:
+        if closed not in _CLOSED:
+            raise ValueError(f"`closed={closed}` is not supported")
+        a.use_bounds, a.lo, a.hi, a.closed = 1, float(bounds[0]), float(bounds[1]), _CLOSED[closed]
+    out = np.empty((len(keys) + 1, 4), dtype=np.float64)
+    a.out, a.device = _ptr(out), _dev(device)
+    check(lib.qmri_region_stats_device(ctypes.byref(a), ctypes.c_void_p(int(stream)) if stream else None))
     return out
 
 

@@ -907,4 +907,28 @@ int qmri_region_stats_host(const qmri_region_stats_args *a) {
     return QMRI_OK;
 }
 
+int qmri_region_stats_device(const qmri_region_stats_args *a, void *hip_stream) {
+    if (!a || !a->values || !a->out) return fail(QMRI_ERR_ARG, "NULL argument");
+    if (a->v_dtype != QMRI_F32 && a->v_dtype != QMRI_F64) return fail(QMRI_ERR_ARG, "values must be f32 or f64");
+    if (a->N < 0) return fail(QMRI_ERR_ARG, "N < 0");
+    const int nkeys = a->labels ? a->nkeys : 0;
+    if (nkeys < 0 || nkeys > QMRI_MAX_REGIONS - 1) return fail(QMRI_ERR_ARG, "nkeys must be 0..%d", QMRI_MAX_REGIONS - 1);
+    if (nkeys > 0 && !a->label_keys) return fail(QMRI_ERR_ARG, "label_keys is NULL");
+    if (a->use_bounds && (a->closed < 0 || a->closed > 3)) return fail(QMRI_ERR_ARG, "closed must be 0..3");
+    if (a->labels && (a->l_kind < 0 || a->l_kind > 2)) return fail(QMRI_ERR_ARG, "l_kind must be 0 (int32), 1 (uint8) or 2 (int16)");
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    AsyncScratch state, dout;
+    HIP_TRY(state.alloc(qmri::region_stats_state_bytes(), st));
+    HIP_TRY(dout.alloc((size_t)(nkeys + 1) * 4 * 8, st));
+    HIP_TRY(qmri::region_stats_launch(a->values, a->v_dtype == QMRI_F64, a->labels, a->l_kind, a->N, nkeys, a->label_keys,
+                                      a->use_bounds, a->lo, a->hi, a->closed, state.p, static_cast<double *>(dout.p),
+                                      ctx->num_cu, st));
+    HIP_TRY(hipMemcpyAsync(a->out, dout.p, (size_t)(nkeys + 1) * 4 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return QMRI_OK;
+}
+
 }  // extern "C"

@@ -324,6 +324,9 @@ typedef struct qmri_region_stats_args {
 } qmri_region_stats_args;
 #define QMRI_MAX_REGIONS 16
 int qmri_region_stats_host(const qmri_region_stats_args *args); /* values / labels in host memory, synchronous */
+/* values / labels already on the device (e.g. the tc map a fit has just written); label_keys and out stay host
+ * pointers; the call enqueues on `hip_stream` and returns after the 4 x (nkeys + 1) results have arrived */
+int qmri_region_stats_device(const qmri_region_stats_args *args, void *hip_stream);
 
 /* Mean kernel time in ms of the last qmri_monoexp_fit_device call on this thread that was issued
  * with timing enabled (qmri_set_timing(1)); measured with hipEvents on the launch stream. */

@@ -120,3 +120,22 @@ def test_full_size_map_against_a_histogram():
         std = float(np.sqrt((h * (vals - mean) ** 2).sum() / n))
         assert g["# Voxels"] == n and g["Median"] == 0.5 * (lo + hi)
         assert abs(g["Mean"] - mean) < 1e-11 * mean and abs(g["Std"] - std) < 1e-10 * std
+
+
+def test_device_pointer_entry_matches_the_host_entry():
+    import torch
+
+    rng = np.random.default_rng(9)
+    n = 300_001
+    v = rng.uniform(-5, 105, n)
+    v[::11] = np.nan
+    lab = rng.integers(0, 4, n).astype(np.uint8)
+    want = L.region_stats_host(v, lab, keys=(1, 2, 3), bounds=(0, 100), closed="both")
+    dev = torch.device("cuda", 0)
+    tv, tl = torch.from_numpy(v).to(dev), torch.from_numpy(lab).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    got = L.region_stats_device(tv.data_ptr(), np.float64, n, tl.data_ptr(), np.uint8, keys=(1, 2, 3), bounds=(0, 100),
+                                closed="both", stream=st)
+    assert np.array_equal(got[:, [0, 3]], want[:, [0, 3]]) and np.allclose(got, want, rtol=1e-12, equal_nan=True)
+    whole = L.region_stats_device(tv.data_ptr(), np.float64, n, stream=st)
+    assert whole[0, 0] == np.isfinite(v).sum() and whole[0, 3] == np.nanmedian(v)

@@ -5,29 +5,38 @@
     (N > 1: launched by the driver through torch.distributed.run, one rank per GPU)
 
 Metric (BASELINE.json): voxel-fits/sec, 8-echo mono-exponential T2 fit of a 512x512x160 volume
-(config[1]: "T2 monoexponential fit, 512x512x160 x 8 echoes, fp32, 1 MI355X").
+(configs[1]: "T2 monoexponential fit, 512x512x160 x 8 echoes, fp32, 1 MI355X") + UNet2D slices/sec.
 
 A "step" is one pass of the hot path over one synthetic volume per GPU: ONE launch of the fused
 kernel (LM fit + MonoExponentialFit post-processing) on (8, 41 943 040) fp32 samples already
 resident in HBM, writing fp32 (a, tc) + r2 -- i.e. `MonoExponentialFit().fit(x, y)` with the
-reference's defaults (tc0 = 30 -> p0 = (1, -1/30), bounds (0, 100), r2 >= 0.9, 1 decimal).
-The scan-class recipe (tc0 = "polyfit", 3 decimals) is timed too and reported under "runs".
-Multi-GPU: volumes are independent, so each rank fits its own volume (weak scaling, no data-path
-collective); the only communication is the barrier / max-reduction of the timing.
+reference's defaults (tc0 = 30 -> p0 = (1, -1/30), bounds (0, 100), r2 >= 0.9, 1 decimal).  `value` is that rate at
+every N (weak scaling: one volume per GPU per step, no data-path collective), so the per-N values are comparable.
+Reported beside it in the same JSON line:
 
-Rank 0 prints ONE JSON line (see the task contract) including
-  "roofline":     algorithmic HBM bytes (44 B/voxel = 8 x 4 B in + 12 B out) / kernel
-                  time measured with HIP events on the launch stream, vs the 8 TB/s HBM3E peak;
-  "cpu_baseline": the reference's own call pattern (one scipy.optimize.curve_fit per voxel under
-                  multiprocessing.Pool, dosma/core/fitting.py:855-868, 1026-1073) timed on this
-                  host's cores on a bounded sample of the same volume (N = 1 runs only).
+  "parity"       what the TIMED kernel wrote, checked after the timed loop against the oracle's C restatement on the
+                 SURVEY 8(d) sample (first 20 000 tissue + 1 000 background voxels) -- the oracle is the checker here,
+                 never inside a timed region;
+  "runs"         the f64-output variant (56 B/voxel, what the drop-in API returns), the scan-class recipe
+                 (tc0 = "polyfit", 3 decimals) and BASELINE configs[2] (T1rho ROI);
+  "unet2d"       UNet2D slices/s at 384x384x160 (configs[3]): `value` = the mode that meets the 1e-3 logit bar,
+                 the plain-bf16 mode beside it;
+  "cfg5"         BASELINE configs[4]: 8 volumes per GPU (64 at N = 8), fit + 512x512 UNet segmentation per volume,
+                 sharded by dosma_amd.dist.run_batch, UNet weights made on rank 0 and broadcast once (RCCL);
+  "roofline"     algorithmic HBM bytes (44 B/voxel = 8 x 4 B in + 12 B out) / kernel
+                 time measured with HIP events on the launch stream, vs the 8 TB/s HBM3E peak;
+  "cpu_baseline" the reference's own call pattern (one scipy.optimize.curve_fit per voxel, serial and under
+                 multiprocessing.Pool, dosma/core/fitting.py:855-868, 1026-1073) timed on this
+                 host's cores on a bounded sample of the same volume (N = 1 runs only).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
 import time
+from functools import partial
 
 import numpy as np
 
@@ -38,7 +47,9 @@ SHAPE = (512, 512, 160)
 E = 8
 TE = np.arange(1, E + 1) * 10.0  # ms
 BYTES_PER_VOXEL = 4 * E + 4 * 3  # fp32 echoes in, fp32 (a, tc, r2) out -- SURVEY.md section 8(d)
+BYTES_PER_VOXEL_F64 = 4 * E + 8 * 3  # float64 outputs like the reference returns (56 B)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+P0_A = (1.0, -1 / 30.0)
 
 
 def make_volume(torch, device, seed):
@@ -55,21 +66,58 @@ def make_volume(torch, device, seed):
     return y.contiguous()
 
 
-def make_args(L, y, popt, r2, stream, recipe):
+def make_args(L, y, popt, r2, stream, recipe, out_dtype=None):
     a = L.default_args()
     n = y.shape[1]
     a.y, a.y_dtype, a.E, a.N, a.ld = y.data_ptr(), L.QMRI_F32, E, n, n
     a.x = TE.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    a.popt, a.r2, a.out_dtype = popt.data_ptr(), r2.data_ptr(), L.QMRI_F32
+    a.popt, a.r2, a.out_dtype = popt.data_ptr(), r2.data_ptr(), (L.QMRI_F32 if out_dtype is None else out_dtype)
     a.stream = stream
     bounds = ((-np.inf, np.inf), (0.0, 100.0))
     if recipe == "A":  # MonoExponentialFit() defaults
-        a.init, a.a0, a.b0 = L.INIT_SCALAR, 1.0, -1 / 30.0
+        a.init, a.a0, a.b0 = L.INIT_SCALAR, P0_A[0], P0_A[1]
         L.set_post(a, inv_abs_b=True, bounds=bounds, r2_threshold=0.9, nan_to_num=0.0, decimals=1)
     else:              # scan classes: tc0="polyfit", decimal_precision=3
         a.init = L.INIT_LOGLIN
         L.set_post(a, inv_abs_b=True, bounds=bounds, r2_threshold=0.9, nan_to_num=0.0, decimals=3)
     return a
+
+
+def parity_sample(L, torch, y, popt, r2):
+    """What the timed kernel wrote vs the oracle (SURVEY.md 8(d) cfg2 parity sample).  `popt` / `r2` are the output
+    buffers of the LAST TIMED LAUNCH (recipe A, fp32): post-processed (a, tc) and r2 of every voxel."""
+    from oracle import fit_oracle as fo  # the checker (never inside a timed region)
+
+    nz = (y != 0).any(dim=0)
+    idx = torch.cat([torch.nonzero(nz)[:20000, 0], torch.nonzero(~nz)[:1000, 0]])
+    ys = y[:, idx].cpu().numpy().astype(np.float64)
+    got_p = popt[idx].cpu().numpy().astype(np.float64)
+    got_r = r2[idx].cpu().numpy().astype(np.float64)
+    _, ref_r, ref_p = fo.monoexp_fit_arrays(TE, ys, bounds=(0, 100), tc0=30.0, r2_threshold=0.9, decimal_precision=None)
+    same_zero = (got_p == 0) == (ref_p == 0)
+    both = (ref_p != 0) & (got_p != 0)
+    with np.errstate(all="ignore"):
+        rel = np.abs(got_p[both] / ref_p[both] - 1)
+    # MINPACK's own trajectory: an extra UNTIMED launch of the same kernel on the sample with the raw outputs and the
+    # per-voxel stop code / evaluation count, against the C restatement run with full_output
+    raw = L.monoexp_fit_host(TE, ys.astype(np.float32), p0=P0_A, want_info=True)
+    cp, cr, cinfo, cnfev = fo.curve_fit_c(TE, ys.astype(np.float32), P0_A, full_output=True)
+    ok = ~np.isnan(cp[:, 0])
+    with np.errstate(all="ignore"):
+        raw_rel = np.abs(raw["popt"][ok] / cp[ok] - 1)
+    return {
+        "n": int(idx.numel()), "sample": "first 20000 tissue + first 1000 background voxels of the timed volume",
+        "timed_outputs": {"max_rel": float(rel.max()) if rel.size else 0.0,
+                          "zero_pattern_equal_frac": float(same_zero.mean()),
+                          "r2_max_abs": float(np.abs(got_r - ref_r).max()),
+                          "what": "popt (a, tc) and r2 written by the last timed launch (fp32) vs "
+                                  "oracle.fit_oracle.monoexp_fit_arrays (float64)"},
+        "max_rel": float(np.nanmax(raw_rel)) if raw_rel.size else 0.0,
+        "nfev_equal_frac": float((raw["nfev"] == cnfev).mean()),
+        "info_class_equal_frac": float((((raw["info"] >= 1) & (raw["info"] <= 4)) == ((cinfo >= 1) & (cinfo <= 4))).mean()),
+        "failed_equal": bool(np.array_equal(np.isnan(raw["popt"][:, 0]), ~ok)),
+        "tolerance": "north_star: popt / r2 within 1e-4 relative of scipy.optimize.curve_fit",
+    }
 
 
 def bench_t1rho_roi(L, lib, torch, device, local_rank, args):
@@ -120,9 +168,19 @@ def bench_t1rho_roi(L, lib, torch, device, local_rank, args):
             "kernel": lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode()}
 
 
+def _ref_style_voxel(y_i, x, p0, ftol, maxfev, eps):
+    """One voxel the way the reference's `_curve_fit` treats it (dosma/core/fitting.py:1026-1073): skip rule,
+    scipy.optimize.curve_fit(func, x, y, p0, ftol, maxfev), r2, RuntimeError -> NaN / 0.  Module level so that
+    `partial(...)` of it pickles ONCE per chunk like the reference's `partial(_curve_fit, ...)` (:844-853)."""
+    from oracle import fit_oracle as fo
+
+    return fo._one_voxel_scipy((fo.monoexponential, x, y_i, p0, ftol, maxfev, eps, 2, False))
+
+
 def cpu_baseline(y_dev, cores_cap=None):
-    """The reference's per-voxel scipy loop under multiprocessing.Pool(all cores) (fitting.py:855-868)
-    on a bounded sample of the bench volume: ~6000 voxels per core (a few seconds per core)."""
+    """The reference's per-voxel scipy loop (fitting.py:855-868) on a bounded sample of the bench volume, timed on
+    this host: serial (num_workers = 0), Pool(1) (num_workers = 1) and Pool(all cores) with
+    chunksize 1000 -- rows of y_T mapped through ONE partial, exactly the reference's `p.map(fitter, y_T, chunksize)`."""
     import multiprocessing as mp
 
     import scipy
@@ -137,31 +195,44 @@ def cpu_baseline(y_dev, cores_cap=None):
         cores = min(cores, cores_cap)
     n = int(min(y_dev.shape[1], 6000 * cores, 2_000_000))
     ys = y_dev[:, :n].cpu().numpy()
-    p0 = (1.0, -1 / 30.0)
-    jobs = [(fo.monoexponential, TE, ys[:, i], p0, fo.FTOL, fo.MAXFEV, fo.R2_EPS, 2, False)
-            for i in range(n)]
-    with mp.Pool(cores) as pool:
-        pool.map(fo._one_voxel_scipy, jobs[: cores * 4], chunksize=4)  # start the workers
+    y_T = np.ascontiguousarray(ys.T)  # (N, E): one row per voxel, like the reference's y.T (:833)
+    fitter = partial(_ref_style_voxel, x=TE, p0=P0_A, ftol=fo.FTOL, maxfev=fo.MAXFEV, eps=fo.R2_EPS)
+    # serial (num_workers = 0) and one worker (num_workers = 1) on a small slice
+    m1 = min(n, 12000)
+    t = time.perf_counter()
+    for i in range(m1):
+        fitter(y_T[i])
+    dt_serial = time.perf_counter() - t
+    with mp.Pool(1) as pool:
+        pool.map(fitter, y_T[:64], chunksize=8)
         t = time.perf_counter()
-        pool.map(fo._one_voxel_scipy, jobs, chunksize=1000)
+        pool.map(fitter, y_T[:m1], chunksize=1000)
+        dt_one = time.perf_counter() - t
+    with mp.Pool(cores) as pool:
+        pool.map(fitter, y_T[: cores * 4], chunksize=4)  # start the workers
+        t = time.perf_counter()
+        pool.map(fitter, y_T, chunksize=1000)
         dt = time.perf_counter() - t
     # single-thread C restatement of MINPACK on a slice, for scale
     m = min(n, 200_000)
     t = time.perf_counter()
-    fo.curve_fit_c(TE, ys[:, :m], p0, threads=1)
+    fo.curve_fit_c(TE, ys[:, :m], P0_A, threads=1)
     dt_c = time.perf_counter() - t
-    # the same C restatement on every core (pthreads inside the library): the best this host can do with the algorithm
-    fo.curve_fit_c(TE, ys[:, : min(n, 4 * cores)], p0, threads=cores)  # start the threads
+    # the same C restatement on every core (threads inside the library): the best this host can do with the algorithm
+    fo.curve_fit_c(TE, ys[:, : min(n, 4 * cores)], P0_A, threads=cores)  # start the threads
     t = time.perf_counter()
-    fo.curve_fit_c(TE, ys, p0, threads=cores)
+    fo.curve_fit_c(TE, ys, P0_A, threads=cores)
     dt_call = time.perf_counter() - t
     return {
         "value": n / dt, "unit": "voxel-fits/s", "cores": cores, "kind": "port",
         "sample": (f"first {n} voxels of the bench volume (70% tissue / 30% zero background): one "
-                   f"scipy.optimize.curve_fit per voxel under multiprocessing.Pool({cores}), "
-                   f"chunksize 1000 (the reference's call pattern), scipy {scipy.__version__}, "
-                   f"{dt:.1f} s wall, pool start-up excluded"),
+                   f"scipy.optimize.curve_fit per voxel, rows of y.T through multiprocessing.Pool({cores}).map("
+                   f"partial(fitter), chunksize=1000) (the reference's call pattern, fitting.py:860-868), scipy "
+                   f"{scipy.__version__}, {dt:.1f} s wall, pool start-up excluded"),
         "per_core": n / dt / cores,
+        "num_workers_0_serial": m1 / dt_serial,
+        "num_workers_1": m1 / dt_one,
+        "serial_sample": f"first {m1} voxels",
         "c_restatement_1thread": m / dt_c,
         "c_restatement_all_cores": n / dt_call,
     }
@@ -202,16 +273,19 @@ def bench_dess(L, lib, torch, device, local_rank, world, args, barrier):
 UNET_HW = 384
 UNET_SLICES = 160
 UNET_GFLOP_PER_SLICE = 70.79   # 35.39 GMAC per 384x384 slice
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+UNET_PARITY_MODE = "bf16x3"      # the precision mode whose logits meet north_star's 1e-3 (tests/test_unet_gpu.py)
 
 
 def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device):
-    """UNet2D slices/s (BASELINE.json configs[3]: IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv).
+    """UNet2D slices/s (BASELINE.json configs[3]: IWOAIOAIUnet2DNormalized, 384x384x160, MFMA conv).
 
     A step = one whole volume (160 sagittal slices incl. whole-volume whitening) per GPU through the
-    network, input resident in HBM, logits + masks written to HBM.  Random He-initialised weights of
-    the reference architecture (the trained .h5 is not distributed; throughput does not depend on
-    the values) and random-normal input (not zeros: DVFS, cdna_hip_programming.md rule 25)."""
+    network, input resident in HBM, logits + masks written to HBM.  `value` is the PARITY mode (logits within 1e-3 of
+    the fp64 restatement: three 16-bit MFMAs per product); the plain-bf16 mode (one MFMA per product, logits within
+    ~0.25) is reported beside it.  Random He-initialised weights of the reference architecture (the trained .h5 is
+    not distributed; throughput does not depend on the values) and random-normal input (not zeros: DVFS,
+    cdna_hip_programming.md rule 25)."""
     from dosma_amd.models import weights as W
 
     eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), UNET_HW, UNET_HW,
@@ -223,7 +297,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     stream = torch.cuda.current_stream(device)
     steps = max(2, args.steps // 4)
     res = {}
-    for prec in ("bf16x3", "bf16"):
+    for prec in ("bf16", UNET_PARITY_MODE):
         eng.set_precision(prec)
         for _ in range(max(1, args.warmup // 2)):
             eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
@@ -241,17 +315,128 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
             el = t[0].item()
         res[prec] = UNET_SLICES * world * steps / el
     eng.close()
-    tf = res["bf16"] / world * UNET_GFLOP_PER_SLICE / 1e3
+    tf = res[UNET_PARITY_MODE] / world * UNET_GFLOP_PER_SLICE / 1e3
+    tf16 = res["bf16"] / world * UNET_GFLOP_PER_SLICE / 1e3
     return {
-        "metric": "UNet2D slices/sec (IWOAIOAIUnet2DNormalized, 384x384x160, bf16 MFMA conv)",
-        "value": res["bf16"], "unit": "slices/s", "steps": steps, "batch": args.unet_batch,
-        "precision": "plain-bf16 mode: bf16 weights and activations (in HBM too), fp32 accumulate; the split-bf16x3 parity mode is reported beside it",
-        "slices_per_s_bf16x3": res["bf16x3"],
+        "metric": "UNet2D slices/sec (IWOAIOAIUnet2DNormalized, 384x384x160, MFMA conv)",
+        "value": res[UNET_PARITY_MODE], "unit": "slices/s", "steps": steps, "batch": args.unet_batch,
+        "precision": f"{UNET_PARITY_MODE}: 16-bit hi + lo operand parts, hi*hi + hi*lo + lo*hi on MFMA (3 per product), "
+                     "fp32 accumulate -- the mode whose logits are within 1e-3 of the fp64 restatement "
+                     "(tests/test_unet_gpu.py); the plain-bf16 mode (1 MFMA per product, logits within ~0.25) is "
+                     "`slices_per_s_bf16`",
+        "slices_per_s_bf16": res["bf16"],
         "data": "synthetic (random He weights of the reference architecture, random-normal input)",
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_BF16_PEAK_TFLOPS, "gflop_per_slice": UNET_GFLOP_PER_SLICE,
+                     "mfma_issued_frac": 3 * tf / MFMA_BF16_PEAK_TFLOPS,
+                     "note": "achieved = ALGORITHMIC flops (70.79 GFLOP per slice); the parity mode issues 3 MFMAs per "
+                             "product, so the matrix pipes are busy 3x that fraction (mfma_issued_frac)",
+                     "bf16_mode": {"achieved": tf16, "frac": tf16 / MFMA_BF16_PEAK_TFLOPS},
                      "traffic": None},
     }
+
+
+def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
+    """BASELINE.json configs[4] / SURVEY 8(d) cfg5: a batch of knee volumes (512x512x160 x 8 echoes), 8 per GPU
+    (64 at N = 8), per volume the mono-exponential fit + the UNet2D segmentation of one 512x512x160 channel, sharded on
+    the batch axis by dosma_amd.dist.run_batch (volume v -> rank v mod world, no collective on the data path).
+    The UNet weights are created on rank 0 only and reach the other ranks through ONE broadcast (RCCL over xGMI).
+    Host feed: the volumes are generated on-device from seeds and are resident in HBM before the clock starts
+    (86 GB of fp32 input at N = 8 would otherwise come over PCIe); the host-fed rate of ONE volume per rank through the
+    host entry -- all ranks at once, so host memory bandwidth is shared like in a real N-GPU run -- is `host_feed`."""
+    from dosma_amd.models import weights as W
+
+    per_gpu = args.cfg5_volumes_per_gpu
+    n_vol = per_gpu * world
+    n = vol0.shape[1]
+    H = W_ = 512
+    S = 160
+    # ---- weights: rank 0's values everywhere ----
+    t0 = time.perf_counter()
+    wts = W.random_weights(seed=0 if rank == 0 else 1000 + rank)  # other ranks: same shapes, different values
+    t_make = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wts = qd.broadcast_weights(wts, src=0)
+    t_bcast = time.perf_counter() - t0
+    checksum = float(sum(float(np.asarray(v, dtype=np.float64).sum()) for v in wts.values()))
+    sums = qd.allgather_scalars([checksum])[:, 0]
+    wbytes = int(sum(np.asarray(v).size for v in wts.values()) * 4)
+    eng = L.Unet2dEngine(W.to_abi_order(wts), H, W_, max_batch=args.cfg5_unet_batch, precision=UNET_PARITY_MODE,
+                         device=local_rank)
+    stream = torch.cuda.current_stream(device)
+    popt = torch.empty((n, 2), dtype=torch.float32, device=device)
+    r2 = torch.empty(n, dtype=torch.float32, device=device)
+    mask = torch.empty((S, H, W_, 4), device=device, dtype=torch.uint8)
+    vols = {}
+
+    def setup(mine):
+        for v in mine:  # resident in HBM before the timed region (on-device generation from the volume's seed)
+            vols[v] = vol0 if v == rank else make_volume(torch, device, 20260928 + v)
+        torch.cuda.synchronize(device)
+
+    def per_volume(v):
+        y = vols[v]
+        t = time.perf_counter()
+        a = make_args(L, y, popt, r2, stream.cuda_stream, "A")
+        a.device = local_rank
+        L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
+        torch.cuda.synchronize(device)
+        t_fit = time.perf_counter() - t
+        t = time.perf_counter()
+        # one 512 x 512 x 160 channel of the volume (echo 1), as 160 slices of 512 x 512 (the flat echo row
+        # reinterpreted: synthetic voxels carry no geometry), whole-volume whitening like IWOAIOAIUnet2DNormalized
+        eng.forward_device(y[0].data_ptr(), S, None, mask.data_ptr(), whiten=True, stream=stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        t_seg = time.perf_counter() - t
+        fitted = float((popt[:, 1] > 0).sum().item())
+        return {"fit_s": t_fit, "seg_s": t_seg, "voxels": float(n), "slices": float(S), "t2_nonzero": fitted,
+                "mask_voxels": float(mask[..., 0].sum().item())}
+
+    # warm-up (kernel module load, workspace allocation) on this rank's own volume, then the batch
+    setup([rank])
+    per_volume(rank)
+    out = qd.run_batch(n_vol, per_volume, setup=setup)
+    summ = out.pop("summary")
+    out.update({
+        "config": f"{n_vol} volumes of 512x512x160 x 8 echoes: mono-exponential fit (MonoExponentialFit defaults) + UNet2D "
+                  f"segmentation at 512x512 ({UNET_PARITY_MODE}) per volume, {per_gpu} volumes per GPU (BASELINE configs[4])",
+        "voxel_fits_per_s": float(np.nansum(summ["voxels"])) / out["wall_s"],
+        "slices_per_s": float(np.nansum(summ["slices"])) / out["wall_s"],
+        "fit_s_per_volume": float(np.nanmean(summ["fit_s"])), "seg_s_per_volume": float(np.nanmean(summ["seg_s"])),
+        "unet_gflop_per_slice_512": UNET_GFLOP_PER_SLICE * (512 / 384) ** 2,
+        "host_feed_note": "inputs generated on-device from per-volume seeds, resident in HBM before the clock starts",
+        "weights_broadcast": {"bytes": wbytes, "seconds": t_bcast, "make_seconds_rank0": t_make,
+                              "identical_on_all_ranks": bool(np.all(sums == sums[0])),
+                              "collective": "one torch.distributed.broadcast of the packed fp32 weights (RCCL) from rank 0"},
+    })
+    eng.close()
+    # ---- host-fed rate: one volume per rank through the host entry (pageable numpy in, numpy out), all ranks at once
+    y_host = [vol0[e].cpu().numpy() for e in range(E)]
+    qd.barrier()
+    t0 = time.perf_counter()
+    res = L.monoexp_fit_host(TE, y_host, p0=P0_A, want_tc=True, want_popt=False,
+                             post=dict(inv_abs_b=True, bounds=((-np.inf, np.inf), (0.0, 100.0)), r2_threshold=0.9,
+                                       nan_to_num=0.0, decimals=1), device=local_rank)
+    mine = time.perf_counter() - t0
+    qd.barrier()
+    wall = qd.allreduce_max(time.perf_counter() - t0)
+    per_rank = qd.allgather_scalars([mine])[:, 0]
+    del res
+    out["host_feed"] = {
+        "what": "qmri_monoexp_fit_host on one 512x512x160x8 float32 volume per rank (1.34 GB up, tc + r2 float64 = 0.67 GB "
+                "down, fresh output arrays: PCIe both ways + first-touch page zeroing), every rank at the same time",
+        "seconds_per_rank": per_rank.tolist(), "wall_s": wall,
+        "voxel_fits_per_s": n * world / wall,
+    }
+    return out
+
+
+def _kernel_source_sha1():
+    h = hashlib.sha1()
+    for f in ("monoexp_lm.hip", "fp64_fast.h", "qmri_internal.h"):
+        with open(os.path.join(ROOT, "dosma_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def main():
@@ -262,15 +447,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recipes", default="B,A", help="which recipes to time (A = headline, last)")
     ap.add_argument("--no-unet", action="store_true", help="skip the UNet2D slices/s leg")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] batch (8 volumes per GPU: fit + seg)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run parity sample")
     ap.add_argument("--unet-batch", type=int, default=160,
                     help="slices per pass through the network (default: the whole 160-slice volume)")
+    ap.add_argument("--cfg5-volumes-per-gpu", type=int, default=8)
+    ap.add_argument("--cfg5-unet-batch", type=int, default=32)
+    ap.add_argument("--print-kernel-hash", action="store_true")
     args = ap.parse_args()
+    if args.print_kernel_hash:
+        print(_kernel_source_sha1())
+        return
 
     from dosma_amd import _lib as L
 
     lib = L.load()
     import torch
     import torch.distributed as dist
+
+    from dosma_amd import dist as qd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -294,6 +489,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     local_rank = dev_index
+    L.set_default_device(local_rank)
 
     y = make_volume(torch, device, 20260928 + rank)
     n = y.shape[1]
@@ -307,10 +503,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    results = {}
-    for recipe in args.recipes.split(","):  # A last: it is the headline
-        a = make_args(L, y, popt, r2, stream.cuda_stream, recipe)
-        a.device = local_rank
+    def timed_fit(a):
         for _ in range(args.warmup):
             L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -328,32 +521,62 @@ def main():
             t = torch.tensor([elapsed, kernel_ms], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = t[0].item(), t[1].item()
-        results[recipe] = dict(elapsed=elapsed, kernel_ms=kernel_ms,
-                               kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
+        return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
+
+    results = {}
+    # float64 outputs (what the drop-in API returns: 56 B/voxel) first, the headline (fp32 outputs) last so that the
+    # parity check below reads the headline's own output buffers
+    popt64 = torch.empty((n, 2), dtype=torch.float64, device=device)
+    r264 = torch.empty(n, dtype=torch.float64, device=device)
+    a64 = make_args(L, y, popt64, r264, stream.cuda_stream, "A", out_dtype=L.QMRI_F64)
+    a64.device = local_rank
+    results["A_f64"] = timed_fit(a64)
+    del popt64, r264
+    for recipe in args.recipes.split(","):  # A last: it is the headline
+        a = make_args(L, y, popt, r2, stream.cuda_stream, recipe)
+        a.device = local_rank
+        results[recipe] = timed_fit(a)
+
+    parity = None
+    if rank == 0 and not args.no_parity and args.recipes.split(",")[-1] == "A":
+        parity = parity_sample(L, torch, y, popt, r2)
 
     roi_run = bench_t1rho_roi(L, lib, torch, device, local_rank, args) if rank == 0 else None
     dess = bench_dess(L, lib, torch, device, local_rank, world, args, barrier) if rank == 0 or world > 1 else None
     unet = None
     if not args.no_unet:
         unet = bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device)
+    cfg5 = None
+    if not args.no_cfg5:
+        cfg5 = bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, y)
 
     if rank == 0:
         ra = results["A"]
         total_voxels = n * world * args.steps
         value = total_voxels / ra["elapsed"]
         achieved = BYTES_PER_VOXEL * n / (ra["kernel_ms"] * 1e-3) / 1e9
-        traffic = None
-        valu_lane_instr = None
-        prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(prof):
-            with open(prof) as f:
-                pj = json.load(f)
-            traffic = pj.get("hbm_bytes_per_launch")
-            valu_lane_instr = pj.get("valu_lane_instr_per_launch")
+        # HBM traffic and VALU lane-instructions per launch are rocprofv3 PMC results (separate passes: gpurun refuses
+        # counters + tracing in one run), collected by scripts/collect_profile.sh and reduced by
+        # scripts/summarize_profile.py into profiles/<round>_hbm_traffic.json together with the hash of the kernel
+        # sources they were measured on; a kernel edit makes them "stale" here instead of silently wrong
+        traffic = valu_lane_instr = None
+        traffic_src = None
+        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            prof = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(prof):
+                with open(prof) as f:
+                    pj = json.load(f)
+                traffic = pj.get("hbm_bytes_per_launch")
+                valu_lane_instr = pj.get("valu_lane_instr_per_launch")
+                sha = pj.get("kernel_source_sha1")
+                traffic_src = {"file": f"profiles/{name}", "counters": pj.get("source"),
+                               "kind": "constant from a rocprofv3 --pmc collection (not re-measured by this run)",
+                               "stale": (sha != _kernel_source_sha1()) if sha else None, "pmc": pj.get("pmc")}
+                break
         # the bound that actually binds: vector-ALU issue.  Peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz lane-
         # instructions/s (an fp64 FMA on every lane every clock = the 78.6 TFLOP/s vector fp64 figure); achieved = the
-        # kernel's active lane-instructions per launch (rocprofv3 PMC, SQ_INSTS_VALU x lanes active per instruction,
-        # profiles/r01e_counters.json) over the launch duration measured here
+        # kernel's active lane-instructions per launch (rocprofv3 PMC, SQ_INSTS_VALU x lanes active per instruction)
+        # over the launch duration measured here
         valu_peak = 256 * 4 * 16 * 2.4e9
         valu_rate = valu_lane_instr / (ra["kernel_ms"] * 1e-3) if valu_lane_instr else None
         out = {
@@ -374,6 +597,7 @@ def main():
                             "(BASELINE.json configs[1]); MonoExponentialFit() defaults; "
                             "one volume per GPU per step",
                 "voxels_per_gpu_per_step": n,
+                "solved_voxels_per_gpu_per_step": int((y != 0).any(dim=0).sum().item()),
                 "echoes": E,
                 "parallelism": f"volumes sharded over {world} GPU(s), no data-path collective",
                 "kernel": ra["kernel"],
@@ -385,28 +609,35 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_voxel": BYTES_PER_VOXEL,
                 "kernel_ms": ra["kernel_ms"],
                 "note": "the kernel is fp64-VALU bound, not HBM bound: MINPACK's early-stopped trajectory is ~20 LM rounds "
-                        "per voxel (53 charged model evaluations) of ~1050 fp64 VALU instructions each (lmpar, model "
+                        "per voxel (53 charged model evaluations) of ~1000 fp64 VALU instructions each (lmpar, model "
                         "evaluation, ratio tests, forward-difference Jacobian + QR); see `valu` and DESIGN.md 3.1",
-                # measured with rocprofv3 PMC on this kernel and workload (profiles/r01e_counters.json; constants, not
-                # re-measured by this run): VALU pipes busy 78 % of the kernel's cycles, 40.4 of 64 lanes active per
-                # VALU instruction (divergent lmpar iteration counts / rejected steps), HBM traffic 1.15x algorithmic
-                "valu": {"busy_frac": 0.79, "lanes_active_frac": 0.630, "hbm_traffic_over_algorithmic": 1.15,
-                         "valu_instructions_per_wave_round": 1051, "source": "profiles/r01e_counters.json",
-                         "lane_instr_per_s": valu_rate, "peak_lane_instr_per_s": valu_peak,
-                         "frac_of_valu_peak": (valu_rate / valu_peak) if valu_rate else None},
+                "valu": {"lane_instr_per_launch": valu_lane_instr, "lane_instr_per_s": valu_rate,
+                         "peak_lane_instr_per_s": valu_peak,
+                         "frac_of_valu_peak": (valu_rate / valu_peak) if valu_rate else None,
+                         "source": traffic_src},
             },
             "runs": {
                 "A_defaults_fixed_p0": {"voxel_fits_per_s": n * world * args.steps / ra["elapsed"],
                                         "kernel_ms": ra["kernel_ms"]},
+                "A_f64_outputs": {"voxel_fits_per_s": n * world * args.steps / results["A_f64"]["elapsed"],
+                                  "kernel_ms": results["A_f64"]["kernel_ms"],
+                                  "algorithmic_bytes_per_voxel": BYTES_PER_VOXEL_F64,
+                                  "hbm_gb_per_s": BYTES_PER_VOXEL_F64 * n / (results["A_f64"]["kernel_ms"] * 1e-3) / 1e9,
+                                  "note": "float64 (popt, r2) like the reference returns -- what the drop-in API uses"},
             },
         }
+        if parity is not None:
+            out["parity"] = parity
         if unet is not None:
             out["unet2d"] = unet
         if dess is not None:
             out["dess_t2"] = dess
+        if cfg5 is not None:
+            out["cfg5"] = cfg5
         if roi_run is not None:
             out["runs"]["cfg2_t1rho_roi"] = roi_run
         if "B" in results:

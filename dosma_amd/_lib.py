@@ -325,7 +325,8 @@ def set_post(a: QmriMonoexpArgs, inv_abs_b=False, bounds=None, r2_threshold=None
 
 def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=None, b0v=None,
                      post=None, want_tc=False, want_info=False, out_dtype=np.float64, device=None,
-                     ftol=None, maxfev=None, r2_eps=None, y_bounds=None, out=None, want_popt=True):
+                     ftol=None, maxfev=None, r2_eps=None, y_bounds=None, out=None, want_popt=True,
+                     xtol=None, gtol=None, factor=None):
     """Run the HIP fit on host (numpy) buffers.  ``y``: (E, N) C-contiguous, echo-major.
 
     Returns dict(popt (N,2), r2 (N,), [tc (N,)], [info (N,) int8, nfev (N,) int16]).
@@ -379,6 +380,9 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
         a.maxfev = int(maxfev)
     if r2_eps is not None:
         a.r2_eps = float(r2_eps)
+    for opt, val in (("xtol", xtol), ("gtol", gtol), ("factor", factor)):  # MINPACK options (scipy leastsq names)
+        if val is not None:
+            setattr(a, opt, float(val))
     if y_bounds is not None:
         a.use_y_bounds = 1
         a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
@@ -448,7 +452,7 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
 
 
 def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds=None, want_info=False,
-               device=None):
+               device=None, xtol=None, gtol=None, factor=None):
     """General lmdif (true forward differences) on the GPU.  ``model``: "biexponential" | "monoexponential";
     ``y`` (E, N) echo-major; ``p0``: one entry per parameter, a float or a float64 array of length N.
     Returns dict(popt (N, n), r2 (N,), [info, nfev])."""
@@ -483,6 +487,9 @@ def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds
         a.maxfev = int(maxfev)
     if r2_eps is not None:
         a.r2_eps = float(r2_eps)
+    for opt, val in (("xtol", xtol), ("gtol", gtol), ("factor", factor)):
+        if val is not None:
+            setattr(a, opt, float(val))
     if y_bounds is not None:
         a.use_y_bounds = 1
         a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])

@@ -45,15 +45,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not _stale():
             return SO
-        return _build_locked(bdir, verbose)
+        return _build_locked(bdir, verbose, force)
 
 
-def _build_locked(bdir: str, verbose: bool) -> str:
+def _build_locked(bdir: str, verbose: bool, force: bool = False) -> str:
     objs = []
     procs = []
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "qmri.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
+        # per-file staleness: an object newer than its source and every header is reused (a kernel edit recompiles one
+        # translation unit, not nine)
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(os.path.join(CSRC, src)), hdr_time)):
+            continue
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

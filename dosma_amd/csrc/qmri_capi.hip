@@ -43,14 +43,11 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr int kMaxDevices = 16;
-constexpr int kSlots = 64;  // concurrent calls per device before counters are reused
 
 struct DeviceCtx {
     std::once_flag once;
     hipError_t init_err = hipSuccess;
-    unsigned int *counters = nullptr;  // [kSlots][16] (64-byte spaced): tile counter + non-finite flag
     int num_cu = 0;
-    std::atomic<unsigned> next{0};
 };
 DeviceCtx g_ctx[kMaxDevices];
 
@@ -58,8 +55,6 @@ hipError_t ctx_get(int device, DeviceCtx **out) {
     DeviceCtx &c = g_ctx[device];
     std::call_once(c.once, [&] {
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.counters), kSlots * 64);
-        if (e == hipSuccess) e = hipMemset(c.counters, 0, kSlots * 64);
         hipDeviceProp_t prop;
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) c.num_cu = prop.multiProcessorCount;
@@ -200,8 +195,11 @@ int launch_fit(const qmri_monoexp_args *a, int32_t *flag_out) {
 
     qmri::FitKArgs k;
     fill_kargs(a, k);
-    const unsigned slot = ctx->next.fetch_add(1) % kSlots;
-    unsigned int *cnt = ctx->counters + slot * 16;
+    // the tile counter + non-finite flag of THIS launch: stream-ordered scratch, so any number of fits can be in flight
+    // on one device (a fixed ring of slots handed two concurrent kernels the same counter once it wrapped)
+    AsyncScratch cnt_scratch;
+    HIP_TRY(cnt_scratch.alloc(64, stream));
+    unsigned int *cnt = static_cast<unsigned int *>(cnt_scratch.p);
     k.tile_counter = cnt;
     k.nonfinite = flag_out ? flag_out : reinterpret_cast<int *>(cnt + 1);
     HIP_TRY(hipMemsetAsync(cnt, 0, 8, stream));
@@ -697,11 +695,12 @@ int qmri_lmfit_device(const qmri_lmfit_args *a, int32_t *nonfinite_flag) {
     k.info = a->info;
     k.nfev = a->nfev;
     for (int i = 0; i < a->E; ++i) k.x[i] = a->x[i];
+    AsyncScratch flag_scratch;  // per-launch flag word when the caller does not collect it
     if (nonfinite_flag) {
         k.nonfinite = nonfinite_flag;
     } else {
-        const unsigned slot = ctx->next.fetch_add(1) % kSlots;
-        k.nonfinite = reinterpret_cast<int *>(ctx->counters + slot * 16 + 1);
+        HIP_TRY(flag_scratch.alloc(64, stream));
+        k.nonfinite = static_cast<int *>(flag_scratch.p);
     }
     HIP_TRY(qmri::lm_generic_launch(k, a->model, ctx->num_cu, stream));
     return QMRI_OK;

@@ -189,14 +189,12 @@ def curve_fit(
     returns ``popts`` (N, P) float64 and ``r_squared`` (N,) float64; a voxel that is all zero, out of
     ``y_bounds``, or whose fit does not converge (MINPACK info not in 1..4) is ``(nan, nan), 0``.
     ``show_pbar`` / ``num_workers`` / ``chunksize`` are accepted for compatibility and ignored (there
-    is no per-voxel Python loop to parallelise).  Extra scipy ``**kwargs`` (``bounds=``, ``sigma=``,
-    ``method=`` ...) select solvers this library does not implement -> NotImplementedError.
+    is no per-voxel Python loop to parallelise).  Of the extra scipy ``**kwargs`` the MINPACK options
+    ``xtol`` / ``gtol`` / ``factor`` (and ``method="lm"``) are honoured; ``bounds=``, ``sigma=``, ``jac=``,
+    another ``method`` ... select solvers this library does not implement -> NotImplementedError.
     """
     model = _model_of(func)
-    if kwargs:
-        raise NotImplementedError(
-            f"curve_fit(**{sorted(kwargs)}): only scipy's default unbounded Levenberg-Marquardt "
-            "('lm') configuration is implemented on the GPU; there is no CPU fallback.")
+    solver = _solver_options(kwargs, "curve_fit")
     if isinstance(x, MedicalVolume) or isinstance(y, MedicalVolume):
         raise TypeError("`x` and `y` must be array-like (use CurveFitter for MedicalVolumes)")
     x = np.asarray(x)
@@ -216,7 +214,7 @@ def curve_fit(
         if x.reshape(-1).shape[0] < len(param_args):
             raise TypeError("The number of func parameters must not exceed the number of data points")  # scipy
         out = _lib.lmfit_host(model, x.astype(np.float64).reshape(-1), _as_kernel_samples(y), p0,
-                              ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds)
+                              ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds, **solver)
         return out["popt"], out["r2"]
     per_voxel = any(isinstance(v, np.ndarray) for v in p0)
     out = _lib.monoexp_fit_host(
@@ -225,7 +223,7 @@ def curve_fit(
         p0=tuple(1.0 if isinstance(v, np.ndarray) else v for v in p0),
         a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
         b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,
-        ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds,
+        ftol=ftol, maxfev=maxfev, r2_eps=eps, y_bounds=y_bounds, **solver,
     )
     return out["popt"], out["r2"]
 
@@ -251,9 +249,110 @@ def polyfit(x, y, deg: int, rcond=None, full=False, w=None, cov=False, eps=1e-8,
     return out["popt"], out["r2"]
 
 
+# ---------------------------------------------------------------------------------------------------
+# Post-processing options shared by the fitters.  The reference spreads this over four private helpers of
+# `_Fitter` (fitting.py:60-146); here the options are validated once into a small table and applied by one
+# function.  Message strings and the public attribute names are the reference's (they are API), the code is not.
+# ---------------------------------------------------------------------------------------------------
+def _checked_ufuncs(spec, nparams):
+    """``out_ufuncs``: one callable for the whole (N, P) array, or a sequence with None / a callable per parameter."""
+    per_param = not callable(spec)
+    if per_param:
+        try:
+            entries = list(spec)
+        except TypeError:
+            entries = [spec]
+        if any(e is not None and not callable(e) for e in entries):
+            raise TypeError(f"`out_ufuncs` must be callable or sequence of callables. Got {spec}")
+        if isinstance(spec, Sequence) and len(entries) > nparams:
+            warnings.warn(f"len(out_ufuncs)={len(entries)}, but only {nparams} parameters. "
+                          f"Extra ufuncs will be ignored.")
+    return spec
+
+
+def _checked_bounds(spec):
+    """``out_bounds``: (lb, ub) for every parameter, or one (lb, ub) row per (leading) parameter."""
+    table = np.asarray(spec)
+    well_formed = table.ndim in (1, 2) and table.shape[-1] == 2
+    if not well_formed:
+        raise ValueError("Invalid `out_bounds` - shape must be ([num_params,] 2)")
+    lower, upper = table[..., 0], table[..., 1]
+    if (lower > upper).any():
+        raise ValueError("Invalid `out_bounds` - lower bound must be <= upper bound")
+    return table
+
+
+def _resolved_r2_threshold(spec):
+    """``r2_threshold``: None, a number, or the string "preferences" (-> preferences.fitting_r2_threshold)."""
+    if not isinstance(spec, str):
+        return spec
+    if spec == "preferences":
+        return preferences.fitting_r2_threshold
+    raise ValueError(f"Invalid value r2_threshold='{spec}'. "
+                     f"Expected `None`, a number between [0, 1], or 'preferences'.")
+
+
+def _bounds_table(out_bounds, nparams):
+    """(lb[P], ub[P]) from ``out_bounds``: a single pair applies to every parameter; missing rows are open."""
+    lb = np.full(nparams, -np.inf)
+    ub = np.full(nparams, np.inf)
+    table = np.asarray(out_bounds, dtype=np.float64)
+    if table.ndim == 1:
+        lb[:], ub[:] = table[0], table[1]
+    else:
+        rows = min(nparams, table.shape[0])
+        lb[:rows], ub[:rows] = table[:rows, 0], table[:rows, 1]
+    return lb, ub
+
+
+def _apply_post(popt, r_squared, out_ufuncs, out_bounds, r2_threshold, nan_to_num):
+    """Reference order (fitting.py:109-146): ufuncs, bounds -> NaN, r2 threshold -> NaN rows, nan_to_num."""
+    nparams = popt.shape[-1]
+    with np.errstate(all="ignore"):
+        if callable(out_ufuncs):
+            popt = out_ufuncs(popt)
+        elif out_ufuncs is not None:
+            for j, fn in enumerate(list(out_ufuncs)[:nparams]):
+                if fn is not None:
+                    popt[..., j] = fn(popt[..., j])
+        if out_bounds is not None:
+            lb, ub = _bounds_table(out_bounds, nparams)
+            outside = np.logical_or(popt < lb, popt > ub)
+            popt[outside] = np.nan
+        if r2_threshold is not None:
+            popt[r_squared < r2_threshold] = np.nan
+        if nan_to_num is not None:
+            popt = np.nan_to_num(popt, nan=nan_to_num, copy=False)
+    return popt
+
+
+# scipy.optimize.leastsq options the kernels implement (everything else scipy accepts selects another solver)
+_KERNEL_SOLVER_OPTIONS = ("xtol", "gtol", "factor")
+
+
+def _solver_options(kwargs, who):
+    """Split the reference's ``**kwargs`` (forwarded to scipy.optimize.curve_fit, fitting.py:827-830) into the
+    MINPACK options the kernels take.  ``method="lm"`` is the default solver and accepted; anything else
+    (``bounds=``, ``sigma=``, ``jac=``, ``method="trf"`` ...) is a different algorithm -> NotImplementedError."""
+    opts = {}
+    rest = {}
+    for k, v in kwargs.items():
+        if k in _KERNEL_SOLVER_OPTIONS:
+            opts[k] = float(v)
+        elif k == "method" and v in (None, "lm"):
+            continue
+        else:
+            rest[k] = v
+    if rest:
+        raise NotImplementedError(
+            f"{who}(**{sorted(rest)}): only scipy's default unbounded Levenberg-Marquardt "
+            "('lm') configuration is implemented on the GPU; there is no CPU fallback.")
+    return opts
+
+
 class _Fitter:
-    """Plumbing shared by the fitters: validation of the post-processing options, the mask, and the
-    wrapping of (N, P) / (N,) results into MedicalVolumes (reference :51-235)."""
+    """Plumbing shared by the fitters: the post-processing options, the mask, and the wrapping of
+    (N, P) / (N,) results into MedicalVolumes (reference :51-235)."""
 
     nan_to_num = None
     out_ufuncs = None
@@ -261,75 +360,31 @@ class _Fitter:
     r2_threshold = None
     y_bounds = None
 
-    def _format_out_ufuncs(self, _out_ufuncs, _func_nparams):
-        if not isinstance(_out_ufuncs, Callable) and not all(
-            isinstance(u, Callable) or u is None for u in _out_ufuncs
-        ):
-            raise TypeError(
-                f"`out_ufuncs` must be callable or sequence of callables. Got {_out_ufuncs}")
-        if isinstance(_out_ufuncs, Sequence) and len(_out_ufuncs) > _func_nparams:
-            warnings.warn(f"len(out_ufuncs)={len(_out_ufuncs)}, but only {_func_nparams} parameters. "
-                          f"Extra ufuncs will be ignored.")
-        return _out_ufuncs
-
-    def _format_out_bounds(self, _out_bounds):
-        out_bounds = np.asarray(_out_bounds)
-        if out_bounds.shape[-1] != 2 or out_bounds.ndim > 2:
-            raise ValueError("Invalid `out_bounds` - shape must be ([num_params,] 2)")
-        if np.any(out_bounds[..., 0] > out_bounds[..., 1]):
-            raise ValueError("Invalid `out_bounds` - lower bound must be <= upper bound")
-        return out_bounds
-
-    def _format_r2_threshold(self, _r2_threshold):
-        if isinstance(_r2_threshold, str):
-            if _r2_threshold != "preferences":
-                raise ValueError(
-                    f"Invalid value r2_threshold='{_r2_threshold}'. "
-                    f"Expected `None`, a number between [0, 1], or 'preferences'.")
-            _r2_threshold = preferences.fitting_r2_threshold
-        return _r2_threshold
+    def _set_post_options(self, nparams, *, y_bounds, out_ufuncs, out_bounds, r2_threshold, nan_to_num):
+        self.y_bounds = y_bounds
+        self.out_ufuncs = None if out_ufuncs is None else _checked_ufuncs(out_ufuncs, nparams)
+        self.out_bounds = None if out_bounds is None else _checked_bounds(out_bounds)
+        self.r2_threshold = _resolved_r2_threshold(r2_threshold)
+        self.nan_to_num = nan_to_num
 
     def _process_mask(self, mask, y: MedicalVolume):
+        """``mask`` -> boolean MedicalVolume in ``y``'s orientation (reference :95-107)."""
         if isinstance(mask, np.ndarray):
             mask = y._partial_clone(volume=mask, headers=None)
-        elif not isinstance(mask, MedicalVolume):
+        if not isinstance(mask, MedicalVolume):
             raise TypeError("`mask` must be a MedicalVolume or ndarray")
-        mask = mask.reformat_as(y)
-        if not mask.is_same_dimensions(y, defaults.AFFINE_DECIMAL_PRECISION):
+        aligned = mask.reformat_as(y)
+        if not aligned.is_same_dimensions(y, defaults.AFFINE_DECIMAL_PRECISION):
             raise RuntimeError("`mask` and `y` dimension mismatch")
-        return mask > 0
+        return aligned > 0
 
     def _process_params(self, x, r_squared):
-        """Host post-processing for the general case (arbitrary Python ``out_ufuncs``): ufuncs ->
-        bounds -> r2 threshold -> nan_to_num, in the reference's order (:109-146).  The
+        """Host post-processing for the general case (arbitrary Python ``out_ufuncs``).  The
         MonoExponentialFit recipe never comes here: it is fused into the kernel."""
-        nparams = x.shape[-1]
-        out_ufuncs, out_bounds = self.out_ufuncs, self.out_bounds
-        with np.errstate(all="ignore"):
-            if isinstance(out_ufuncs, Callable):
-                x = out_ufuncs(x)
-            elif isinstance(out_ufuncs, Sequence):
-                for i in range(min(nparams, len(out_ufuncs))):
-                    if out_ufuncs[i] is not None:
-                        x[..., i] = out_ufuncs[i](x[..., i])
-            if out_bounds is not None:
-                lb, ub = self._bounds_per_param(nparams)
-                x[(x < lb) | (x > ub)] = np.nan
-            if self.r2_threshold is not None:
-                x[(r_squared < self.r2_threshold)] = np.nan
-            if self.nan_to_num is not None:
-                x = np.nan_to_num(x, nan=self.nan_to_num, copy=False)
-        return x
+        return _apply_post(x, r_squared, self.out_ufuncs, self.out_bounds, self.r2_threshold, self.nan_to_num)
 
     def _bounds_per_param(self, nparams):
-        ob = np.asarray(self.out_bounds, dtype=np.float64)
-        if ob.ndim == 1:
-            ob = np.tile(ob, (nparams, 1))
-        elif ob.shape[0] < nparams:
-            pad = np.tile([[-np.inf, np.inf]], (nparams - ob.shape[0], 1))
-            ob = np.concatenate([ob, pad], axis=0)
-        ob = ob[:nparams]
-        return ob[:, 0].copy(), ob[:, 1].copy()
+        return _bounds_table(self.out_bounds, nparams)
 
     # ---- shared front half of fit(): checks + flatten to (E, N) ----
     def _prepare(self, x, y, mask, rows=False):
@@ -371,7 +426,8 @@ class CurveFitter(_Fitter):
 
     Same constructor and ``fit`` contract as the reference's ``CurveFitter`` (:238-458).  ``func`` must
     be the mono-exponential or the bi-exponential model (see :func:`curve_fit`).  ``num_workers`` / ``chunksize`` / ``verbose``
-    are accepted and ignored.
+    are accepted and ignored; ``**kwargs`` are forwarded like the reference does (``maxfev``, ``ftol``, ``eps``, and the
+    MINPACK options ``xtol`` / ``gtol`` / ``factor``), anything that selects another scipy solver raises at ``fit``.
     """
 
     def __init__(
@@ -388,27 +444,13 @@ class CurveFitter(_Fitter):
         verbose: bool = False,
         **kwargs,
     ):
-        func_name = func.__name__ if hasattr(func, "__name__") else type(func).__name__
-        func_args = list(inspect.signature(func).parameters)
-        func_nparams = len(func_args) - 2 if "self" in func_args else len(func_args) - 1
-        if out_ufuncs is not None:
-            out_ufuncs = self._format_out_ufuncs(out_ufuncs, func_nparams)
-        if out_bounds is not None:
-            out_bounds = self._format_out_bounds(out_bounds)
-        r2_threshold = self._format_r2_threshold(r2_threshold)
-
         self._func = func
-        self._func_name = func_name
-        self._func_nparams = func_nparams
+        self._func_name = getattr(func, "__name__", type(func).__name__)
+        self._func_nparams = len(_func_param_names(func))
+        self._set_post_options(self._func_nparams, y_bounds=y_bounds, out_ufuncs=out_ufuncs, out_bounds=out_bounds,
+                               r2_threshold=r2_threshold, nan_to_num=nan_to_num)
         self.p0 = self._format_p0(p0)
-        self.y_bounds = y_bounds
-        self.out_ufuncs = out_ufuncs
-        self.out_bounds = out_bounds
-        self.r2_threshold = r2_threshold
-        self.nan_to_num = nan_to_num
-        self.num_workers = num_workers
-        self.chunksize = chunksize
-        self.verbose = verbose
+        self.num_workers, self.chunksize, self.verbose = num_workers, chunksize, verbose
         self.kwargs = kwargs
 
     def _format_p0(self, p0, ref: MedicalVolume = None, flatten: bool = False, depth: int = 0):
@@ -464,10 +506,17 @@ class CurveFitter(_Fitter):
         """Fit every voxel; returns ``(popt, r2)`` MedicalVolumes (``popt`` has a trailing parameter
         axis).  Voxels outside ``mask`` hold NaN (or ``nan_to_num``) like the reference (:205-215)."""
         model = _model_of(self._func)
-        if self.kwargs:
-            raise NotImplementedError(
-                f"CurveFitter(**{sorted(self.kwargs)}): extra scipy arguments are not implemented "
-                "on the GPU; there is no CPU fallback.")
+        # the reference forwards **kwargs to its module-level curve_fit (:422-435): maxfev / ftol / eps are that
+        # function's own arguments, the rest go to scipy
+        fit_kw = dict(self.kwargs)
+        named = {k: fit_kw.pop(k) for k in ("maxfev", "ftol", "eps") if k in fit_kw}
+        solver = _solver_options(fit_kw, "CurveFitter")
+        if "maxfev" in named:
+            solver["maxfev"] = int(named["maxfev"])
+        if "ftol" in named:
+            solver["ftol"] = float(named["ftol"])
+        if "eps" in named:
+            solver["r2_eps"] = float(named["eps"])
         if isinstance(x, MedicalVolume):
             raise RuntimeError("`x` must be on the CPU")
         x, y, svs, mask_flat = self._prepare(x, y, mask, rows=model == "monoexponential")
@@ -486,7 +535,7 @@ class CurveFitter(_Fitter):
             warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
 
         if model != "monoexponential":
-            return self._fit_general(model, x, y, svs, mask_flat, p0, copy_headers)
+            return self._fit_general(model, x, y, svs, mask_flat, p0, copy_headers, solver)
 
         post = self._fusable_post()
         if post is not None and _decimals is not None:
@@ -498,7 +547,7 @@ class CurveFitter(_Fitter):
             a0v=p0[0] if isinstance(p0[0], np.ndarray) else None,
             b0v=p0[1] if isinstance(p0[1], np.ndarray) else None,
             post=post, want_tc=tc_only or (_decimals is not None and post is not None),
-            y_bounds=self.y_bounds, want_popt=not tc_only,
+            y_bounds=self.y_bounds, want_popt=not tc_only, **solver,
         )
         if tc_only:
             shape = y[0].shape
@@ -520,7 +569,7 @@ class CurveFitter(_Fitter):
             self._last_tc = out["tc"]
         return popt_mv, r2_mv
 
-    def _fit_general(self, model, x, y, svs, mask_flat, p0, copy_headers):
+    def _fit_general(self, model, x, y, svs, mask_flat, p0, copy_headers, solver):
         """Models on the general lmdif kernel (bi-exponential): gather the masked columns like the
         reference (:199-200), fit, post-process on the host (:109-146), scatter back (:205-215)."""
         N = svs.shape[1]
@@ -528,7 +577,7 @@ class CurveFitter(_Fitter):
         cols = svs if sel is None else np.ascontiguousarray(svs[:, sel])
         p0 = [v[sel] if (sel is not None and isinstance(v, np.ndarray)) else v for v in p0]
         out = _lib.lmfit_host(model, x.astype(np.float64).reshape(-1), _as_kernel_samples(cols), p0,
-                              y_bounds=self.y_bounds)
+                              y_bounds=self.y_bounds, **solver)
         popt_s = self._process_params(out["popt"], out["r2"])
         r2_s = out["r2"]
         if sel is None:
@@ -556,20 +605,10 @@ class PolyFitter(_Fitter):
     def __init__(self, deg: int, rcond: float = None, y_bounds=None, out_ufuncs=None,
                  out_bounds=None, r2_threshold="preferences", nan_to_num: float = None,
                  num_workers: int = None, chunksize: int = None, verbose: bool = False):
-        if out_ufuncs is not None:
-            out_ufuncs = self._format_out_ufuncs(out_ufuncs, deg + 1)
-        if out_bounds is not None:
-            out_bounds = self._format_out_bounds(out_bounds)
-        self.deg = deg
-        self.rcond = rcond
-        self.y_bounds = y_bounds
-        self.out_ufuncs = out_ufuncs
-        self.out_bounds = out_bounds
-        self.r2_threshold = self._format_r2_threshold(r2_threshold)
-        self.nan_to_num = nan_to_num
-        self.num_workers = num_workers
-        self.chunksize = chunksize
-        self.verbose = verbose
+        self.deg, self.rcond = deg, rcond
+        self._set_post_options(deg + 1, y_bounds=y_bounds, out_ufuncs=out_ufuncs, out_bounds=out_bounds,
+                               r2_threshold=r2_threshold, nan_to_num=nan_to_num)
+        self.num_workers, self.chunksize, self.verbose = num_workers, chunksize, verbose
 
     def fit(self, x, y: Sequence[MedicalVolume], mask=None, copy_headers: bool = True):
         x, y, svs, mask_flat = self._prepare(x, y, mask)
@@ -606,29 +645,22 @@ class MonoExponentialFit:
                  mask: MedicalVolume = None, bounds=(0, 100.0), tc0=30.0,
                  r2_threshold="preferences", decimal_precision: int = 1, num_workers: int = 0,
                  chunksize: int = 1000, verbose: bool = False):
-        self.x = x
-        if y is not None:
-            warnings.warn(
-                f"Setting `y` in the constructor can result in significant memory overhead. "
-                f"Specify `y` in `{type(self).__name__}.fit(y=...)` instead.")
-            self._check_y(x, y)
-        self.y = y
-        if mask is not None:
-            warnings.warn(
-                f"Setting `mask` in the constructor can result in significant memory overhead. "
-                f"Specify `mask` in `{type(self).__name__}.fit(mask=...)` instead.")
-        self.mask = mask
-        if not (isinstance(tc0, Number) or (isinstance(tc0, str) and tc0 == "polyfit")):
+        # argument checks first (the reference interleaves them with the assignments, :646-676)
+        if not (isinstance(tc0, Number) or tc0 == "polyfit"):
             raise ValueError("`tc0` must either be a float or the string 'polyfit'.")
-        self.verbose = verbose
-        self.num_workers = num_workers
         if len(bounds) != 2:
             raise ValueError("`bounds` should provide lower/upper bound in format (lb, ub)")
-        self.bounds = bounds
-        self.chunksize = chunksize
-        self.r2_threshold = r2_threshold
-        self.tc0 = tc0
-        self.decimal_precision = decimal_precision
+        for name, given in (("y", y), ("mask", mask)):
+            if given is not None:
+                warnings.warn(
+                    f"Setting `{name}` in the constructor can result in significant memory overhead. "
+                    f"Specify `{name}` in `{type(self).__name__}.fit({name}=...)` instead.")
+        if y is not None:
+            self._check_y(x, y)
+        self.x, self.y, self.mask = x, y, mask
+        self.bounds, self.tc0 = bounds, tc0
+        self.r2_threshold, self.decimal_precision = r2_threshold, decimal_precision
+        self.num_workers, self.chunksize, self.verbose = num_workers, chunksize, verbose
         self._eps = 1e-10  # epsilon for polyfit (reference :676) -- fixed in the kernel
 
     def fit(self, x=None, y: Sequence[MedicalVolume] = None, mask=None):

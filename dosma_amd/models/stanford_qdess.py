@@ -7,6 +7,7 @@ root-sum-of-squares of the two echoes (:177-178) -- on the GPU (``qmri_rss_host`
 import numpy as np
 
 from dosma_amd import _lib
+from dosma_amd.fitting import _as_kernel_samples
 from dosma_amd.med_volume import MedicalVolume
 from dosma_amd.models.oaiunet2d import IWOAIOAIUnet2D
 
@@ -32,8 +33,15 @@ class StanfordQDessUNet2D(IWOAIOAIUnet2D):
             arr = volume.volume
             if arr.shape[-1] != 2:
                 raise ValueError("4D volumes must have shape (..., 2): echo 1 and echo 2")
-            rss = _lib.rss_host(arr[..., 0], arr[..., 1], method="rss")
-            volume = MedicalVolume(rss, volume.affine)
+            # any real dtype, like the reference's np.sqrt(np.sum(v ** 2)) (:177-178): the echoes are widened to a
+            # dtype the kernel reads, exactly as QDess._combine_echoes does
+            e1 = _as_kernel_samples(np.ascontiguousarray(arr[..., 0]))
+            e2 = _as_kernel_samples(np.ascontiguousarray(arr[..., 1]))
+            if e1.dtype != e2.dtype:
+                e1, e2 = e1.astype(np.float64), e2.astype(np.float64)
+            rss = _lib.rss_host(e1, e2, method="rss")
+            headers = volume.headers()
+            volume = volume._partial_clone(volume=rss, headers=None if headers is None else headers[..., 0])
         return super().generate_mask(volume)
 
     def __preprocess_volume__(self, volume: np.ndarray):

@@ -97,10 +97,14 @@ def load_npz(path):
 def load_keras_h5(path, depth=6):
     """Read a Keras ``.h5`` weights file of this architecture (layer groups in creation order, each
     with ``weight_names`` ``kernel:0 / bias:0 / gamma:0 / beta:0 / moving_mean:0 / moving_variance:0``)."""
+    opener = None
     try:
         import h5py
-        opener = lambda p: h5py.File(p, "r")  # noqa: E731
+        if isinstance(getattr(h5py, "File", None), type) and hasattr(h5py.File, "__enter__"):
+            opener = lambda p: h5py.File(p, "r")  # noqa: E731
     except ImportError:
+        pass
+    if opener is None:  # no (real) h5py in this environment: the package's own reader of the HDF5 subset Keras writes
         from ..io import _hdf5_lite
         opener = _hdf5_lite.File
     with opener(path) as f:

@@ -303,9 +303,50 @@ def g7():
     save("g7_biexp.npz", x=x, y=y, p0=np.array(p0), **out)
 
 
+def g8():
+    """QuantitativeValue.to_metrics (quant_vals.py:145-229; pinned by tests/core/test_quant_vals.py:52-174): the real
+    reference's DataFrame for label maps, ``labels`` subsets, ``bounds`` with all four ``closed`` modes, non-finite
+    voxels, float64 and float32 maps."""
+    from dosma.core.quant_vals import T2
+
+    rng = np.random.default_rng(8)
+    shape = (40, 36, 12)
+    vol = rng.uniform(5.0, 95.0, shape)
+    vol[rng.uniform(size=shape) < 0.02] = np.nan
+    vol[rng.uniform(size=shape) < 0.01] = np.inf
+    vol[rng.uniform(size=shape) < 0.01] = -np.inf
+    vol.reshape(-1)[:600] = np.round(vol.reshape(-1)[:600])          # exact ties and values ON the bounds
+    vol[3, 3, 3], vol[4, 4, 4], vol[5, 5, 5] = 20.0, 60.0, 60.0      # both interval ends present
+    lab = rng.integers(0, 5, shape).astype(np.uint8)                 # labels 0 (background) .. 4
+    lab[:, :4, :] = 0
+    lab[vol == 20.0] = 2
+    out = dict(vol=vol, labels=lab)
+
+    def record(tag, df):
+        out[f"{tag}_category"] = np.array(list(df["Category"]), dtype="U16")
+        for col, key in (("Mean", "mean"), ("Std", "std"), ("Median", "median"), ("# Voxels", "count")):
+            out[f"{tag}_{key}"] = np.asarray(df[col], dtype=np.float64)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for dt in (np.float64, np.float32):
+            tag = np.dtype(dt).name
+            qv = T2(MV(vol.astype(dt), np.eye(4)))
+            mask = MV(lab, np.eye(4))
+            record(f"{tag}_nomask", qv.to_metrics())
+            record(f"{tag}_auto", qv.to_metrics(mask))
+            record(f"{tag}_subset", qv.to_metrics(mask, labels={3: "tc", 1: "fc"}))
+            for closed in ("right", "left", "both", "neither"):
+                record(f"{tag}_b_{closed}", qv.to_metrics(mask, bounds=(20.0, 60.0), closed=closed))
+            record(f"{tag}_b_nomask", qv.to_metrics(bounds=(20.0, 60.0)))
+            # a label that selects nothing (all of its voxels out of bounds) -> NaN statistics, 0 voxels
+            record(f"{tag}_empty", qv.to_metrics(mask, labels={4: "men"}, bounds=(1000.0, 2000.0)))
+    save("g8_to_metrics.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         t = time.time()
         print(name, "...")

@@ -192,6 +192,10 @@ class _InertFinder:
 
 
 _LOADED = {}
+# stand-ins the product itself probes for (`import h5py` in dosma_amd/models/weights.py): removed from sys.modules once
+# the reference is imported (its own modules keep their reference to the stub; dosma/utils/io_utils.py:7 imports h5py
+# unconditionally, so the import itself needs one)
+_DROP_AFTER_IMPORT = ("h5py",)
 
 
 def load_reference():
@@ -225,7 +229,15 @@ def load_reference():
     import matplotlib
 
     matplotlib.use("Agg")
-    dosma = importlib.import_module("dosma")
+    try:
+        dosma = importlib.import_module("dosma")
+    finally:
+        # the stand-ins are only for the reference's own import: leaving the finder on sys.meta_path would hand
+        # an inert stub to any later `import h5py` / `import skimage` in the same process (e.g. the product's
+        # weights loader choosing between h5py and its own HDF5 reader)
+        sys.meta_path.remove(finder)
+        for name in [m for m in sys.modules if m.split(".")[0] in _DROP_AFTER_IMPORT and isinstance(sys.modules[m], _Inert)]:
+            del sys.modules[name]
     _LOADED["dosma"] = dosma
     return dosma
 

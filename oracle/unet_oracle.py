@@ -40,16 +40,39 @@ def layer_names(nf=NF):
     return names
 
 
-def make_weights(seed=0, nf=NF, n_classes=4, dtype=np.float32):
-    """Seeded random weights in Keras layouts (He-normal kernels so activations stay O(1))."""
+def make_weights(seed=0, nf=NF, n_classes=4, dtype=np.float32, bn="he"):
+    """Seeded random weights in Keras layouts (He-normal kernels so activations stay O(1)).
+
+    ``bn="he"``: BatchNormalization statistics near the identity (variance 0.5-1.5, mean 0.2-0.6).
+    ``bn="realistic"``: moving statistics spread like a trained network's -- every block's second convolution
+    gets a per-output-channel gain s in [0.1, 10] (kernel column and bias scaled; ReLU is positively homogeneous,
+    so the pre-BN activation scales by s) and the BatchNormalization that follows carries the matching moving
+    statistics: variance s^2 * U(0.5, 1.5) in [5e-3, 1.5e2], mean s * U(-0.6, 0.6) of either sign, gamma in
+    [0.2, 2].  The block output stays O(1) (as after training) while the folded per-channel scale
+    gamma / sqrt(var + eps) spans 0.02 ... 25 and the 1e-3 epsilon matters for the small-variance channels."""
     rng = np.random.default_rng(seed)
     w = {}
+    bn_kind = bn
+    if bn_kind not in ("he", "realistic"):
+        raise ValueError(bn_kind)
 
     def conv(name, kh, cin, cout):
         w[f"{name}_kernel"] = (rng.standard_normal((kh, kh, cin, cout)) * np.sqrt(2.0 / (kh * kh * cin))).astype(dtype)
         w[f"{name}_bias"] = (0.05 * rng.standard_normal(cout)).astype(dtype)
 
+    def bn_realistic(name, c):
+        s = 10.0 ** rng.uniform(-1.0, 1.0, c)
+        conv2 = name.replace("_bn", "_conv2")
+        w[f"{conv2}_kernel"] = (w[f"{conv2}_kernel"] * s.astype(dtype)).astype(dtype)  # (kh, kw, Cin, Cout): per Cout
+        w[f"{conv2}_bias"] = (w[f"{conv2}_bias"] * s.astype(dtype)).astype(dtype)
+        w[f"{name}_var"] = (s * s * rng.uniform(0.5, 1.5, c)).astype(dtype)
+        w[f"{name}_mean"] = (s * rng.uniform(-0.6, 0.6, c)).astype(dtype)
+        w[f"{name}_gamma"] = rng.uniform(0.2, 2.0, c).astype(dtype)
+        w[f"{name}_beta"] = (0.3 * rng.standard_normal(c)).astype(dtype)
+
     def bn(name, c):
+        if bn_kind == "realistic":
+            return bn_realistic(name, c)
         w[f"{name}_gamma"] = rng.uniform(0.7, 1.3, c).astype(dtype)
         w[f"{name}_beta"] = (0.1 * rng.standard_normal(c)).astype(dtype)
         w[f"{name}_mean"] = rng.uniform(0.2, 0.6, c).astype(dtype)

@@ -35,9 +35,25 @@ assert sorted(local) == qd.partition(n_vol, world, rank)
 tmax = qd.allreduce_max(1.0 + rank)
 w = qd.broadcast_array(np.arange(6.0) * (1 if rank == 0 else -1))
 g = qd.allgather_scalars([rank, 10 * rank])
+# the configs[4] driver exactly as bench.py uses it: weights made on rank 0 and broadcast ONCE, volumes partitioned,
+# per-volume work between barriers, scalars gathered
+weights = {"k": np.full((3, 2), 7.0 if rank == 0 else -1.0, np.float32), "b": np.arange(4, dtype=np.float32) * (rank == 0)}
+weights = qd.broadcast_weights(weights)
+resident = []
+def setup(vs):
+    resident.extend(vs)
+def vol(v):
+    out = work(v)
+    out["w"] = float(weights["k"][0, 0] + weights["b"][3])
+    return out
+batch = qd.run_batch(n_vol, vol, setup=setup)
+assert resident == qd.partition(n_vol, world, rank)
 qd.barrier()
 print("RESULT " + json.dumps({"rank": rank, "owned": sorted(local), "tmax": tmax, "w": w.tolist(),
-                              "g": g.tolist(), "summary": {k: v.tolist() for k, v in summary.items()}}))
+                              "g": g.tolist(), "summary": {k: v.tolist() for k, v in summary.items()},
+                              "batch": {"per_rank": batch["per_rank"], "wall_s": batch["wall_s"], "volumes": batch["volumes"],
+                                        "busy": batch["rank_busy_s"],
+                                        "summary": {k: v.tolist() for k, v in batch["summary"].items()}}}))
 '''
 
 
@@ -77,6 +93,12 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res[0]["summary"]["rank"] == [0.0, 1.0, 0.0, 1.0, 0.0]
     assert res[0]["summary"]["voxels"] == [64.0] * 5
     assert all(15 < t < 80 for t in res[0]["summary"]["mean_tc"])
+    # run_batch (BASELINE configs[4] driver): same partition, weights of rank 0 everywhere (7 + 3), one wall time
+    b0, b1 = res[0]["batch"], res[1]["batch"]
+    assert b0["per_rank"] == b1["per_rank"] == [3, 2] and b0["volumes"] == 5
+    assert b0["summary"] == b1["summary"] and b0["summary"]["w"] == [10.0] * 5
+    assert b0["summary"]["rank"] == [0.0, 1.0, 0.0, 1.0, 0.0]
+    assert b0["wall_s"] == b1["wall_s"] >= max(b0["busy"]) > 0 and len(b0["busy"]) == 2
 
 
 def test_partition_covers_everything_once():

@@ -379,3 +379,67 @@ class TestPolyFitter:
         popt, _ = PolyFitter(deg=1, out_ufuncs=[lambda v: v + 1, lambda v: v + 2]).fit(x, y)
         assert np.allclose(popt[..., 0].A, a + 1) and np.allclose(popt[..., 1].A, b + 2)
         assert "deg=2" in str(PolyFitter(deg=2, rcond=0.5, y_bounds=(0, 200), r2_threshold=0.9))
+
+
+def test_process_params_matrix_vs_reference_golden(golden, relerr):
+    """Every case of the g5 golden (the reference's `_process_params` matrix, /root/reference/tests/core/test_fitting.py:
+    325-412, made by running the real `dosma.CurveFitter(**case).fit`) through THIS package's CurveFitter on the GPU:
+    bounds spellings (fused epilogue), ufunc spellings (host route after the GPU fit), r2 thresholds, nan_to_num, p0."""
+    g = golden("g5_process_params.npz")
+    x, y = g["x"], g["y"]
+    vols = [MedicalVolume(np.array(v), np.eye(4)) for v in y]
+    ufunc = lambda v: 2 * np.abs(v) + 5  # noqa: E731
+    cases = {
+        "bounds_all": dict(out_bounds=(0, 1.2)),
+        "bounds_second": dict(out_bounds=[(-np.inf, np.inf), (0, 1.2)]),
+        "bounds_first": dict(out_bounds=[(0, 1.2)]),
+        "nan_to_num": dict(out_bounds=(0, 1.2), nan_to_num=0.0),
+        "ufunc_all": dict(out_ufuncs=ufunc),
+        "ufunc_second": dict(out_ufuncs=[None, ufunc]),
+        "ufunc_first": dict(out_ufuncs=[ufunc]),
+        "r2_none": dict(r2_threshold=None),
+        "r2_099": dict(r2_threshold=0.9999, nan_to_num=-1.0),
+        "p0_tuple": dict(p0=(1.0, 0.5)),
+    }
+    for name, kw in cases.items():
+        popt, r2 = CurveFitter(monoexponential, **kw).fit(x, vols)
+        assert popt.shape == g[f"popt_{name}"].shape and r2.shape == g[f"r2_{name}"].shape, name
+        assert relerr(popt.volume, g[f"popt_{name}"]).max() < 1e-4, name   # NaN pattern identical, values to 1e-4 rel
+        assert np.abs(r2.volume - g[f"r2_{name}"]).max() < 1e-6, name
+
+
+def test_solver_kwargs_are_forwarded():
+    """CurveFitter(**kwargs) / curve_fit(**kwargs) reach the solver like the reference's do (fitting.py:422-435 ->
+    :755-768 -> scipy): maxfev / ftol / eps by name, the MINPACK options xtol / gtol / factor; checked against the C
+    restatement run with the same options."""
+    from oracle import fit_oracle as fo
+
+    rng = np.random.default_rng(11)
+    x = np.arange(1, 9) * 10.0
+    n = 4000
+    y = rng.uniform(300, 1500, n) * np.exp(-x[:, None] / rng.uniform(15, 80, n)) + 15 * rng.standard_normal((8, n))
+    p0 = (1.0, -1 / 30.0)
+    ref_popt, ref_r2 = fo.curve_fit_c(x, y, p0, maxfev=50)
+    popt, r2 = curve_fit(monoexponential, x, y, p0=p0, maxfev=50)
+    failed = np.isnan(ref_popt[:, 0])
+    assert 0.05 < failed.mean() < 0.999 and np.array_equal(np.isnan(popt[:, 0]), failed)  # maxfev = 50 really binds (the default 100 fails none of these)
+    ok = ~failed
+    assert np.abs(popt[ok] / ref_popt[ok] - 1).max() < 1e-4
+    vols = [MedicalVolume(v.reshape(40, 10, 10), np.eye(4)) for v in y]
+    pm, _ = CurveFitter(monoexponential, p0=p0, r2_threshold=None, maxfev=50).fit(x, vols)
+    assert np.array_equal(np.isnan(pm.volume[..., 0].reshape(-1)), failed)
+    # a looser ftol stops earlier: fewer evaluations than the default on most voxels, same answer class
+    loose, _ = curve_fit(monoexponential, x, y, p0=p0, ftol=1e-2)
+    ref_loose, _ = fo.curve_fit_c(x, y, p0, ftol=1e-2)
+    # (stopping this early leaves most voxels far from the minimum, where the trajectory is sensitive to the last bit:
+    #  the bulk must agree to 1e-4, the tail to 1e-2; and the option must have had an effect at all)
+    rel = np.abs(loose / ref_loose - 1).max(axis=1)
+    assert np.quantile(rel, 0.99) < 1e-4 and rel.max() < 1e-2
+    default, _ = curve_fit(monoexponential, x, y, p0=p0)
+    assert (np.abs(loose / default - 1).max(axis=1) > 1e-3).mean() > 0.5
+    tight, _ = curve_fit(monoexponential, x, y, p0=p0, xtol=1e-3, factor=10.0, method="lm")
+    ref_tight, _ = fo.curve_fit_c(x, y, p0, xtol=1e-3, factor=10.0)
+    good = ~np.isnan(ref_tight[:, 0])
+    assert np.array_equal(np.isnan(tight[:, 0]), ~good) and np.abs(tight[good] / ref_tight[good] - 1).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        CurveFitter(monoexponential, sigma=np.ones(8)).fit(x, vols)

@@ -168,3 +168,60 @@ def test_quantitative_values_to_metrics():
     assert "r2" in qv.additional_volumes
     with pytest.raises(TypeError):
         qv.add_additional_volume("r2", np.ones(3))
+
+
+G8_CALLS = {
+    "nomask": lambda qv, m: qv.to_metrics(),
+    "auto": lambda qv, m: qv.to_metrics(m),
+    "subset": lambda qv, m: qv.to_metrics(m, labels={3: "tc", 1: "fc"}),
+    "b_right": lambda qv, m: qv.to_metrics(m, bounds=(20.0, 60.0), closed="right"),
+    "b_left": lambda qv, m: qv.to_metrics(m, bounds=(20.0, 60.0), closed="left"),
+    "b_both": lambda qv, m: qv.to_metrics(m, bounds=(20.0, 60.0), closed="both"),
+    "b_neither": lambda qv, m: qv.to_metrics(m, bounds=(20.0, 60.0), closed="neither"),
+    "b_nomask": lambda qv, m: qv.to_metrics(bounds=(20.0, 60.0)),
+    "empty": lambda qv, m: qv.to_metrics(m, labels={4: "men"}, bounds=(1000.0, 2000.0)),
+}
+
+
+def check_against_g8(g, tag, case, df, exact_moments):
+    """One DataFrame against the real reference's (tests/golden/g8_to_metrics.npz, made by oracle/make_golden.py g8
+    from /root/reference/dosma/core/quant_vals.py:145-229).  Counts and medians are exact; means / standard deviations
+    are exact when the evaluation is numpy's own (host route), else fp64 sums in another order."""
+    key = f"{tag}_{case}"
+    assert list(df["Category"]) == list(g[f"{key}_category"]), key
+    assert np.array_equal(df["# Voxels"].to_numpy(np.float64), g[f"{key}_count"]), key
+    f32 = tag == "float32"
+    for col, name in (("Median", "median"), ("Mean", "mean"), ("Std", "std")):
+        ours, ref = df[col].to_numpy(np.float64), g[f"{key}_{name}"]
+        assert np.array_equal(np.isnan(ours), np.isnan(ref)), (key, col)
+        ok = ~np.isnan(ref)
+        if name == "median" or exact_moments:
+            assert np.array_equal(ours[ok], ref[ok]), (key, col, ours, ref)
+        else:  # float32 maps: numpy (the reference) accumulates in float32, the kernel in float64
+            tol = 2e-6 if f32 else 1e-12
+            assert np.all(np.abs(ours[ok] - ref[ok]) <= tol * np.maximum(1.0, np.abs(ref[ok]))), (key, col, ours, ref)
+
+
+@pytest.mark.parametrize("tag", ["float64", "float32"])
+def test_to_metrics_host_route_vs_reference_golden(golden, tag):
+    """The host (numpy) route of to_metrics -- taken whenever `fns` holds user callables -- against the reference's own
+    output on the same seeded map: every column bit-equal."""
+    from dosma_amd.quant_vals import T2
+
+    g = golden("g8_to_metrics.npz")
+    qv = T2(MedicalVolume(g["vol"].astype(tag), np.eye(4)))
+    mask = MedicalVolume(g["labels"], np.eye(4))
+    for case in G8_CALLS:
+        kw_fns = {"n": lambda v: v.size}
+        calls = {
+            "nomask": lambda: qv.to_metrics(fns=kw_fns),
+            "auto": lambda: qv.to_metrics(mask, fns=kw_fns),
+            "subset": lambda: qv.to_metrics(mask, labels={3: "tc", 1: "fc"}, fns=kw_fns),
+            "b_nomask": lambda: qv.to_metrics(bounds=(20.0, 60.0), fns=kw_fns),
+            "empty": lambda: qv.to_metrics(mask, labels={4: "men"}, bounds=(1000.0, 2000.0), fns=kw_fns),
+        }
+        if case.startswith("b_") and case != "b_nomask":
+            df = qv.to_metrics(mask, bounds=(20.0, 60.0), closed=case[2:], fns=kw_fns)
+        else:
+            df = calls[case]()
+        check_against_g8(g, tag, case, df.drop(columns=["n"]), exact_moments=True)

@@ -139,3 +139,20 @@ def test_device_pointer_entry_matches_the_host_entry():
     assert np.array_equal(got[:, [0, 3]], want[:, [0, 3]]) and np.allclose(got, want, rtol=1e-12, equal_nan=True)
     whole = L.region_stats_device(tv.data_ptr(), np.float64, n, stream=st)
     assert whole[0, 0] == np.isfinite(v).sum() and whole[0, 3] == np.nanmedian(v)
+
+
+@pytest.mark.parametrize("tag", ["float64", "float32"])
+def test_to_metrics_vs_reference_golden(golden, tag):
+    """region_stats.hip against the REAL reference's DataFrames (tests/golden/g8_to_metrics.npz, produced by
+    oracle/make_golden.py g8 from /root/reference/dosma/core/quant_vals.py:145-229): label maps, `labels` subsets,
+    `bounds` with the four `closed=` modes (values exactly on both interval ends are in the map), NaN / +-inf voxels,
+    an empty region, float64 and float32 maps.  Counts and medians exact; means / standard deviations to 1e-12
+    (float32 maps: the reference sums in float32)."""
+    from test_host_logic import G8_CALLS, check_against_g8
+
+    g = golden("g8_to_metrics.npz")
+    qv = T2(dm.MedicalVolume(g["vol"].astype(tag), np.eye(4)))
+    mask = dm.MedicalVolume(g["labels"], np.eye(4))
+    assert QuantitativeValue._region_stats_gpu(qv.volumetric_map.volume, None, None, None, "right") is not None  # the GPU route is live
+    for case, call in G8_CALLS.items():
+        check_against_g8(g, tag, case, call(qv, mask), exact_moments=False)

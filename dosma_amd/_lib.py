@@ -126,13 +126,15 @@ class QmriLmfitArgs(ctypes.Structure):
 
 MODELS = {"monoexponential": 0, "biexponential": 1}
 MODEL_NPARAMS = {"monoexponential": 2, "biexponential": 4}
-PRECISION = {"bf16": 0, "bf16x3": 1}
+# "fp16x3" is the parity mode (logits within 1e-3 of an fp64 run); "fp16x3-general" forces it onto the general
+# convolution kernel in the operator-level entry (tests); "bf16" is the single-MFMA throughput mode
+PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2}
 
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
     "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
-    "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_forward", "qmri_unet2d_destroy",
+    "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_trace", "qmri_unet2d_forward", "qmri_unet2d_destroy",
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
@@ -220,6 +222,8 @@ def load():
         lib.qmri_unet2d_create.restype = ctypes.c_int
         lib.qmri_unet2d_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         lib.qmri_unet2d_set_precision.restype = ctypes.c_int
+        lib.qmri_unet2d_trace.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]
+        lib.qmri_unet2d_trace.restype = ctypes.c_int
         lib.qmri_unet2d_forward.argtypes = [
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
             ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
@@ -506,7 +510,7 @@ def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds
 
 
 def conv2d_nhwc_host(x, kernel, bias, *, scale=None, shift=None, relu=True, transposed=False,
-                     precision="bf16x3", device=None):
+                     precision="fp16x3", device=None):
     """One conv layer on the GPU from host arrays: x (B,H,W,Cin) f32; kernel in the Keras layout --
     (3,3,Cin,Cout) for Conv2D, (3,3,Cout,Cin) for Conv2DTranspose(strides=2).  Returns NHWC f32."""
     lib = load()
@@ -531,7 +535,7 @@ class Unet2dEngine:
     """Owns a native U-Net instance (weights packed on the GPU + activation buffers)."""
 
     def __init__(self, tensors, H, W, *, depth=6, base_features=32, n_classes=4, max_batch=16,
-                 precision="bf16x3", device=None, bn_eps=1e-3):
+                 precision="fp16x3", device=None, bn_eps=1e-3):
         lib = load()
         require_device()
         self._lib = lib
@@ -549,7 +553,15 @@ class Unet2dEngine:
         self.H, self.W, self.n_classes, self.max_batch = int(H), int(W), int(n_classes), int(max_batch)
 
     def set_precision(self, precision):
+        if precision == "fp16x3-general":
+            raise ValueError("the engine picks its kernels itself: 'fp16x3' or 'bf16'")
         check(self._lib.qmri_unet2d_set_precision(self._handle, PRECISION[precision]))
+
+    def trace(self):
+        """Kernel family of every layer of the last forward batch: ["down0.conv1:c1/split", "down0.conv2:s3/2d/bn32", ...]."""
+        buf = ctypes.create_string_buffer(8192)
+        self._lib.qmri_unet2d_trace(self._handle, buf, len(buf))
+        return [t for t in buf.value.decode().split(";") if t]
 
     def forward_host(self, x, *, whiten=False, eps=0.0, want_logits=True, want_mask=True):
         """x (S, H, W) float32 host array -> (logits (S,H,W,C) f32 | None, mask (S,H,W,C) u8 | None)."""

@@ -108,7 +108,8 @@ struct ConvKArgs {
     int tiles_y, tiles_x;     // filled by conv_igemm_launch
     int halo_bufs;            // filled by conv_igemm_launch: 2 (double-buffered halo) or 1 (single K chunk)
     const __bf16 *w_hi;  // [Cout][chunk][tap][32] bf16: K index = (chunk*ntaps + tap)*32 + c (K-major per cout)
-    const __bf16 *w_lo;  // low parts (SPLIT3) or nullptr
+    const __bf16 *w_lo;  // parity mode: w_hi / w_lo hold the fp16 hi / lo parts of 2^wshift * weights (same 2-byte slots)
+    float winv;          // parity mode: 2^-wshift (the accumulators hold 2^wshift * convolution)
     const float *bias;   // [Cout] or nullptr
     const float *scale;  // [Cout] or nullptr   y = scale * relu(acc + bias) + shift
     const float *shift;
@@ -132,6 +133,45 @@ struct ConvKArgs {
     unsigned char *mask; // [pixels][head_nc]  (logit > 0)
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
+
+// Parity-mode ("fp16x3") 3x3 convolution on SPLIT activations (unet_s3.hip).  Activation layout (x, y, pool_y): per pixel
+// `ld` channel slots of 4 bytes; the 32-channel chunk starting at channel c (a multiple of 32) is the 128 bytes at
+// ((pixel * ld + off + c) * 4): 32 fp16 hi parts, then 32 fp16 lo parts (value = hi + lo).
+struct ConvS3Args {
+    const void *x;
+    long long ldx;
+    int xoff;
+    int B, H, W;
+    int Cin, Cout;
+    const void *w;       // packed by pack_s3_weights: [Cout / BN][chunk * 9 + tap][plane hi | lo][BN][4 x 16 B swizzled], fp16, x 2^wshift
+    float winv;          // 2^-wshift: the accumulators hold 2^wshift * convolution
+    const float *bias;   // [Cout] or nullptr
+    const float *scale;  // [Cout] or nullptr   y = scale * relu(acc * winv + bias) + shift
+    const float *shift;
+    int relu;
+    void *y;             // nullable (head-only layer)
+    long long ldy;
+    int yoff;
+    void *pool_y;        // fused MaxPooling2D(2x2), compact split layout with pool_ld channel slots per pixel (nullable)
+    int pool_ld;
+    int head_nc;         // fused 1x1 head (Cout = 32 only)
+    const float *head_w; // [32][head_nc]
+    const float *head_b;
+    float *logits;
+    unsigned char *mask;
+    // filled by conv_s3_launch
+    int chunks, steps, nb, ntiles, nwork, tiles_x, tiles_y, P, nj;
+};
+bool conv_s3_supported(const ConvS3Args &k);
+int conv_s3_block_channels(int Cout);  // channel-block size the kernel uses for a layer: the weight packing depends on it
+hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
+// streaming kernels on the split layout (unet_s3.hip)
+hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
+                           long long ldy, int yoff, hipStream_t stream);
+hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream);
+hipError_t head_split_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC, float *logits,
+                             unsigned char *mask, hipStream_t stream);
+hipError_t split_cast_launch(const void *x, long long npix, int C, void *y, int to_split, hipStream_t stream);
 // register-weights kernel for the Cout = 32 layers in plain-bf16 mode (unet_rw.hip)
 bool conv_rw_supported(const ConvKArgs &k);
 hipError_t conv_rw_launch(const ConvKArgs &k, hipStream_t stream);

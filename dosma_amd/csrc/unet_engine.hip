@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "qmri_internal.h"
@@ -70,13 +71,75 @@ struct DevBuf {
     }
 };
 
+// parity mode ("fp16x3"): weights are stored as fp16 hi + lo parts of 2^wshift * w.  The power-of-two pre-scale keeps the
+// lo parts of typical weights (|w| ~ 1e-2: lo ~ 5e-6) out of the fp16 subnormal range -- scripts/unet_precision_sim.py:
+// 1.7e-4 -> 1.4e-5 on the logits -- and is undone for free in the epilogue's first fma (acc * 2^-wshift + bias).
+int weight_shift(const std::vector<float> &wk) {
+    float m = 0.f;
+    for (float v : wk) m = std::fmax(m, std::fabs(v));
+    if (!(m > 0.f) || !std::isfinite(m)) return 0;
+    int e = 0;
+    std::frexp(m, &e);           // m = f * 2^e, f in [0.5, 1)
+    int sh = 14 - e;             // 2^sh * m in [2^13, 2^14): far below the fp16 maximum 65504
+    if (sh < -14) sh = -14;
+    if (sh > 24) sh = 24;
+    return sh;
+}
+void split_f16_host(float v, unsigned short &hi, unsigned short &lo) {
+    const _Float16 h = static_cast<_Float16>(v);  // round to nearest even
+    const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+    std::memcpy(&hi, &h, 2);
+    std::memcpy(&lo, &l, 2);
+}
+
 struct ConvLayer {
     int Cin = 0, Cout = 0, ntaps = 0;
     int dy[9] = {0}, dx[9] = {0};
     int relu = 0;
     int deconv = 0;
     DevBuf w_hi, w_lo, bias, scale, shift;
+    DevBuf h_hi, h_lo;   // parity mode, general kernel: fp16 hi / lo parts, same K-major layout as w_hi
+    DevBuf w_s3;         // parity mode, conv_s3_kernel: per channel block and K step the [plane][BN][64 B] LDS image
+    float winv = 1.f;    // 2^-wshift
     bool has_affine = false;
+
+    // fp16 hi / lo images of the host weights W[co][K] (K = (chunk * ntaps + tap) * 32 + c)
+    hipError_t upload_parity(const std::vector<float> &wk, bool for_s3) {
+        const int sh = weight_shift(wk);
+        const float sc = std::ldexp(1.f, sh);
+        winv = std::ldexp(1.f, -sh);
+        const size_t n = wk.size();
+        std::vector<unsigned short> hi(n), lo(n);
+        for (size_t i = 0; i < n; ++i) split_f16_host(wk[i] * sc, hi[i], lo[i]);
+        hipError_t e = hipSuccess;
+        if (!for_s3) {
+            e = h_hi.alloc(n * 2);
+            if (e == hipSuccess) e = h_lo.alloc(n * 2);
+            if (e == hipSuccess) e = hipMemcpy(h_hi.p, hi.data(), n * 2, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(h_lo.p, lo.data(), n * 2, hipMemcpyHostToDevice);
+            return e;
+        }
+        // conv_s3_kernel: [nb][step][plane][BN rows][4 positions x 8 halfs], position pos of row n holds the K piece
+        // q = pos ^ ((n >> 2) & 3) (the bank-conflict swizzle of the LDS image; the DMA copies the image linearly)
+        const int BN = qmri::conv_s3_block_channels(Cout);
+        const int steps = ntaps * (Cin / 32);
+        const size_t K = (size_t)steps * 32;
+        std::vector<unsigned short> img((size_t)Cout * K * 2);
+        for (int nb = 0; nb < Cout / BN; ++nb)
+            for (int st = 0; st < steps; ++st)
+                for (int plane = 0; plane < 2; ++plane)
+                    for (int r = 0; r < BN; ++r)
+                        for (int pos = 0; pos < 4; ++pos) {
+                            const int q = pos ^ ((r >> 2) & 3);
+                            const size_t src = (size_t)(nb * BN + r) * K + (size_t)st * 32 + q * 8;
+                            const size_t dst = ((((size_t)nb * steps + st) * 2 + plane) * BN + r) * 32 + pos * 8;
+                            const unsigned short *from = (plane ? lo.data() : hi.data()) + src;
+                            for (int k = 0; k < 8; ++k) img[dst + k] = from[k];
+                        }
+        e = w_s3.alloc(img.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        return e;
+    }
 
     // pack host weights W[co][t*Cin + ci] (fp32) into bf16 hi/lo and upload
     hipError_t upload(const std::vector<float> &wk, const float *b, const std::vector<float> *sc,
@@ -187,6 +250,7 @@ qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int 
         k.taps |= (unsigned long long)((L.dy[t] + 1) | ((L.dx[t] + 1) << 2)) << (4 * t);
     k.w_hi = L.w_hi.as<__bf16>();
     k.w_lo = L.w_lo.as<__bf16>();
+    k.winv = 1.f;
     k.bias = L.bias.as<float>();
     k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
     k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
@@ -203,8 +267,11 @@ qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int 
     return k;
 }
 
+bool s3_width_ok(int W) { return W % 32 == 0 || W + 2 <= 50; }  // what conv_s3_kernel tiles (unet_s3.hip: conv_s3_supported)
+
 struct Unet {
-    int depth = 0, ncls = 0, H = 0, W = 0, maxB = 0, device = 0, split3 = 1;
+    int depth = 0, ncls = 0, H = 0, W = 0, maxB = 0, device = 0, split3 = 1, num_cu = 256;
+    std::string trace;  // kernel family of every layer of the last forward batch (tests assert the dispatch)
     std::vector<int> nf;
     DevBuf c1_w, c1_b;  // first layer fp32: [9][nf0], [nf0]
     std::vector<std::unique_ptr<ConvLayer>> down1, down2, up1, up2;  // index by level
@@ -258,6 +325,11 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->maxB = d->max_batch;
     U->device = d->device;
     U->split3 = d->precision != 0;
+    {
+        hipDeviceProp_t prop;
+        U_TRY(hipGetDeviceProperties(&prop, d->device));
+        U->num_cu = prop.multiProcessorCount;
+    }
     for (int l = 0; l < d->depth; ++l) U->nf.push_back(d->base_features << l);
     if (U->nf[0] > 256) return ufail(QMRI_ERR_UNSUPPORTED, "base_features > 256");
     const double eps = d->bn_eps > 0 ? d->bn_eps : 1e-3;
@@ -303,12 +375,14 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             U->down1[l]->relu = 1;
             pack_conv3x3(k1, Cin, C, *U->down1[l], wk);
             U_TRY(U->down1[l]->upload(wk, b1, nullptr, nullptr));
+            U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
         }
         fold_bn(C, sc, sh);
         U->down2[l].reset(new ConvLayer);
         U->down2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->down2[l], wk);
         U_TRY(U->down2[l]->upload(wk, b2, &sc, &sh));
+        U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
     }
     for (int l = d->depth - 2; l >= 0; --l) {
         const int C = U->nf[l], Cup = U->nf[l + 1];
@@ -320,6 +394,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             L->relu = 0;
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
+            U_TRY(L->upload_parity(wk, false));
             if (U->split_levels >> l & 1u)
                 for (int ph = 0; ph < 4; ++ph) {
                     auto &P = U->updec_ph[(size_t)l * 4 + ph];
@@ -327,17 +402,20 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
                     P->relu = 0;
                     pack_deconv_phase(kd, Cup, C, ph >> 1, ph & 1, *P, wk);
                     U_TRY(P->upload(wk, bd, nullptr, nullptr));
+                    U_TRY(P->upload_parity(wk, false));
                 }
         }
         U->up1[l].reset(new ConvLayer);
         U->up1[l]->relu = 1;
         pack_conv3x3(k1, 2 * C, C, *U->up1[l], wk);
         U_TRY(U->up1[l]->upload(wk, b1, nullptr, nullptr));
+        U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
         fold_bn(C, sc, sh);
         U->up2[l].reset(new ConvLayer);
         U->up2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->up2[l], wk);
         U_TRY(U->up2[l]->upload(wk, b2, &sc, &sh));
+        U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
     }
     // head: Keras (1,1,C0,NC) == [C0][NC]
     U_TRY(U->head_w.alloc((size_t)U->nf[0] * U->ncls * 4));
@@ -376,23 +454,138 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     return QMRI_OK;
 }
 
+int qmri_unet2d_trace(void *handle, char *buf, int32_t size) {
+    if (!handle || !buf || size <= 0) return ufail(QMRI_ERR_ARG, "handle / buf is NULL");
+    const std::string &t = static_cast<Unet *>(handle)->trace;
+    std::snprintf(buf, (size_t)size, "%s", t.c_str());
+    return (int)t.size();
+}
+
 int qmri_unet2d_set_precision(void *handle, int32_t precision) {
     if (!handle) return ufail(QMRI_ERR_ARG, "handle is NULL");
     static_cast<Unet *>(handle)->split3 = precision != 0;
     return QMRI_OK;
 }
 
-// one batch of `Bt` slices already in U->in (device) -> logits / mask device pointers for that batch.
-// Activation buffers are allocated for fp32 and reinterpreted as bf16 in the plain-bf16 mode.
-static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hipStream_t st) {
+// ---- parity mode ("fp16x3"): activations in the split layout (qmri_internal.h: ConvS3Args), 3x3 convolutions on
+// conv_s3_kernel where it tiles the level (W % 32 == 0 or W <= 48), otherwise -- and for the transposed convolutions --
+// on the general kernel reading / writing the same layout.
+static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const void *x, long long ldx, int xoff, int Bt, int H,
+                          int W, void *y, long long ldy, int yoff, void *pool_y, int pool_ld, bool head, float *logits,
+                          unsigned char *mask, hipStream_t st) {
+    char buf[96];
+    if (L.w_s3.p) {
+        qmri::ConvS3Args k;
+        std::memset(&k, 0, sizeof(k));
+        k.x = x; k.ldx = ldx; k.xoff = xoff;
+        k.B = Bt; k.H = H; k.W = W;
+        k.Cin = L.Cin; k.Cout = L.Cout;
+        k.w = L.w_s3.p;
+        k.winv = L.winv;
+        k.bias = L.bias.as<float>();
+        k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
+        k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
+        k.relu = L.relu;
+        k.y = y; k.ldy = ldy; k.yoff = yoff;
+        const int bn = qmri::conv_s3_block_channels(L.Cout);
+        const bool flat = W % 32 != 0;
+        const bool fuse_pool = pool_y && !flat && bn >= 64 && !(H & 1);
+        if (fuse_pool) { k.pool_y = pool_y; k.pool_ld = pool_ld; }
+        const bool fuse_head = head && !flat && L.Cout == 32;
+        if (fuse_head) {
+            k.y = nullptr;  // the last feature map is only consumed by the head: never written to HBM
+            k.head_w = U->head_w.as<float>(); k.head_b = U->head_b.as<float>(); k.head_nc = U->ncls;
+            k.logits = logits; k.mask = mask;
+        }
+        U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
+        snprintf(buf, sizeof(buf), "%s:s3/%s/bn%d%s%s;", name, flat ? "flat" : "2d", bn, fuse_pool ? "+pool" : "", fuse_head ? "+head" : "");
+        U->trace += buf;
+        if (pool_y && !fuse_pool) {
+            U_TRY(qmri::maxpool2_split_launch(y, ldy, yoff, Bt, H, W, L.Cout, pool_y, st));
+            U->trace += "pool:split;";
+        }
+        if (head && !fuse_head) {
+            U_TRY(qmri::head_split_launch(y, (long long)Bt * H * W, L.Cout, U->head_w.as<float>(), U->head_b.as<float>(), U->ncls,
+                                          logits, mask, st));
+            U->trace += "head:split;";
+        }
+        return QMRI_OK;
+    }
+    auto k = conv_args(L, x, ldx, xoff, Bt, H, W, y, ldy, yoff, H, W, 1, 1, 0, 0);
+    k.w_hi = L.h_hi.as<__bf16>();
+    k.w_lo = L.h_lo.as<__bf16>();
+    k.winv = L.winv;
+    if (pool_y && !((H | W) & 1)) { k.pool_y = pool_y; k.pool_ld = pool_ld; }
+    U_TRY(qmri::conv_igemm_launch(k, 1, st));
+    snprintf(buf, sizeof(buf), "%s:igemm%s;", name, k.pool_y ? "+pool" : "");
+    U->trace += buf;
+    if (head) {
+        U_TRY(qmri::head_split_launch(y, (long long)Bt * H * W, L.Cout, U->head_w.as<float>(), U->head_b.as<float>(), U->ncls, logits,
+                                      mask, st));
+        U->trace += "head:split;";
+    }
+    return QMRI_OK;
+}
+
+static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *mask, hipStream_t st) {
     const int D = U->depth;
-    const int s3 = U->split3;
-    const int ab = s3 ? 0 : 1;  // activations stored as bf16?
-    const size_t es = ab ? 2 : 4;
-    auto at = [&](const DevBuf &b, long long elem_off) -> void * {
-        return static_cast<unsigned char *>(b.p) + (size_t)elem_off * es;
-    };
-    (void)at;
+    char nm[32];
+    for (int l = 0; l < D; ++l) {
+        const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
+        void *t1 = U->tmp[l]->p;
+        if (l == 0) {
+            U_TRY(qmri::c1_split_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(), C, t1, C, 0, st));
+            U->trace += "down0.conv1:c1/split;";
+        } else {
+            snprintf(nm, sizeof(nm), "down%d.conv1", l);
+            const int rc = conv3x3_parity(U, nm, *U->down1[l], U->pool[l]->p, U->nf[l - 1], 0, Bt, H, W, t1, C, 0, nullptr, 0, false,
+                                          nullptr, nullptr, st);
+            if (rc != QMRI_OK) return rc;
+        }
+        snprintf(nm, sizeof(nm), "down%d.conv2", l);
+        int rc;
+        if (l < D - 1)  // block output (post-BN) = the skip = 2nd half of the level's concat buffer; pooled copy -> next level
+            rc = conv3x3_parity(U, nm, *U->down2[l], t1, C, 0, Bt, H, W, U->cat[l]->p, 2 * C, C, U->pool[l + 1]->p, C, false, nullptr,
+                                nullptr, st);
+        else
+            rc = conv3x3_parity(U, nm, *U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, nullptr, 0, false, nullptr, nullptr, st);
+        if (rc != QMRI_OK) return rc;
+    }
+    const void *src = U->bottom.p;
+    for (int l = D - 2; l >= 0; --l) {
+        const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
+        void *cat = U->cat[l]->p;
+        {
+            const ConvLayer &L = *U->updec[(size_t)l];
+            auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
+            k.w_hi = L.h_hi.as<__bf16>();
+            k.w_lo = L.h_lo.as<__bf16>();
+            k.winv = L.winv;
+            U_TRY(qmri::conv_igemm_launch(k, 1, st));
+            snprintf(nm, sizeof(nm), "up%d.deconv:igemm;", l);
+            U->trace += nm;
+        }
+        void *t1 = U->tmp[l]->p;
+        snprintf(nm, sizeof(nm), "up%d.conv1", l);
+        int rc = conv3x3_parity(U, nm, *U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, nullptr, 0, false, nullptr, nullptr, st);
+        if (rc != QMRI_OK) return rc;
+        void *out = U->upout[l]->p;
+        snprintf(nm, sizeof(nm), "up%d.conv2", l);
+        rc = conv3x3_parity(U, nm, *U->up2[l], t1, C, 0, Bt, H, W, out, C, 0, nullptr, 0, l == 0, logits, mask, st);
+        if (rc != QMRI_OK) return rc;
+        src = out;
+    }
+    return QMRI_OK;
+}
+
+// one batch of `Bt` slices already in U->in (device) -> logits / mask device pointers for that batch.
+// Activation buffers are allocated for 4 bytes per channel (split fp16 hi | lo) and reinterpreted as bf16 in the plain mode.
+static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hipStream_t st) {
+    U->trace.clear();
+    if (U->split3) return forward_batch_parity(U, Bt, logits, mask, st);
+    const int D = U->depth;
+    const int s3 = 0;
+    const int ab = 1;  // activations stored as bf16
     // ---- contracting path ----
     for (int l = 0; l < D; ++l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
@@ -586,7 +779,7 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
     if (Cin % 32 || Cout % 32) return ufail(QMRI_ERR_UNSUPPORTED, "Cin and Cout must be multiples of 32");
     U_TRY(hipSetDevice(device));
     const int Ho = transposed ? 2 * H : H, Wo = transposed ? 2 * W : W;
-    const int ab = precision == 0;  // plain bf16 mode: bf16 activations on the device
+    const int ab = precision == 0;  // plain bf16 mode: bf16 activations on the device; parity mode: the split layout
     const long long nx = (long long)B * H * W * Cin, ny = (long long)B * Ho * Wo * Cout;
     DevBuf dx, dy, dxb, dyb;
     U_TRY(dx.alloc((size_t)nx * 4));
@@ -596,6 +789,10 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         U_TRY(dxb.alloc((size_t)nx * 2));
         U_TRY(dyb.alloc((size_t)ny * 2));
         U_TRY(qmri::cast_launch(dx.p, nx, dxb.p, 1, nullptr));
+    } else {
+        U_TRY(dxb.alloc((size_t)nx * 4));
+        U_TRY(dyb.alloc((size_t)ny * 4));
+        U_TRY(qmri::split_cast_launch(dx.p, (long long)B * H * W, Cin, dxb.p, 1, nullptr));
     }
     std::vector<float> wk, sc, sh;
     if (scale && shift) {
@@ -610,15 +807,38 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         else
             pack_conv3x3(kernel, Cin, Cout, L, wk);
         U_TRY(L.upload(wk, bias, sc.empty() ? nullptr : &sc, sc.empty() ? nullptr : &sh));
-        auto k = conv_args(L, ab ? dxb.p : dx.p, Cin, 0, B, H, W, ab ? dyb.p : dy.p, Cout, 0, Ho, Wo,
-                           transposed ? 2 : 1, transposed ? 2 : 1, 0, 0);
-        U_TRY(qmri::conv_igemm_launch(k, precision != 0, nullptr));
+        hipDeviceProp_t prop;
+        U_TRY(hipGetDeviceProperties(&prop, device));
+        // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
+        const bool s3 = !ab && !transposed && precision != 2 && s3_width_ok(W);
+        if (!ab) U_TRY(L.upload_parity(wk, s3));
+        if (s3) {
+            qmri::ConvS3Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.x = dxb.p; k.ldx = Cin; k.B = B; k.H = H; k.W = W; k.Cin = Cin; k.Cout = Cout;
+            k.w = L.w_s3.p; k.winv = L.winv;
+            k.bias = L.bias.as<float>();
+            k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
+            k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
+            k.relu = relu;
+            k.y = dyb.p; k.ldy = Cout;
+            U_TRY(qmri::conv_s3_launch(k, prop.multiProcessorCount, nullptr));
+        } else {
+            auto k = conv_args(L, dxb.p, Cin, 0, B, H, W, dyb.p, Cout, 0, Ho, Wo, transposed ? 2 : 1, transposed ? 2 : 1, 0, 0);
+            if (!ab) {
+                k.w_hi = L.h_hi.as<__bf16>();
+                k.w_lo = L.h_lo.as<__bf16>();
+                k.winv = L.winv;
+            }
+            U_TRY(qmri::conv_igemm_launch(k, !ab, nullptr));
+        }
         U_TRY(hipDeviceSynchronize());
     }
-    if (ab) {
+    if (ab)
         U_TRY(qmri::cast_launch(dyb.p, ny, dy.p, 0, nullptr));
-        U_TRY(hipDeviceSynchronize());
-    }
+    else
+        U_TRY(qmri::split_cast_launch(dyb.p, (long long)B * Ho * Wo, Cout, dy.p, 0, nullptr));
+    U_TRY(hipDeviceSynchronize());
     U_TRY(hipMemcpy(y, dy.p, (size_t)B * Ho * Wo * Cout * 4, hipMemcpyDeviceToHost));
     return QMRI_OK;
 }

@@ -29,6 +29,8 @@
 namespace qmri {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kBK = 32;         // channels per K step (one tap x 32 input channels)
@@ -56,22 +58,20 @@ struct TileCfg {
     static constexpr int WALL_PAIRS = (9 * BN * 4 + NT - 1) / NT;
 };
 
-__device__ __forceinline__ void split_bf16(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo,
-                                           bool want_lo) {
-    hi[0] = static_cast<__bf16>(a.x); hi[1] = static_cast<__bf16>(a.y);
-    hi[2] = static_cast<__bf16>(a.z); hi[3] = static_cast<__bf16>(a.w);
-    hi[4] = static_cast<__bf16>(b.x); hi[5] = static_cast<__bf16>(b.y);
-    hi[6] = static_cast<__bf16>(b.z); hi[7] = static_cast<__bf16>(b.w);
-    if (want_lo) {
-        lo[0] = static_cast<__bf16>(a.x - static_cast<float>(hi[0]));
-        lo[1] = static_cast<__bf16>(a.y - static_cast<float>(hi[1]));
-        lo[2] = static_cast<__bf16>(a.z - static_cast<float>(hi[2]));
-        lo[3] = static_cast<__bf16>(a.w - static_cast<float>(hi[3]));
-        lo[4] = static_cast<__bf16>(b.x - static_cast<float>(hi[4]));
-        lo[5] = static_cast<__bf16>(b.y - static_cast<float>(hi[5]));
-        lo[6] = static_cast<__bf16>(b.z - static_cast<float>(hi[6]));
-        lo[7] = static_cast<__bf16>(b.w - static_cast<float>(hi[7]));
+// Parity mode ("fp16x3"): activations are stored SPLIT -- per pixel and 32-channel chunk 32 fp16 hi parts, then 32 fp16
+// lo parts (see ConvS3Args in qmri_internal.h).  8 fp32 values -> their 8 hi (lo) parts as 16 bytes.  hi is rounded
+// toward zero (v_cvt_pkrtz: one instruction per pair, never overflows to inf), lo = rtz(v - hi): 21+ significant bits.
+__device__ __forceinline__ void split_f16(const float (&v)[8], uint4 &hi, uint4 &lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h16x2 hh = __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]);
+        const h16x2 ll = __builtin_amdgcn_cvt_pkrtz(v[2 * q] - (float)hh[0], v[2 * q + 1] - (float)hh[1]);
+        h[q] = __builtin_bit_cast(unsigned, hh);
+        l[q] = __builtin_bit_cast(unsigned, ll);
     }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 template <int BN, int TH, bool SPLIT3, typename AT, bool DECONV, bool C1 = false, int TW = 16, int NW = 4, int WN = 0>
@@ -87,8 +87,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
     // its phase's accumulator, and the epilogue writes four interleaved output tiles.  The input halo is
     // fetched once instead of four times and the launch count drops 4x.
     constexpr int NPH = DECONV ? 4 : 1;
-    constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode) or fp32
-    static_assert(!(SPLIT3 && ACT_BF16), "split-bf16 needs fp32 activations");
+    constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode), or split fp16 hi | lo (SPLIT3;
+                                                // AT = float is then only the type of the epilogue's LDS tile)
+    static_assert(SPLIT3 != ACT_BF16, "plain mode: bf16 activations; parity mode: split fp16 activations");
     constexpr bool WALL = BN <= 64 && !SPLIT3;
     using C = TileCfg<BN, TH, WALL, TW, NW, WN>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
@@ -138,12 +139,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
         const int hy = hp / (kTW + 2), hx = hp - hy * (kTW + 2);
         const int yy = y0 + hy - 1, xx = x0 + hx - 1;
         const bool ok = hp < C::HALO_PIX && yy >= 0 && yy < A.H && xx >= 0 && xx < A.W;
-        h_src[r] = ok ? (img_base + (long long)yy * A.W + xx) * A.ldx + A.xoff + grp * 8 : -1;
+        h_src[r] = ok ? (img_base + (long long)yy * A.W + xx) * A.ldx + A.xoff + (SPLIT3 ? 0 : grp * 8) : -1;
         h_dst[r] = hp < C::HALO_PIX ? (hp * kLdsRow + grp * 8) * 2 : -1;
     }
 
-    float4 rh0[C::HALO_PAIRS], rh1[C::HALO_PAIRS];  // fp32 activations: 8 channels = 2 x float4
-    bf16x8 rhb[C::HALO_PAIRS];                       // bf16 activations: 8 channels = 16 bytes
+    bf16x8 rhb[C::HALO_PAIRS];  // 8 channels = 16 bytes: bf16 values, or the fp16 hi parts (the registers only move bits)
+    bf16x8 rhl[C::HALO_PAIRS];  // parity mode: the fp16 lo parts
     bf16x8 rb_hi[WALL ? C::WALL_PAIRS : C::B_PAIRS], rb_lo[C::B_PAIRS];
     const int ntaps = A.ntaps;
     const int K = ntaps * A.Cin;
@@ -153,17 +154,19 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
 #define QMRI_LOAD_HALO(c0_)                                                                        \
     _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                    \
         const bool ok_ = h_src[r] >= 0;                                                            \
-        const AT *p_ = static_cast<const AT *>(A.x) + (ok_ ? h_src[r] : 0) + (c0_);                \
+        bf16x8 z_;                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) z_[q] = static_cast<__bf16>(0.f);            \
         if constexpr (ACT_BF16) {                                                                  \
+            const __bf16 *p_ = static_cast<const __bf16 *>(A.x) + (ok_ ? h_src[r] : 0) + (c0_);    \
             const bf16x8 v_ = *reinterpret_cast<const bf16x8 *>(p_);                               \
-            bf16x8 z_;                                                                             \
-            _Pragma("unroll") for (int q = 0; q < 8; ++q) z_[q] = static_cast<__bf16>(0.f);        \
             rhb[r] = ok_ ? v_ : z_;                                                                \
-        } else {                                                                                   \
-            const float4 v0_ = *reinterpret_cast<const float4 *>(p_);                              \
-            const float4 v1_ = *reinterpret_cast<const float4 *>(p_ + 4);                          \
-            rh0[r] = ok_ ? v0_ : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
-            rh1[r] = ok_ ? v1_ : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+        } else { /* split: chunk at ((pixel * ld + off + c0) * 4) bytes: [32 hi][32 lo] fp16 */    \
+            const unsigned char *p_ = static_cast<const unsigned char *>(A.x) +                    \
+                                      ((ok_ ? h_src[r] : 0) + (c0_)) * 4 + (tid & 3) * 16;         \
+            const bf16x8 v_ = *reinterpret_cast<const bf16x8 *>(p_);                               \
+            const bf16x8 w_ = *reinterpret_cast<const bf16x8 *>(p_ + 64);                          \
+            rhb[r] = ok_ ? v_ : z_;                                                                \
+            rhl[r] = ok_ ? w_ : z_;                                                                \
         }                                                                                          \
     }
 #define QMRI_STORE_HALO(buf_)                                                                      \
@@ -171,14 +174,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
         unsigned char *base_ = halo_base + (buf_) * NPLANES * HALO_BYTES;                          \
         _Pragma("unroll") for (int r = 0; r < C::HALO_PAIRS; ++r) {                                \
             if (h_dst[r] >= 0) {                                                                   \
-                if constexpr (ACT_BF16) {                                                          \
-                    *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = rhb[r];                        \
-                } else {                                                                           \
-                    bf16x8 hi_, lo_;                                                               \
-                    split_bf16(rh0[r], rh1[r], hi_, lo_, SPLIT3);                                  \
-                    *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = hi_;                           \
-                    if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + HALO_BYTES + h_dst[r]) = lo_;  \
-                }                                                                                  \
+                *reinterpret_cast<bf16x8 *>(base_ + h_dst[r]) = rhb[r];                            \
+                if (SPLIT3) *reinterpret_cast<bf16x8 *>(base_ + HALO_BYTES + h_dst[r]) = rhl[r];   \
             }                                                                                      \
         }                                                                                          \
     }
@@ -287,8 +284,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rhb[r][c] = static_cast<__bf16>(o[c]);
             } else {
-                rh0[r] = make_float4(o[0], o[1], o[2], o[3]);
-                rh1[r] = make_float4(o[4], o[5], o[6], o[7]);
+                uint4 hi_, lo_;
+                split_f16(o, hi_, lo_);
+                rhb[r] = __builtin_bit_cast(bf16x8, hi_);
+                rhl[r] = __builtin_bit_cast(bf16x8, lo_);
             }
         }
     }
@@ -351,11 +350,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
                 }                                                                                       \
                 _Pragma("unroll") for (int i = 0; i < C::TM; ++i)                                       \
                 _Pragma("unroll") for (int j = 0; j < C::TN; ++j) {                                     \
-                    if (SPLIT3) {                                                                       \
-                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[ph_][i][j], 0, 0, 0); \
-                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[ph_][i][j], 0, 0, 0); \
+                    if constexpr (SPLIT3) { /* fp16 parts: lo*hi + hi*lo + hi*hi */                       \
+                        const f16x8 ah_ = __builtin_bit_cast(f16x8, a_hi[i]), al_ = __builtin_bit_cast(f16x8, a_lo[i]); \
+                        const f16x8 bh_ = __builtin_bit_cast(f16x8, b_hi[j]), bl_ = __builtin_bit_cast(f16x8, b_lo[j]); \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, acc[ph_][i][j], 0, 0, 0); \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, acc[ph_][i][j], 0, 0, 0); \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, acc[ph_][i][j], 0, 0, 0); \
+                    } else {                                                                            \
+                        acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[ph_][i][j], 0, 0, 0); \
                     }                                                                                   \
-                    acc[ph_][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[ph_][i][j], 0, 0, 0); \
                 }                                                                                       \
             }                                                                                           \
             ++step;                                                                                     \
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + (e & 3) + 8 * (e >> 2);
-                float v = acc[ph][i][j][e] + bias;
+                float v = SPLIT3 ? fmaf(acc[ph][i][j][e], A.winv, bias) : acc[ph][i][j][e] + bias;
                 if (A.relu) v = fmaxf(v, 0.f);
                 v = v * scale + shift;
                 otile[row * BN + col] = static_cast<AT>(v);
@@ -421,12 +424,24 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
             const int row = idx / CH, c = idx - row * CH;
             const int pix = rowpix[row];
             if (pix >= 0) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(otile) +
-                                                                 (size_t)row * BN * sizeof(AT) + c * 16);
                 unsigned char *dst = static_cast<unsigned char *>(A.y) +
                                      ((long long)(pix + ph_off) * A.ldy + A.yoff + n0) * (long long)sizeof(AT) +
                                      c * 16;
-                *reinterpret_cast<uint4 *>(dst) = v;
+                if constexpr (SPLIT3) {
+                    // 16-byte piece c of the pixel's split run: chunk c / 8, pieces 0-3 = hi parts, 4-7 = lo parts of
+                    // channels (c & 3) * 8 .. + 8 of that chunk
+                    const float *src = reinterpret_cast<const float *>(otile) + (size_t)row * BN + (c >> 3) * 32 + (c & 3) * 8;
+                    float v8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v8[q] = src[q];
+                    uint4 hi_, lo_;
+                    split_f16(v8, hi_, lo_);
+                    *reinterpret_cast<uint4 *>(dst) = (c & 4) ? lo_ : hi_;
+                } else {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(otile) +
+                                                                     (size_t)row * BN * sizeof(AT) + c * 16);
+                    *reinterpret_cast<uint4 *>(dst) = v;
+                }
             }
         }
     }
@@ -440,6 +455,18 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
             const int yy = (y0 >> 1) + qy, xx = (x0 >> 1) + qx;
             if (yy < Hp && xx < Wp) {
                 const int r00 = (2 * qy) * kTW + 2 * qx;
+                if constexpr (SPLIT3) {
+                    const float *p0 = reinterpret_cast<const float *>(otile) + (size_t)r00 * BN + (c >> 3) * 32 + (c & 3) * 8;
+                    float m8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        m8[k] = fmaxf(fmaxf(p0[k], p0[BN + k]), fmaxf(p0[kTW * BN + k], p0[(kTW + 1) * BN + k]));
+                    uint4 hi_, lo_;
+                    split_f16(m8, hi_, lo_);
+                    unsigned char *dst = static_cast<unsigned char *>(A.pool_y) +
+                                         (((long long)(b * Hp + yy) * Wp + xx) * A.pool_ld + n0) * 4 + c * 16;
+                    *reinterpret_cast<uint4 *>(dst) = (c & 4) ? lo_ : hi_;
+                } else {
                 const AT *p0 = otile + (size_t)r00 * BN + c * VPC;
                 AT o[VPC];
 #pragma unroll
@@ -452,6 +479,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
                 AT *dst = static_cast<AT *>(A.pool_y) +
                           ((long long)(b * Hp + yy) * Wp + xx) * A.pool_ld + n0 + c * VPC;
                 *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
+                }
             }
         }
     }

@@ -1,0 +1,770 @@
+// unet_s3.hip -- the parity-mode ("fp16x3") 3x3 convolution of the 2D U-Net for gfx950 (MI355X).
+//
+// Same layer as conv_igemm_kernel (unet_kernels.hip): Conv2D(3x3, SAME) + bias + ReLU (+ the BatchNormalization affine
+// that follows the 2nd ReLU of a block) of /root/reference/dosma/models/oaiunet2d.py:213-226, 266-279, in the
+// precision mode whose logits meet north_star's 1e-3 bar: every operand is a 16-bit hi + lo pair and a product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate).  scripts/unet_precision_sim.py shows why it has
+// to be three MFMAs (any two-MFMA split is 7e-3 .. 3e-2 off on the logits) and why the parts are fp16, not bf16
+// (2^-22 vs 2^-17 per product: 1.4e-5 instead of 6.7e-4 on a network with realistic BatchNorm statistics).
+//
+// What is different from the general kernel (which reached 33-37 % MFMA issue in this mode, round 1):
+//   * ACTIVATIONS LIVE IN HBM ALREADY SPLIT: per pixel and 32-channel chunk 32 fp16 hi parts then 32 fp16 lo parts
+//     (128 B, the bytes of the fp32 values they replace).  The producing epilogue splits once; consumers never convert,
+//     so the halo goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass,
+//     no VALU work in the main loop at all.
+//   * PERSISTENT blocks of 8 waves walk (channel block, pixel tile) work items.  The K loop is a stream of
+//     steps (32-channel chunk x tap) that does not stop at a tile boundary: weights run through a 4-slot LDS ring
+//     requested three steps ahead, the halo of the next chunk -- possibly the next tile's first -- is requested one
+//     piece per step into the other halo buffer, all by DMA with COUNTED s_waitcnt vmcnt (never 0 in the loop) and ONE
+//     raw s_barrier per step; the MFMA operands of step s+1 are read from LDS before the barrier that ends step s.
+//   * a tile is 8 image rows x 32 pixels (one MFMA row-tile = 32 consecutive pixels of one image row: with the
+//     XOR-swizzled 64-byte pixel rows every ds_read_b128 lane group is conflict-free at any tap shift), or, for images
+//     narrower than 64 pixels, 256 consecutive positions of the FLATTENED zero-framed image stack (pitch W + 2, one
+//     zero row between images): a 3x3 tap is then a constant shift of the flat index, row-tiles are still 32
+//     consecutive LDS pixels, and only the 2 frame columns per row are wasted (12 x 12 images: 14 % instead of the
+//     44 % a 16 x 16 tile wastes).
+//   * the epilogue goes through a wave-private 4 KB LDS window (the finished chunk's halo buffer): bias / ReLU /
+//     affine, split, [pixel][hi | lo] image, 16-byte global stores of whole 128-byte pixel-chunks; fused 2x2 max-pool
+//     (lane-local in the MFMA C layout) and fused 1x1 head + threshold as in the general kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "qmri_internal.h"
+
+namespace qmri {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;  // what v_cvt_pkrtz_f16_f32 returns
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ uint4 g_zero16_s3;  // source of halo pieces outside the image (zero padding)
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kMTile = 256;        // output positions per tile: 8 MFMA row-tiles of 32
+constexpr int kPitch2D = 34;       // halo row pitch of the 8 x 32 tile
+constexpr int kHalo2D = 10 * kPitch2D;
+constexpr int kRing = 4;           // weight ring slots
+
+// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16 (M0), global source per lane.
+// Issued through inline asm so that hipcc neither counts it (it would drain vmcnt(0) before every ds_read it cannot
+// prove disjoint) nor waits for it: every wait in this file is a hand-counted s_waitcnt vmcnt(N).
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_base)
+                 : "memory");
+}
+
+template <int BN>
+struct S3Cfg {
+    static constexpr int WN = BN >= 64 ? 2 : 1;          // waves along the channel axis
+    static constexpr int WM = kWaves / WN;               // waves along the pixel axis
+    static constexpr int RT = 8 / WM;                    // 32-pixel row-tiles per wave
+    static constexpr int CT = BN / WN / 32;              // 32-channel column tiles per wave
+    static constexpr int SLOT_BYTES = BN * 128;          // one ring slot: [plane][BN][64 B]
+    static constexpr int W_INSTR = SLOT_BYTES / 1024;    // DMA wave-instructions per slot: 16 / 8 / 4
+    static constexpr int W_PER_WAVE = W_INSTR >= kWaves ? W_INSTR / kWaves : 1;
+    static constexpr int DPS = W_PER_WAVE + 1;           // DMA instructions per wave per step (weights + one halo piece)
+};
+
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)(lds_void *)p; }
+
+// decode a flat position of the zero-framed image stack: f = R * P + c, R = b * (H + 1) + y + 1, c = x + 1
+__device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
+    if (f < P) return -1;
+    const int R = f / P, c = f - R * P;
+    if (c < 1 || c > W) return -1;
+    const int r1 = R - 1;
+    const int b = r1 / (H + 1), y = r1 - b * (H + 1);
+    if (y >= H || b >= B) return -1;
+    return (b * H + y) * W + (c - 1);
+}
+
+}  // namespace
+
+template <int BN, bool FLAT>
+__global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A) {
+    using C = S3Cfg<BN>;
+    constexpr int RT = C::RT, CT = C::CT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NJ = A.nj;                       // DMA instructions (16 pixels each) per halo plane
+    const int plane_bytes = NJ * 1024;
+    const int hbuf_bytes = 2 * plane_bytes;
+    unsigned char *halo = smem;                                  // [2 buffers][2 planes][NJ * 16 pixels][64 B]
+    unsigned char *ring = smem + 2 * hbuf_bytes;                 // [kRing][2 planes][BN][64 B]
+    int *outpix = reinterpret_cast<int *>(ring + kRing * C::SLOT_BYTES);  // [256] output pixel of a tile position, or -1
+    float *prm = reinterpret_cast<float *>(outpix + kMTile);     // bias | scale | shift, [BN] each
+    float *hw = prm + 3 * BN;                                    // head weights [32][4] + bias [4] (BN = 32 only)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % C::WN, wm = wave / C::WN;
+    const int P = FLAT ? A.P : kPitch2D;       // LDS / flat pitch of one image row
+    const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
+
+    const int steps = A.steps;                 // chunks * 9 per work item
+    const int nwork = A.nwork;                 // channel blocks x tiles
+    const int ntiles = A.ntiles;
+
+    // ---- per-lane constants of the halo DMA: this wave's slot i is instruction j = wave + 8 i of the 2 NJ that
+    // make up a halo buffer: plane j / NJ, pixels (j % NJ) * 16 + lane / 4, LDS position lane & 3 holds source piece
+    // q = pos ^ ((hp >> 2) & 3) (the swizzle lives on the SOURCE address and on the ds_read address)
+    constexpr int kSlots = 6;
+    int h_hp[kSlots], h_srcb[kSlots];  // halo pixel (or -1: beyond the halo), byte offset inside the pixel-chunk
+    unsigned h_dst[kSlots];            // LDS byte offset of the instruction inside a halo buffer
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+        int j = wave + kWaves * i;
+        if (j >= 2 * NJ) j = wave;  // no such piece: repeat this wave's first one (same bytes to the same place)
+        const int plane = j >= NJ ? 1 : 0;
+        const int jj = j - plane * NJ;
+        const int hp = jj * 16 + (lane >> 2);
+        const int q = (lane & 3) ^ ((hp >> 2) & 3);
+        h_hp[i] = hp < hpix ? hp : -1;
+        h_srcb[i] = plane * 64 + q * 16;
+        h_dst[i] = (unsigned)(plane * plane_bytes + jj * 1024);
+    }
+
+    // ---- work item -> tile geometry ----
+    // 2D:   tile = (image b, rows y0 .. y0+7, columns x0 .. x0+31)
+    // FLAT: tile = flat positions f0 .. f0+255
+    int t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0, t_nb = 0;
+    auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
+        nb = w / ntiles;
+        const int t = w - nb * ntiles;
+        if (FLAT) {
+            f0 = A.P + t * kMTile;
+            b = y0 = x0 = 0;
+        } else {
+            const int per_img = A.tiles_y * A.tiles_x;
+            b = t / per_img;
+            const int r = t - b * per_img;
+            const int ty = r / A.tiles_x;
+            y0 = ty * 8;
+            x0 = (r - ty * A.tiles_x) * 32;
+            f0 = 0;
+        }
+    };
+    // source pixel (index into the NHWC pixel grid) of this lane's piece of slot i for a tile, or -1
+    auto halo_src_pix = [&](int i, int b, int y0, int x0, int f0) -> int {
+        const int hp = h_hp[i];
+        if (hp < 0) return -1;
+        if (FLAT) return flat_to_pix(f0 - P - 1 + hp, P, A.H, A.W, A.B);
+        const int hy = hp / kPitch2D, hx = hp - hy * kPitch2D;
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+        if ((unsigned)yy >= (unsigned)A.H || (unsigned)xx >= (unsigned)A.W) return -1;
+        return (b * A.H + yy) * A.W + xx;
+    };
+    const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
+    const unsigned halo_lds = lds_off(halo), ring_lds = lds_off(ring);
+
+    int src_pix[kSlots];   // of the tile whose chunks are being REQUESTED (the current tile, or the next one)
+    int req_work, req_chunk;  // the next halo chunk to request: work item and chunk index
+    int req_buf;
+
+    auto issue_halo_piece = [&](int i) {
+        const long long off = ((long long)src_pix[i] * A.ldx + A.xoff + req_chunk * 32) * 4 + h_srcb[i];
+        const void *g = src_pix[i] >= 0 ? static_cast<const void *>(xbase + off) : static_cast<const void *>(&g_zero16_s3);
+        dma16(g, halo_lds + (unsigned)(req_buf * hbuf_bytes) + h_dst[i]);
+    };
+    // weights of (channel block nb, local step s) -> ring slot
+    const unsigned char *wbase = static_cast<const unsigned char *>(A.w);
+    auto issue_weights = [&](int nb, int s, int slot) {
+#pragma unroll
+        for (int r = 0; r < C::W_PER_WAVE; ++r) {
+            const int jj = (wave * C::W_PER_WAVE + r) % C::W_INSTR;  // BN = 32: waves 4-7 repeat the pieces of waves 0-3
+            const unsigned char *g = wbase + ((long long)nb * steps + s) * C::SLOT_BYTES + jj * 1024 + lane * 16;
+            dma16(g, ring_lds + (unsigned)(slot * C::SLOT_BYTES + jj * 1024));
+        }
+    };
+
+    // ---- per-lane LDS read addressing ----
+    // A fragment (row-tile i, tap shift sh, k-step kk, plane p): pixel hp = abase[i] + sh, piece (kk*2 + lane>>5) ^ ((hp>>2)&3)
+    int abase[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int rt = wm * RT + i;
+        abase[i] = FLAT ? rt * 32 + (lane & 31) + P + 1 : (rt + 1) * kPitch2D + (lane & 31) + 1;
+    }
+    // B fragment (column tile j, k-step kk, plane p): row n = (wn*CT + j)*32 + lane&31 of the slot image
+    unsigned boff[CT][2];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int n = (wn * CT + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) boff[j][kk] = (unsigned)(n * 64 + (((kk * 2 + (lane >> 5)) ^ ((n >> 2) & 3)) * 16));
+    }
+    const int khalf = lane >> 5;
+
+    struct Frags {
+        f16x8 ah[RT], al[RT], bh[CT], bl[CT];
+    };
+    auto load_frags = [&](Frags &f, int buf, int slot, int shift, int kk) {
+        const unsigned char *hb = halo + buf * hbuf_bytes;
+        const unsigned char *wb = ring + slot * C::SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int hp = abase[i] + shift;
+            const int off = hp * 64 + (((kk * 2 + khalf) ^ ((hp >> 2) & 3)) * 16);
+            f.ah[i] = *reinterpret_cast<const f16x8 *>(hb + off);
+            f.al[i] = *reinterpret_cast<const f16x8 *>(hb + plane_bytes + off);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            f.bh[j] = *reinterpret_cast<const f16x8 *>(wb + boff[j][kk]);
+            f.bl[j] = *reinterpret_cast<const f16x8 *>(wb + BN * 64 + boff[j][kk]);
+        }
+    };
+
+    f32x16 acc[RT][CT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    auto mma = [&](const Frags &f) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    int work = blockIdx.x;
+    if (work >= nwork) return;
+    decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
+
+    // ---- prologue: halo chunk 0 of the first tile (all 6 pieces), weights of steps 0, 1, 2 ----
+    req_work = work;
+    req_chunk = 0;
+    req_buf = 0;
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) src_pix[i] = halo_src_pix(i, t_b, t_y0, t_x0, t_f0);
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) issue_halo_piece(i);
+    // weight requests run 3 steps ahead of the computation: (w_work, w_nb, w_s) is the NEXT step to request
+    int w_work = work, w_nb = t_nb, w_s = 0, w_slot = 0;
+    auto advance_w = [&]() {
+        if (++w_s == steps) {
+            w_s = 0;
+            w_work += gridDim.x;
+            w_nb = w_work < nwork ? w_work / ntiles : w_nb;
+        }
+        w_slot = (w_slot + 1) & (kRing - 1);
+    };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        issue_weights(w_nb, w_s, w_slot);
+        advance_w();
+    }
+    // the request pointer of the halo moves to chunk 1 (or the next tile's chunk 0)
+    auto advance_req = [&]() {
+        req_buf ^= 1;
+        if (++req_chunk == A.chunks) {
+            req_chunk = 0;
+            req_work += gridDim.x;
+        }
+    };
+    advance_req();
+    bool req_tile_ready = req_chunk != 0;  // src_pix belongs to the tile of req_work?
+    for (int i = tid; i < 3 * BN; i += kThreads) {  // epilogue parameters of this block's FIRST channel block
+        const int c = i % BN, which = i / BN;
+        const int n = t_nb * BN + c;
+        prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
+    }
+    if (BN == 32 && A.head_w)
+        for (int i = tid; i < 32 * 4 + 4; i += kThreads) {
+            const int NC = A.head_nc;
+            float v = 0.f;
+            if (i < 128) {
+                const int co = i >> 2, c = i & 3;
+                v = c < NC ? A.head_w[co * NC + c] : 0.f;
+            } else {
+                v = (i - 128) < NC ? A.head_b[i - 128] : 0.f;
+            }
+            hw[i] = v;
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    zero_acc();
+    int s = 0, chunk = 0, tap = 0, cbuf = 0, slot = 0;
+    Frags f0, f1;
+    load_frags(f0, cbuf, slot, -P - 1, 0);
+
+    while (true) {
+        // ---------------- requests of this step: weights of step s + 3, one halo piece of the next chunk ----------
+        // (past the last work item there is nothing left to request: the first slot image is requested again so that the
+        //  per-step DMA count stays constant -- the waits below are counted)
+        const int lw_nb = w_work < nwork ? w_nb : t_nb, lw_s = w_work < nwork ? w_s : 0, lw_slot = w_slot;
+        issue_weights(lw_nb, lw_s, lw_slot);
+        advance_w();
+        if (tap < kSlots) {
+            if (tap == 0 && !req_tile_ready) {
+                // first request for a new tile: where do its halo pixels come from
+                int nb_, b_, y0_, x0_, f0_;
+                const int rw = req_work < nwork ? req_work : work;  // past the end: re-request this tile (harmless)
+                decode_work(rw, nb_, b_, y0_, x0_, f0_);
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i) src_pix[i] = halo_src_pix(i, b_, y0_, x0_, f0_);
+                req_tile_ready = true;
+            }
+            // (tap is block-uniform but not a compile-time constant: select the slot's registers)
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i)
+                if (i == tap) issue_halo_piece(i);
+        } else {
+            // taps 6-8: no halo piece left -> one more (identical) request of this step's first weight piece, so that
+            // every step issues the same number of DMA instructions per wave (the waits are counted)
+            const int jj = (wave * C::W_PER_WAVE) % C::W_INSTR;
+            const int pslot = lw_slot;
+            const unsigned char *g = wbase + ((long long)lw_nb * steps + lw_s) * C::SLOT_BYTES + jj * 1024 + lane * 16;
+            dma16(g, ring_lds + (unsigned)(pslot * C::SLOT_BYTES + jj * 1024));
+        }
+
+        // ---------------- compute ----------------
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int shift = dy * P + dx;
+        load_frags(f1, cbuf, slot, shift, 1);
+        mma(f0);
+        // next step's coordinates
+        int n_tap = tap + 1, n_chunk = chunk, n_cbuf = cbuf, n_s = s + 1;
+        if (n_tap == 9) {
+            n_tap = 0;
+            n_chunk = chunk + 1;
+            n_cbuf = cbuf ^ 1;
+        }
+        const bool last = n_s == steps;
+        const int n_slot = (slot + 1) & (kRing - 1);
+        {
+            const int ndy = n_tap / 3 - 1, ndx = n_tap - (n_tap / 3) * 3 - 1;
+            load_frags(f0, n_cbuf, n_slot, ndy * P + ndx, 0);  // operands of step s + 1 (k-step 0), read before the barrier
+        }
+        mma(f1);
+        // everything requested before this step has landed (this wave's part); then everyone's
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");
+        if (n_tap == 0) {  // the chunk is finished: the request pointer moves on to the chunk after the next
+            advance_req();
+            if (req_chunk == 0) req_tile_ready = false;
+        }
+        tap = n_tap;
+        chunk = n_chunk;
+        cbuf = n_cbuf;
+        slot = n_slot;
+        s = n_s;
+        if (!last) continue;
+
+        // ======================= epilogue of this work item =======================
+        // staging: the halo buffer of the chunk that just finished (cbuf ^ 1 after the advance above), 4 KB + per wave
+        {
+            unsigned char *stage = halo + (cbuf ^ 1) * hbuf_bytes + wave * 4096;
+            // output pixel of every tile position (2D: computed inline; FLAT: table filled by the first 256 threads)
+            if (FLAT) {
+                if (tid < kMTile) outpix[tid] = flat_to_pix(t_f0 + tid, P, A.H, A.W, A.B);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            const float winv = A.winv;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = (wn * CT + j) * 32 + (lane & 31);
+                const float bias = prm[col], scale = prm[BN + col], shift_ = prm[2 * BN + col];
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = fmaf(acc[i][j][e], winv, bias);
+                        if (A.relu) v = fmaxf(v, 0.f);
+                        acc[i][j][e] = fmaf(v, scale, shift_);
+                    }
+            }
+            const int n0 = t_nb * BN;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int cbase = n0 + (wn * CT + j) * 32;  // first output channel of this column tile
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int rt = wm * RT + i;
+                    // ---- [32 pixels][32 hi | 32 lo] image of the tile in the wave's window ----
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        // rows (pixels) e and e + 1 of this lane: (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+                        const float v0 = acc[i][j][e], v1 = acc[i][j][e + 1];
+                        const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+                        const h16x2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
+                        const int r0 = (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                        __fp16 *p0 = reinterpret_cast<__fp16 *>(stage + r0 * 128) + (lane & 31);
+                        p0[0] = h[0];
+                        p0[32] = l[0];
+                        p0[64] = h[1];       // next pixel row (+128 B)
+                        p0[64 + 32] = l[1];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (A.y) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int id = t * 64 + lane, px = id >> 3, pc = id & 7;
+                            int pix;
+                            if (FLAT) {
+                                pix = outpix[rt * 32 + px];
+                            } else {
+                                const int yy = t_y0 + rt;
+                                pix = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
+                            }
+                            if (pix >= 0) {
+                                const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
+                                unsigned char *dst = static_cast<unsigned char *>(A.y) +
+                                                     ((long long)pix * A.ldy + A.yoff + cbase) * 4 + pc * 16;
+                                *reinterpret_cast<uint4 *>(dst) = v;
+                            }
+                        }
+                    }
+                    if (BN == 32 && A.head_w) {
+                        // 1x1 head on the finished tile: lane = (pixel, half of the channels)
+                        const int px = lane & 31, half = khalf;
+                        const f16x8 *row = reinterpret_cast<const f16x8 *>(stage + px * 128 + half * 32);
+                        const f16x8 h0 = row[0], h1 = row[1];
+                        const f16x8 l0 = row[4], l1 = row[5];  // + 64 B: the lo parts
+                        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float v = q < 8 ? (float)h0[q] + (float)l0[q] : (float)h1[q - 8] + (float)l1[q - 8];
+                            const float4 w4 = *reinterpret_cast<const float4 *>(hw + (half * 16 + q) * 4);
+                            z[0] = fmaf(v, w4.x, z[0]);
+                            z[1] = fmaf(v, w4.y, z[1]);
+                            z[2] = fmaf(v, w4.z, z[2]);
+                            z[3] = fmaf(v, w4.w, z[3]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
+                        const int yy = t_y0 + rt;
+                        if (half == 0 && yy < A.H) {
+                            const long long pix = (long long)(t_b * A.H + yy) * A.W + t_x0 + px;
+                            const int NC = A.head_nc;
+                            for (int c = 0; c < NC; ++c) {
+                                const float zz = z[c] + hw[128 + c];
+                                if (A.logits) A.logits[pix * NC + c] = zz;
+                                if (A.mask) A.mask[pix * NC + c] = zz > 0.f ? 1 : 0;
+                            }
+                        }
+                    }
+                }
+                // ---- fused MaxPooling2D(2x2): rows rt, rt+1 of this wave (RT = 2) -> 16 pooled pixels x 32 channels ----
+                if (!FLAT && RT == 2 && A.pool_y) {
+#pragma unroll
+                    for (int e2 = 0; e2 < 8; ++e2) {
+                        const int e = 2 * e2;
+                        const float m = fmaxf(fmaxf(acc[0][j][e], acc[0][j][e + 1]), fmaxf(acc[RT - 1][j][e], acc[RT - 1][j][e + 1]));
+                        const int r0 = ((e & 3) + 8 * (e >> 2) + 4 * khalf) >> 1;  // pooled column 0..15
+                        const __fp16 h = __builtin_amdgcn_cvt_pkrtz(m, 0.f)[0];
+                        const __fp16 l = __builtin_amdgcn_cvt_pkrtz(m - (float)h, 0.f)[0];
+                        __fp16 *p0 = reinterpret_cast<__fp16 *>(stage + r0 * 128) + (lane & 31);
+                        p0[0] = h;
+                        p0[32] = l;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int Hp = A.H >> 1, Wp = A.W >> 1;
+                    const int yy = (t_y0 >> 1) + wm;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int id = t * 64 + lane, px = id >> 3, pc = id & 7;
+                        if (yy < Hp) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
+                            const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + px;
+                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + pc * 16;
+                            *reinterpret_cast<uint4 *>(dst) = v;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- next work item ----
+        work += gridDim.x;
+        if (work >= nwork) break;
+        const int prev_nb = t_nb;
+        decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
+        zero_acc();
+        s = 0;
+        chunk = 0;
+        // every wave is done with its staging window (the next chunk's DMA lands there) and with the parameters
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t_nb != prev_nb) {         // (only with more than one channel block per launch)
+            for (int i = tid; i < 3 * BN; i += kThreads) {
+                const int c = i % BN, which = i / BN;
+                const int n = t_nb * BN + c;
+                prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
+}
+
+static size_t s3_lds_bytes(int bn, int nj) {
+    return (size_t)4 * nj * 1024 + (size_t)kRing * bn * 128 + kMTile * 4 + (size_t)3 * bn * 4 + (32 * 4 + 4) * 4;
+}
+
+bool conv_s3_supported(const ConvS3Args &k) {
+    if (k.Cin % 32 || k.Cout % 32) return false;
+    if (k.W % 32 == 0) return true;      // 8 x 32 tiles
+    return k.W + 2 <= 50;                // flattened zero-framed stack (LDS: 256 + 2 (W + 2) + 2 halo pixels)
+}
+
+template <int BN, bool FLAT>
+static hipError_t s3_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
+    auto fn = conv_s3_kernel<BN, FLAT>;
+    const size_t lds = s3_lds_bytes(BN, k.nj);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int grid = k.nwork < num_cu ? k.nwork : num_cu;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), lds, stream, k);
+    return hipGetLastError();
+}
+
+int conv_s3_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32); }
+
+hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
+    ConvS3Args k = k0;
+    if (!conv_s3_supported(k)) return hipErrorInvalidValue;
+    const int bn = conv_s3_block_channels(k.Cout);
+    const bool flat = k.W % 32 != 0;
+    if (k.head_w && (bn != 32 || k.Cout != 32 || flat || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
+    if (k.pool_y && (flat || (k.H & 1) || (k.W & 1) || bn == 32)) return hipErrorInvalidValue;
+    k.chunks = k.Cin / 32;
+    k.steps = k.chunks * 9;
+    k.nb = k.Cout / bn;
+    if (flat) {
+        k.P = k.W + 2;
+        const long long span = (long long)k.B * (k.H + 1) * k.P - k.P;  // flat positions [P, B (H+1) P)
+        k.ntiles = (int)((span + kMTile - 1) / kMTile);
+        k.tiles_x = k.tiles_y = 0;
+        k.nj = (kMTile + 2 * k.P + 2 + 15) / 16;
+    } else {
+        k.P = kPitch2D;
+        k.tiles_x = k.W / 32;
+        k.tiles_y = (k.H + 7) / 8;
+        k.ntiles = k.B * k.tiles_x * k.tiles_y;
+        k.nj = (kHalo2D + 15) / 16;
+    }
+    k.nwork = k.nb * k.ntiles;
+    (void)hipGetLastError();
+    if (flat) {
+        if (bn == 128) return s3_launch_t<128, true>(k, num_cu, stream);
+        if (bn == 64) return s3_launch_t<64, true>(k, num_cu, stream);
+        return s3_launch_t<32, true>(k, num_cu, stream);
+    }
+    if (bn == 128) return s3_launch_t<128, false>(k, num_cu, stream);
+    if (bn == 64) return s3_launch_t<64, false>(k, num_cu, stream);
+    return s3_launch_t<32, false>(k, num_cu, stream);
+}
+
+// =====================================================================================================================
+// Small streaming kernels on the split layout (all HBM-bound): first layer, 2x2 max-pool, 1x1 head, layout casts.
+// One thread = one (pixel, 8-channel group): 16 bytes of hi parts + 16 bytes of lo parts.
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h16x2 hh = __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]);
+        const h16x2 ll = __builtin_amdgcn_cvt_pkrtz(v[2 * q] - (float)hh[0], v[2 * q + 1] - (float)hh[1]);
+        h[q] = __builtin_bit_cast(unsigned, hh);
+        l[q] = __builtin_bit_cast(unsigned, ll);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void join8(const uint4 &hi, const uint4 &lo, float (&v)[8]) {
+    const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h16x2 hh = __builtin_bit_cast(h16x2, h[q]), ll = __builtin_bit_cast(h16x2, l[q]);
+        v[2 * q] = (float)hh[0] + (float)ll[0];
+        v[2 * q + 1] = (float)hh[1] + (float)ll[1];
+    }
+}
+// byte address of the 8-channel group g (channels 8 g .. 8 g + 7) of a pixel's split run starting at `base`
+__device__ __forceinline__ long long split_group_off(int g) { return (long long)(g >> 2) * 128 + (g & 3) * 16; }
+
+// Conv2D(C, 3x3, SAME) on ONE input channel + bias + ReLU (oaiunet2d.py:213-219 on the image), fp32 VALU, split output
+__global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__ x, int B, int H, int W,
+                                                       const float *__restrict__ w /*[9][C]*/, const float *__restrict__ bias,
+                                                       int Cout, unsigned char *__restrict__ y, long long ldy, int yoff) {
+    const int groups = Cout / 8;
+    const long long total = (long long)B * H * W * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        const long long pix = idx / groups;
+        const int xw = (int)(pix % W);
+        const long long t = pix / W;
+        const int yh = (int)(t % H);
+        const float *img = x + (t / H) * (long long)H * W;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bias[g * 8 + c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int yy = yh + kh - 1, xx = xw + kw - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float v = img[(long long)yy * W + xx];
+                    const float *wt = w + (kh * 3 + kw) * Cout + g * 8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
+        uint4 hi, lo;
+        split8(acc, hi, lo);
+        unsigned char *dst = y + (pix * ldy + yoff) * 4 + split_group_off(g);
+        *reinterpret_cast<uint4 *>(dst) = hi;
+        *reinterpret_cast<uint4 *>(dst + 64) = lo;
+    }
+}
+
+// MaxPooling2D(2x2) (oaiunet2d.py:234-243), split in (pixel stride ldx, offset xoff) -> compact split out
+__global__ __launch_bounds__(256) void maxpool2_split_kernel(const unsigned char *__restrict__ x, long long ldx, int xoff, int B,
+                                                             int H, int W, int C, unsigned char *__restrict__ y) {
+    const int Ho = H / 2, Wo = W / 2, groups = C / 8;
+    const long long total = (long long)B * Ho * Wo * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        const long long p = idx / groups;
+        const int xo = (int)(p % Wo);
+        const long long t = p / Wo;
+        const int yo = (int)(t % Ho);
+        const long long b = t / Ho;
+        const long long p00 = (b * H + 2 * yo) * W + 2 * xo;
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long pp = p00 + (q >> 1) * W + (q & 1);
+            const unsigned char *src = x + (pp * ldx + xoff) * 4 + split_group_off(g);
+            float v[8];
+            join8(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 64), v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = q == 0 ? v[c] : fmaxf(m[c], v[c]);
+        }
+        uint4 hi, lo;
+        split8(m, hi, lo);
+        unsigned char *dst = y + p * C * 4 + split_group_off(g);
+        *reinterpret_cast<uint4 *>(dst) = hi;
+        *reinterpret_cast<uint4 *>(dst + 64) = lo;
+    }
+}
+
+// Conv2D(n_classes <= 4, 1x1) head on a split feature map: Cin / 8 lanes per pixel, wave-shuffle reduction
+__global__ __launch_bounds__(256) void head_split_kernel(const unsigned char *__restrict__ x, long long npix, int Cin,
+                                                         const float *__restrict__ w /*[Cin][NC]*/, const float *__restrict__ bias,
+                                                         int NC, float *__restrict__ logits, unsigned char *__restrict__ mask) {
+    const int lpp = Cin / 8;  // lanes per pixel: 4 (Cin = 32) .. 32 (Cin = 256), a power of two
+    const int sub = threadIdx.x % lpp;
+    const long long ppb = 256 / lpp;
+    for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / lpp; p < npix; p += (long long)gridDim.x * ppb) {
+        const unsigned char *src = x + p * Cin * 4 + split_group_off(sub);
+        float v[8];
+        join8(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 64), v);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(v[q], w[(sub * 8 + q) * NC + c], acc[c]);
+        for (int o = lpp / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+        if (sub < NC) {
+            const float z = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + bias[sub];
+            if (logits) logits[p * NC + sub] = z;
+            if (mask) mask[p * NC + sub] = z > 0.f ? 1 : 0;
+        }
+    }
+}
+
+// fp32 NHWC [pix][C] <-> split [pix][C] (operator-level host entry and tests)
+__global__ void f32_to_split_kernel(const float *__restrict__ x, long long npix, int C, unsigned char *__restrict__ y) {
+    const int groups = C / 8;
+    const long long total = npix * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        const long long p = idx / groups;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[p * C + g * 8 + q];
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        unsigned char *dst = y + p * C * 4 + split_group_off(g);
+        *reinterpret_cast<uint4 *>(dst) = hi;
+        *reinterpret_cast<uint4 *>(dst + 64) = lo;
+    }
+}
+__global__ void split_to_f32_kernel(const unsigned char *__restrict__ x, long long npix, int C, float *__restrict__ y) {
+    const int groups = C / 8;
+    const long long total = npix * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        const long long p = idx / groups;
+        const unsigned char *src = x + p * C * 4 + split_group_off(g);
+        float v[8];
+        join8(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 64), v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[p * C + g * 8 + q] = v[q];
+    }
+}
+
+unsigned grid_for(long long total) {
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
+                           long long ldy, int yoff, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(c1_split_kernel, dim3(grid_for((long long)B * H * W * (Cout / 8))), dim3(256), 0, stream, x, B, H, W, w, bias,
+                       Cout, static_cast<unsigned char *>(y), ldy, yoff);
+    return hipGetLastError();
+}
+hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool2_split_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(x), ldx, xoff, B, H, W, C, static_cast<unsigned char *>(y));
+    return hipGetLastError();
+}
+hipError_t head_split_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC, float *logits,
+                             unsigned char *mask, hipStream_t stream) {
+    if (NC > 4 || Cin % 32 || Cin > 256 || (Cin & (Cin - 1))) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(head_split_kernel, dim3(grid_for(npix * (Cin / 8))), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(x), npix, Cin, w, bias, NC, logits, mask);
+    return hipGetLastError();
+}
+hipError_t split_cast_launch(const void *x, long long npix, int C, void *y, int to_split, hipStream_t stream) {
+    (void)hipGetLastError();
+    const unsigned grid = grid_for(npix * (C / 8)) > 8192 ? 8192 : grid_for(npix * (C / 8));
+    if (to_split)
+        hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const float *>(x), npix, C,
+                           static_cast<unsigned char *>(y));
+    else
+        hipLaunchKernelGGL(split_to_f32_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned char *>(x), npix, C,
+                           static_cast<float *>(y));
+    return hipGetLastError();
+}
+
+}  // namespace qmri

@@ -55,8 +55,8 @@ class SegModel(ABC):
 class HipSegModel(SegModel):
     """Counterpart of the reference's ``KerasSegModel``: builds the native engine and loads weights."""
 
-    #: "bf16x3" (split-bf16, ~fp32 accuracy: logits within 1e-3 of an fp32 run) or "bf16" (single MFMA)
-    precision = "bf16x3"
+    #: "fp16x3" (fp16 hi + lo operand parts, 3 MFMAs per product: logits within 1e-3 of an fp64 run) or "bf16" (single MFMA)
+    precision = "fp16x3"
     #: slices per pass through the network on the GPU.  The reference's ``batch_size`` (Keras ``predict(batch_size=)``,
     #: ``preferences.segmentation_batch_size`` = 16) only chunks the work -- results do not depend on it -- and is kept
     #: as an attribute for compatibility; the engine uses the larger of the two (16 -> 64: +30 % throughput; the

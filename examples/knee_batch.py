@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--volumes", type=int, default=8)
     ap.add_argument("--shape", type=int, nargs=3, default=[384, 384, 160])
     ap.add_argument("--backend", default=None, help="nccl (default on GPUs) | gloo")
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="fp16x3")
     args = ap.parse_args()
     rank, local_rank, world = dist.init(args.backend)
     shape = tuple(args.shape)

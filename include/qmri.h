@@ -230,7 +230,9 @@ typedef struct qmri_unet2d_desc {
     int32_t n_classes;      /* 4 (fc, tc, pc, men) */
     int32_t H, W;           /* slice size; multiples of 2^(depth-1) */
     int32_t max_batch;      /* slices per pass through the network (the reference's batch_size) */
-    int32_t precision;      /* 0: bf16 MFMA (1 product);  1: split-bf16 x3 (~fp32 accuracy) */
+    int32_t precision;      /* 0: "bf16" -- bf16 operands, 1 MFMA per product (logits within ~0.25);
+                             * 1: "fp16x3" -- the parity mode: fp16 hi + lo operand parts, hi*hi + hi*lo + lo*hi on MFMA,
+                             *    fp32 accumulate, activations kept split in HBM (logits within 1e-3 of an fp64 run) */
     int32_t device;
     const float *const *tensors; /* HOST pointers, order above */
     int32_t n_tensors;
@@ -240,6 +242,9 @@ typedef struct qmri_unet2d_desc {
 
 int qmri_unet2d_create(const qmri_unet2d_desc *desc, void **handle);
 int qmri_unet2d_set_precision(void *handle, int32_t precision);
+/* Which kernel family ran every layer of the last forward batch ("down1.conv2:s3/2d/bn64+pool;..."): returns the length
+ * of the full string, writes at most size - 1 characters + NUL.  For tests that assert the dispatch. */
+int qmri_unet2d_trace(void *handle, char *buf, int32_t size);
 /*
  * x [S][H][W] fp32 (host or device), optional whole-volume whitening (x - mean)/(std + eps) first.
  * Outputs (nullable): logits [S][H][W][n_classes] fp32 (pre-sigmoid), mask u8 = sigmoid > 0.5.
@@ -263,6 +268,8 @@ int qmri_unet2d_destroy(void *handle);
  *   transposed 0: Conv2D(Cout, 3x3, padding=same), kernel (3,3,Cin,Cout)       oaiunet2d.py:213-226
  *   transposed 1: Conv2DTranspose(Cout, 3x3, strides=2, padding=same), kernel (3,3,Cout,Cin) :259-261
  *   y = scale * relu?(conv + bias) + shift   (scale/shift nullable: the folded BatchNormalization)
+ *   precision 0 / 1 as in qmri_unet2d_desc; 2 = the parity mode forced onto the general kernel (conv_igemm) for shapes
+ *   that would otherwise run on conv_s3_kernel (tests compare the two)
  */
 int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float *kernel,
                           const float *bias, const float *scale, const float *shift, int32_t relu,

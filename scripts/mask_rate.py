@@ -12,7 +12,7 @@ rng = np.random.default_rng(0)
 vol = (rng.standard_normal((H, W, S)) * 80 + 200).astype(np.float32)
 aff = np.array([[0, 0, 1.5, 0.0], [0, -0.4, 0, 0.0], [-0.4, 0, 0, 0.0], [0, 0, 0, 1.0]])  # sagittal already
 mv = dm.MedicalVolume(vol, aff)
-for precision in ("bf16x3", "bf16"):
+for precision in ("fp16x3", "bf16"):
     IWOAIOAIUnet2DNormalized.precision = precision
     model = IWOAIOAIUnet2DNormalized((H, W, 1), w, force_weights=True)
     for rep in range(3):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of an environment switch on the UNet kernels (run on the GPU box through gpurun):
 #   scripts/unet_ab.sh QMRI_CONV_W8 0 1           -> per-layer times of scripts/prof_unet.py (bf16) for each value
-#   PRECISION=bf16x3 scripts/unet_ab.sh ...       -> the same in the parity mode
+#   PRECISION=fp16x3 scripts/unet_ab.sh ...       -> the same in the parity mode
 VAR=$1; shift
 PRECISION=${PRECISION:-bf16}
 cd $GRAFT_REPO_ROOT

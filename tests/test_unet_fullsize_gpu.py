@@ -1,0 +1,115 @@
+"""Full-size parity of the 2D U-Net on the GPU: BASELINE.json configs[3] (384 x 384 slices) and the 512 x 512 slices of
+configs[4], against the fp64 run of the restatement (oracle/unet_oracle.py; PARITY WITH KERAS UNPINNED, see its header).
+
+What the reference pins at this size with data that is absent here: /root/reference/tests/models/test_oaiunet2d.py:19-41,
+109-152 (exact masks of a 384 x 384 x 160 volume).  Here: seeded weights in Keras layouts -- with BatchNormalization
+moving statistics spread like a trained network's (variance 5e-3 .. 1.5e2, means of either sign), not only He / identity
+-- and the north_star tolerance on the logits (1e-3 abs) in the parity mode, for both activation-buffer sizes the bench
+uses (max_batch 16 and 160), plus an assertion on WHICH kernels ran every layer (so that the 384-only dispatch -- 8 x 32
+tiles at 384 / 192 / 96, the flattened tiling at 48 / 24 / 12, fused pool and head -- is what is tested)."""
+import numpy as np
+import pytest
+
+from dosma_amd import _lib as L
+from oracle import unet_oracle as uo
+from test_unet_gpu import weights_in_abi_order
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    w = uo.make_weights(seed=11, bn="realistic")
+    return w, weights_in_abi_order(w)
+
+
+def _volume(S, H, W, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    blob = np.exp(-(((yy - H / 2) / (H / 4)) ** 2 + ((xx - W / 2) / (W / 3)) ** 2))  # structure, not only noise
+    return (rng.standard_normal((S, H, W)) * 60 + 250 * blob[None] + 80).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def ref384(net):
+    w, _ = net
+    vol = _volume(4, 384, 384, 384)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+    return vol, uo.forward(w, xw, dtype="float64")
+
+
+def _expect_families(trace, H, W):
+    """conv_s3_kernel wherever it tiles the level, the general kernel for the transposed convolutions."""
+    by = dict(t.split(":", 1) for t in trace if ":" in t and not t.startswith(("pool", "head")))
+    for lvl in range(6):
+        wl = W >> lvl
+        fam = "s3/2d" if wl % 32 == 0 else ("s3/flat" if wl + 2 <= 50 else "igemm")
+        for name in ([f"down{lvl}.conv2"] + ([f"down{lvl}.conv1"] if lvl else []) + ([f"up{lvl}.conv1", f"up{lvl}.conv2"] if lvl < 5 else [])):
+            assert by[name].startswith(fam), (name, by[name], fam)
+        if lvl < 5:
+            assert by[f"up{lvl}.deconv"].startswith("igemm")
+    assert by["down0.conv1"] == "c1/split"
+    assert by["up0.conv2"].endswith("+head")  # the last feature map never goes to HBM
+    assert by["down1.conv2"].endswith("+pool") and by["down2.conv2"].endswith("+pool")
+
+
+@pytest.mark.parametrize("max_batch", [16, 160])
+def test_384_logits_parity_mode(net, ref384, max_batch):
+    w, tensors = net
+    vol, ref = ref384
+    eng = L.Unet2dEngine(tensors, 384, 384, max_batch=max_batch, precision="fp16x3")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    err = np.abs(logits - ref)
+    assert err.max() < 1e-3, f"max |dlogit| {err.max():.3e} (logits span {np.abs(ref).max():.1f})"
+    assert np.array_equal(mask, (logits > 0).astype(np.uint8))
+    assert (mask == (ref > 0)).mean() > 0.99999
+    tr = eng.trace()
+    _expect_families(tr, 384, 384)
+    fams = {t.split(":", 1)[1].split("+")[0] for t in tr if t.startswith(("down", "up")) and "conv" in t and "deconv" not in t}
+    assert {"s3/2d/bn32", "s3/2d/bn64", "s3/2d/bn128", "s3/flat/bn128"} <= fams, fams
+    eng.close()
+
+
+def test_384_logits_plain_bf16_mode(net, ref384):
+    """The throughput mode at the benchmark size: bf16-level logits, masks equal except next to the decision boundary."""
+    w, tensors = net
+    vol, ref = ref384
+    eng = L.Unet2dEngine(tensors, 384, 384, max_batch=16, precision="bf16")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    span = np.abs(ref).max()
+    err = np.abs(logits - ref)
+    assert err.max() < 0.03 * span + 0.25, (err.max(), span)  # bf16 operands: ~2^-9 per product through 26 layers
+    flips = mask != (ref > 0)
+    assert flips.mean() < 5e-3
+    assert np.abs(ref[flips]).max() < 0.03 * span + 0.25 if flips.any() else True
+    eng.close()
+
+
+def test_512_logits_parity_mode(net):
+    """BASELINE configs[4] segments 512 x 512 slices: every level is a multiple of 32 wide down to 32, then 16 (flattened)."""
+    w, tensors = net
+    vol = _volume(2, 512, 512, 512)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+    ref = uo.forward(w, xw, dtype="float64")
+    eng = L.Unet2dEngine(tensors, 512, 512, max_batch=32, precision="fp16x3")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
+    assert (mask == (ref > 0)).mean() > 0.99999
+    _expect_families(eng.trace(), 512, 512)
+    eng.close()
+
+
+def test_odd_level_widths_take_the_general_kernel(net):
+    """224 x 224: 224 = 7 x 32 (8 x 32 tiles), 112 and 56 are neither multiples of 32 nor <= 48 (general kernel on the split
+    layout), 28 / 14 / 7 flattened -- all three families in one network, same 1e-3 bar."""
+    w, tensors = net
+    vol = _volume(2, 224, 224, 224)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+    ref = uo.forward(w, xw, dtype="float64")
+    eng = L.Unet2dEngine(tensors, 224, 224, max_batch=2, precision="fp16x3")
+    logits, _ = eng.forward_host(vol, whiten=True, eps=0.0)
+    assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
+    tr = eng.trace()
+    _expect_families(tr, 224, 224)
+    assert any(t.startswith("down1.conv2:igemm") for t in tr) and any(t.startswith("down3.conv1:s3/flat") for t in tr)
+    eng.close()

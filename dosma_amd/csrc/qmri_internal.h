@@ -161,6 +161,7 @@ struct ConvS3Args {
     unsigned char *mask;
     // filled by conv_s3_launch
     int chunks, steps, nb, ntiles, nwork, tiles_x, tiles_y, P, nj;
+    int dbg;             // QMRI_S3_DBG timing experiments (0 in production)
 };
 bool conv_s3_supported(const ConvS3Args &k);
 int conv_s3_block_channels(int Cout);  // channel-block size the kernel uses for a layer: the weight packing depends on it

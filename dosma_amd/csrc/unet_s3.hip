@@ -89,6 +89,12 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 
 }  // namespace
 
+#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads)
+#define S3_DBG(bit) (A.dbg & (bit))
+#else
+#define S3_DBG(bit) 0
+#endif
+
 template <int BN, bool FLAT>
 __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A) {
     using C = S3Cfg<BN>;
@@ -166,14 +172,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
     const unsigned halo_lds = lds_off(halo), ring_lds = lds_off(ring);
 
-    int src_pix[kSlots];   // of the tile whose chunks are being REQUESTED (the current tile, or the next one)
+    const unsigned char *zero_line = reinterpret_cast<const unsigned char *>(&g_zero16_s3);
+    // per piece: source of chunk 0 for the tile whose chunks are being REQUESTED (the current tile, or the next one) and
+    // the byte step from chunk to chunk (0 for pieces that read the zero line)
+    const unsigned char *hsrc[kSlots];
+    int hstep[kSlots];
+    auto set_halo_sources = [&](int b, int y0, int x0, int f0) {
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            const int pix = halo_src_pix(i, b, y0, x0, f0);
+            hsrc[i] = pix >= 0 ? xbase + ((long long)pix * A.ldx + A.xoff) * 4 + h_srcb[i] : zero_line;
+            hstep[i] = pix >= 0 ? 128 : 0;
+        }
+    };
     int req_work, req_chunk;  // the next halo chunk to request: work item and chunk index
     int req_buf;
 
     auto issue_halo_piece = [&](int i) {
-        const long long off = ((long long)src_pix[i] * A.ldx + A.xoff + req_chunk * 32) * 4 + h_srcb[i];
-        const void *g = src_pix[i] >= 0 ? static_cast<const void *>(xbase + off) : static_cast<const void *>(&g_zero16_s3);
-        dma16(g, halo_lds + (unsigned)(req_buf * hbuf_bytes) + h_dst[i]);
+        dma16(hsrc[i] + req_chunk * hstep[i], halo_lds + (unsigned)(req_buf * hbuf_bytes) + h_dst[i]);
     };
     // weights of (channel block nb, local step s) -> ring slot
     const unsigned char *wbase = static_cast<const unsigned char *>(A.w);
@@ -233,17 +249,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     };
-    auto mma = [&](const Frags &f) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-            }
-    };
-
     int work = blockIdx.x;
     if (work >= nwork) return;
     decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
@@ -252,8 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     req_work = work;
     req_chunk = 0;
     req_buf = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) src_pix[i] = halo_src_pix(i, t_b, t_y0, t_x0, t_f0);
+    set_halo_sources(t_b, t_y0, t_x0, t_f0);
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) issue_halo_piece(i);
     // weight requests run 3 steps ahead of the computation: (w_work, w_nb, w_s) is the NEXT step to request
@@ -301,70 +305,130 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     zero_acc();
-    int s = 0, chunk = 0, tap = 0, cbuf = 0, slot = 0;
+    int row = 0, chunk = 0, cbuf = 0, slot = 0;  // the step being computed: (chunk, tap row dy = row - 1, dx), ring slot
     Frags f0, f1;
     load_frags(f0, cbuf, slot, -P - 1, 0);
 
-    while (true) {
-        // ---------------- requests of this step: weights of step s + 3, one halo piece of the next chunk ----------
-        // (past the last work item there is nothing left to request: the first slot image is requested again so that the
-        //  per-step DMA count stays constant -- the waits below are counted)
-        const int lw_nb = w_work < nwork ? w_nb : t_nb, lw_s = w_work < nwork ? w_s : 0, lw_slot = w_slot;
-        issue_weights(lw_nb, lw_s, lw_slot);
-        advance_w();
-        if (tap < kSlots) {
-            if (tap == 0 && !req_tile_ready) {
-                // first request for a new tile: where do its halo pixels come from
-                int nb_, b_, y0_, x0_, f0_;
-                const int rw = req_work < nwork ? req_work : work;  // past the end: re-request this tile (harmless)
-                decode_work(rw, nb_, b_, y0_, x0_, f0_);
+    // MFMAs of one k-step in two halves (by row-tile), so that the requests and the address arithmetic of a step can be
+    // placed BETWEEN them: an in-order wave hides ~6 ALU / DMA instructions behind each 32-cycle MFMA, and the two waves of
+    // a SIMD run in lock-step between barriers -- ~100 bookkeeping instructions in one lump idle the matrix pipe for both.
+    auto mma_part = [&](const Frags &f, int part) {
 #pragma unroll
-                for (int i = 0; i < kSlots; ++i) src_pix[i] = halo_src_pix(i, b_, y0_, x0_, f0_);
-                req_tile_ready = true;
-            }
-            // (tap is block-uniform but not a compile-time constant: select the slot's registers)
+        for (int i = 0; i < RT; ++i) {
+            if ((RT == 1 ? 0 : i) != part) continue;
 #pragma unroll
-            for (int i = 0; i < kSlots; ++i)
-                if (i == tap) issue_halo_piece(i);
-        } else {
-            // taps 6-8: no halo piece left -> one more (identical) request of this step's first weight piece, so that
-            // every step issues the same number of DMA instructions per wave (the waits are counted)
-            const int jj = (wave * C::W_PER_WAVE) % C::W_INSTR;
-            const int pslot = lw_slot;
-            const unsigned char *g = wbase + ((long long)lw_nb * steps + lw_s) * C::SLOT_BYTES + jj * 1024 + lane * 16;
-            dma16(g, ring_lds + (unsigned)(pslot * C::SLOT_BYTES + jj * 1024));
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // this wave's first weight piece of the slot image to request next, as a running per-lane pointer
+    const int wjj0 = (wave * C::W_PER_WAVE) % C::W_INSTR;
+    auto wptr_of = [&](int nb, int st) -> const unsigned char * {
+        return wbase + ((long long)nb * steps + st) * C::SLOT_BYTES + wjj0 * 1024 + lane * 16;
+    };
+    const unsigned char *wp = wptr_of(w_work < nwork ? w_nb : t_nb, w_work < nwork ? w_s : 0);
+    const unsigned char *wp_prev = wp;
+    unsigned wdst_prev = 0;
 
-        // ---------------- compute ----------------
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int shift = dy * P + dx;
-        load_frags(f1, cbuf, slot, shift, 1);
-        mma(f0);
-        // next step's coordinates
-        int n_tap = tap + 1, n_chunk = chunk, n_cbuf = cbuf, n_s = s + 1;
-        if (n_tap == 9) {
-            n_tap = 0;
+    // pins: the LDS reads may not sink to their first use (hipcc's default, which exposes the LDS latency); ALU, MFMA and the
+    // request statements float, so that the scheduler can hide them behind each other
+#define S3_PIN() __builtin_amdgcn_sched_barrier(0x07F)
+    // one step = one tap: DXI = dx + 1 is a compile-time constant, the tap row is not
+    // Instruction order of a step, spelled out for the scheduler (sched_group_barrier pipelines): the 2 (RT + CT) LDS
+    // reads of a k-step ride in the gaps of the first MFMAs of the PREVIOUS k-step, two per MFMA pair, so that no
+    // s_waitcnt lgkmcnt sits directly in front of an MFMA; everything else (address arithmetic, the request statements)
+    // is free to fill the remaining gaps.
+#define S3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define S3_PIPE()                                                                                                 \
+    if constexpr (BN == 128) {                                                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { S3_SGB(0x100, 2); S3_SGB(0x008, 2); }                  \
+        S3_SGB(0x008, 4);                                                                                         \
+    } else if constexpr (BN == 64) {                                                                              \
+        _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) { S3_SGB(0x100, 2); S3_SGB(0x008, 1); }                  \
+        S3_SGB(0x008, 3);                                                                                         \
+    } else {                                                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) { S3_SGB(0x100, 2); S3_SGB(0x008, 1); }                  \
+        S3_SGB(0x008, 1);                                                                                         \
+    }
+    // one step = one tap: DXI = dx + 1 is a compile-time constant, the tap row is not
+#define S3_STEP(DXI, NBUF, NSHIFT)                                                                                \
+    {                                                                                                             \
+        if (!S3_DBG(8)) load_frags(f1, cbuf, slot, srow + (DXI) - 1, 1);                                          \
+        mma_part(f0, 0);                                                                                          \
+        mma_part(f0, 1);                                                                                          \
+        { /* weights of step s + 3 -> ring slot w_slot */                                                         \
+            const unsigned wdst = ring_lds + (unsigned)(w_slot * C::SLOT_BYTES + wjj0 * 1024);                    \
+            if (!S3_DBG(4)) {                                                                                     \
+                dma16(wp, wdst);                                                                                  \
+                if (C::W_PER_WAVE == 2) dma16(wp + 1024, wdst + 1024);                                            \
+            }                                                                                                     \
+            wp_prev = wp;                                                                                         \
+            wdst_prev = wdst;                                                                                     \
+            wp += C::SLOT_BYTES;                                                                                  \
+            ++w_s;                                                                                                \
+            w_slot = (w_slot + 1) & (kRing - 1);                                                                  \
+        }                                                                                                         \
+        if (!S3_DBG(4)) { /* tap rows 0, 1: halo piece row * 3 + DXI of the next chunk; row 2: the weight piece again */ \
+            const unsigned char *hs_ = row == 0 ? hsrc[(DXI)] : hsrc[3 + (DXI)];                                  \
+            const int st_ = row == 0 ? hstep[(DXI)] : hstep[3 + (DXI)];                                           \
+            const unsigned hd_ = row == 0 ? h_dst[(DXI)] : h_dst[3 + (DXI)];                                      \
+            const void *gsel_ = row == 2 ? static_cast<const void *>(wp_prev) : static_cast<const void *>(hs_ + req_chunk * st_); \
+            const unsigned dsel_ = row == 2 ? wdst_prev : halo_lds + (unsigned)(req_buf * hbuf_bytes) + hd_;      \
+            dma16(gsel_, (unsigned)__builtin_amdgcn_readfirstlane((int)dsel_));                                   \
+        }                                                                                                         \
+        const int n_slot_ = (slot + 1) & (kRing - 1);                                                             \
+        if (!S3_DBG(8)) load_frags(f0, (NBUF), n_slot_, (NSHIFT), 0); /* operands of the next step (k-step 0) */   \
+        mma_part(f1, 0);                                                                                          \
+        mma_part(f1, 1);                                                                                          \
+        S3_PIPE()                                                                                                 \
+        S3_PIPE()                                                                                                 \
+        /* everything requested before this step has landed (this wave's part); then everyone's */                \
+        if (!S3_DBG(3)) {                                                                                         \
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");                           \
+        } else {                                                                                                  \
+            if (!S3_DBG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPS) : "memory");                         \
+            if (!S3_DBG(2)) asm volatile("s_barrier" ::: "memory");                                               \
+        }                                                                                                         \
+        slot = n_slot_;                                                                                           \
+    }
+
+    while (true) {
+        // ---- one tap row (dy = row - 1) of one 32-channel chunk: three steps ----
+        if (row == 0 && !req_tile_ready && !S3_DBG(4)) {
+            // first request for a new tile: where do its halo pixels come from
+            int nb_, b_, y0_, x0_, f0_;
+            const int rw = req_work < nwork ? req_work : work;  // past the end: re-request this tile (harmless)
+            decode_work(rw, nb_, b_, y0_, x0_, f0_);
+            set_halo_sources(b_, y0_, x0_, f0_);
+            req_tile_ready = true;
+        }
+        const int srow = (row - 1) * P;
+        S3_STEP(0, cbuf, srow + 0)
+        S3_STEP(1, cbuf, srow + 1)
+        int n_row = row + 1, n_chunk = chunk, n_cbuf = cbuf;
+        if (n_row == 3) {
+            n_row = 0;
             n_chunk = chunk + 1;
             n_cbuf = cbuf ^ 1;
         }
-        const bool last = n_s == steps;
-        const int n_slot = (slot + 1) & (kRing - 1);
-        {
-            const int ndy = n_tap / 3 - 1, ndx = n_tap - (n_tap / 3) * 3 - 1;
-            load_frags(f0, n_cbuf, n_slot, ndy * P + ndx, 0);  // operands of step s + 1 (k-step 0), read before the barrier
+        const bool last = n_row == 0 && n_chunk == A.chunks;
+        S3_STEP(2, n_cbuf, (n_row - 1) * P - 1)
+        if (w_s == steps) {  // the request pointer (one tap row ahead) has finished a work item's weights: on to the next one's
+            w_s = 0;
+            w_work += gridDim.x;
+            w_nb = w_work < nwork ? w_work / ntiles : w_nb;
+            wp = wptr_of(w_work < nwork ? w_nb : t_nb, 0);
         }
-        mma(f1);
-        // everything requested before this step has landed (this wave's part); then everyone's
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");
-        if (n_tap == 0) {  // the chunk is finished: the request pointer moves on to the chunk after the next
+        if (n_row == 0) {  // the chunk is finished: the request pointer moves on to the chunk after the next
             advance_req();
             if (req_chunk == 0) req_tile_ready = false;
         }
-        tap = n_tap;
+        row = n_row;
         chunk = n_chunk;
         cbuf = n_cbuf;
-        slot = n_slot;
-        s = n_s;
         if (!last) continue;
 
         // ======================= epilogue of this work item =======================
@@ -496,7 +560,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         const int prev_nb = t_nb;
         decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
         zero_acc();
-        s = 0;
         chunk = 0;
         // every wave is done with its staging window (the next chunk's DMA lands there) and with the parameters
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -559,6 +622,8 @@ hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         k.nj = (kHalo2D + 15) / 16;
     }
     k.nwork = k.nb * k.ntiles;
+    static const int dbg = [] { const char *e = std::getenv("QMRI_S3_DBG"); return e ? std::atoi(e) : 0; }();
+    k.dbg = dbg;
     (void)hipGetLastError();
     if (flat) {
         if (bn == 128) return s3_launch_t<128, true>(k, num_cu, stream);

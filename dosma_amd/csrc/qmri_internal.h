@@ -143,6 +143,8 @@ struct ConvS3Args {
     int xoff;
     int B, H, W;
     int Cin, Cout;
+    int deconv;          // 1: Conv2DTranspose(3x3, strides 2, SAME): (B, H, W) is the INPUT grid, the output grid is 2H x 2W,
+                         //    9 taps packed in phase order (pack_deconv_fused)
     const void *w;       // packed by pack_s3_weights: [Cout / BN][chunk * 9 + tap][plane hi | lo][BN][4 x 16 B swizzled], fp16, x 2^wshift
     float winv;          // 2^-wshift: the accumulators hold 2^wshift * convolution
     const float *bias;   // [Cout] or nullptr
@@ -164,7 +166,7 @@ struct ConvS3Args {
     int dbg;             // QMRI_S3_DBG timing experiments (0 in production)
 };
 bool conv_s3_supported(const ConvS3Args &k);
-int conv_s3_block_channels(int Cout);  // channel-block size the kernel uses for a layer: the weight packing depends on it
+int conv_s3_block_channels(int Cout, int deconv);  // channel-block size the kernel uses for a layer: the weight packing depends on it
 hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 // streaming kernels on the split layout (unet_s3.hip)
 hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,

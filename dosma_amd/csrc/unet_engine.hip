@@ -121,7 +121,7 @@ struct ConvLayer {
         }
         // conv_s3_kernel: [nb][step][plane][BN rows][4 positions x 8 halfs], position pos of row n holds the K piece
         // q = pos ^ ((n >> 2) & 3) (the bank-conflict swizzle of the LDS image; the DMA copies the image linearly)
-        const int BN = qmri::conv_s3_block_channels(Cout);
+        const int BN = qmri::conv_s3_block_channels(Cout, deconv);
         const int steps = ntaps * (Cin / 32);
         const size_t K = (size_t)steps * 32;
         std::vector<unsigned short> img((size_t)Cout * K * 2);
@@ -394,7 +394,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             L->relu = 0;
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
-            U_TRY(L->upload_parity(wk, false));
+            U_TRY(L->upload_parity(wk, s3_width_ok(U->W >> (l + 1))));  // tiles of the INPUT grid (level l + 1)
             if (U->split_levels >> l & 1u)
                 for (int ph = 0; ph < 4; ++ph) {
                     auto &P = U->updec_ph[(size_t)l * 4 + ph];
@@ -487,7 +487,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
         k.relu = L.relu;
         k.y = y; k.ldy = ldy; k.yoff = yoff;
-        const int bn = qmri::conv_s3_block_channels(L.Cout);
+        const int bn = qmri::conv_s3_block_channels(L.Cout, 0);
         const bool flat = W % 32 != 0;
         const bool fuse_pool = pool_y && !flat && bn >= 64 && !(H & 1);
         if (fuse_pool) { k.pool_y = pool_y; k.pool_ld = pool_ld; }
@@ -529,7 +529,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
 
 static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *mask, hipStream_t st) {
     const int D = U->depth;
-    char nm[32];
+    char nm[64];
     for (int l = 0; l < D; ++l) {
         const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
         void *t1 = U->tmp[l]->p;
@@ -557,12 +557,24 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
         void *cat = U->cat[l]->p;
         {
             const ConvLayer &L = *U->updec[(size_t)l];
-            auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
-            k.w_hi = L.h_hi.as<__bf16>();
-            k.w_lo = L.h_lo.as<__bf16>();
-            k.winv = L.winv;
-            U_TRY(qmri::conv_igemm_launch(k, 1, st));
-            snprintf(nm, sizeof(nm), "up%d.deconv:igemm;", l);
+            if (L.w_s3.p) {
+                qmri::ConvS3Args k;
+                std::memset(&k, 0, sizeof(k));
+                k.x = src; k.ldx = Cup; k.B = Bt; k.H = H / 2; k.W = W / 2;
+                k.Cin = L.Cin; k.Cout = L.Cout; k.deconv = 1;
+                k.w = L.w_s3.p; k.winv = L.winv;
+                k.bias = L.bias.as<float>();
+                k.y = cat; k.ldy = 2 * C; k.yoff = 0;
+                U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
+                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/bn%d;", l, (W / 2) % 32 ? "flat" : "2d", qmri::conv_s3_block_channels(L.Cout, 1));
+            } else {
+                auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
+                k.w_hi = L.h_hi.as<__bf16>();
+                k.w_lo = L.h_lo.as<__bf16>();
+                k.winv = L.winv;
+                U_TRY(qmri::conv_igemm_launch(k, 1, st));
+                snprintf(nm, sizeof(nm), "up%d.deconv:igemm;", l);
+            }
             U->trace += nm;
         }
         void *t1 = U->tmp[l]->p;
@@ -810,12 +822,13 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         hipDeviceProp_t prop;
         U_TRY(hipGetDeviceProperties(&prop, device));
         // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
-        const bool s3 = !ab && !transposed && precision != 2 && s3_width_ok(W);
+        const bool s3 = !ab && precision != 2 && s3_width_ok(W);
         if (!ab) U_TRY(L.upload_parity(wk, s3));
         if (s3) {
             qmri::ConvS3Args k;
             std::memset(&k, 0, sizeof(k));
             k.x = dxb.p; k.ldx = Cin; k.B = B; k.H = H; k.W = W; k.Cin = Cin; k.Cout = Cout;
+            k.deconv = transposed ? 1 : 0;
             k.w = L.w_s3.p; k.winv = L.winv;
             k.bias = L.bias.as<float>();
             k.scale = L.has_affine ? L.scale.as<float>() : nullptr;

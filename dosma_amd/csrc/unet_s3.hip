@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "qmri_internal.h"
 
@@ -68,10 +69,16 @@ struct S3Cfg {
     static constexpr int WM = kWaves / WN;               // waves along the pixel axis
     static constexpr int RT = 8 / WM;                    // 32-pixel row-tiles per wave
     static constexpr int CT = BN / WN / 32;              // 32-channel column tiles per wave
-    static constexpr int SLOT_BYTES = BN * 128;          // one ring slot: [plane][BN][64 B]
-    static constexpr int W_INSTR = SLOT_BYTES / 1024;    // DMA wave-instructions per slot: 16 / 8 / 4
-    static constexpr int W_PER_WAVE = W_INSTR >= kWaves ? W_INSTR / kWaves : 1;
-    static constexpr int DPS = W_PER_WAVE + 1;           // DMA instructions per wave per step (weights + one halo piece)
+    // Taps per ring slot = taps between two barriers.  At BN = 32 a tap is only 6 MFMAs per wave -- less than a barrier
+    // and a round of requests cost -- so a slot holds a whole tap ROW (3 taps, 12 KB) and the barrier comes once per row.
+    static constexpr int TPS = BN == 32 ? 3 : 1;
+    static constexpr int TAP_BYTES = BN * 128;           // one tap of one 32-channel chunk: [plane][BN][64 B]
+    static constexpr int SLOT_BYTES = TPS * TAP_BYTES;   // one ring slot
+    static constexpr int W_INSTR = SLOT_BYTES / 1024;    // DMA wave-instructions per slot: 16 / 8 / 12
+    static constexpr int W_PER_WAVE = (W_INSTR + kWaves - 1) / kWaves;
+    static constexpr int H_PER_TAP = TPS == 3 ? 2 : 1;   // halo pieces (or repeats) requested per tap
+    // DMA instructions per wave between two barriers (the waits are counted): weights of one slot + the halo pieces
+    static constexpr int DPS = W_PER_WAVE + TPS * H_PER_TAP;
 };
 
 __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)(lds_void *)p; }
@@ -95,10 +102,16 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 #define S3_DBG(bit) 0
 #endif
 
-template <int BN, bool FLAT>
+// DECONV: Conv2DTranspose(3x3, strides 2, SAME) (oaiunet2d.py:259-261) on the same machinery.  The tile is a tile of the
+// INPUT grid; the 9 taps (packed in phase order by pack_deconv_fused: 4 + 2 + 2 + 1) read the input at (dy, dx) in
+// {0, -1}^2 and accumulate into the accumulator set of their output phase (py, px); the epilogue writes the four phases
+// to the output pixels (2 y + py, 2 x + px).  The taps are unrolled (the accumulator set must be a compile-time index).
+template <int BN, bool FLAT, bool DECONV>
 __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A) {
     using C = S3Cfg<BN>;
     constexpr int RT = C::RT, CT = C::CT;
+    constexpr int NPH = DECONV ? 4 : 1;
+    static_assert(!DECONV || C::TPS == 1 || BN == 32, "");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NJ = A.nj;                       // DMA instructions (16 pixels each) per halo plane
     const int plane_bytes = NJ * 1024;
@@ -117,6 +130,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
 
     const int steps = A.steps;                 // chunks * 9 per work item
+    const int wsteps = steps / C::TPS;         // ring slots per work item
     const int nwork = A.nwork;                 // channel blocks x tiles
     const int ntiles = A.ntiles;
 
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
         for (int r = 0; r < C::W_PER_WAVE; ++r) {
             const int jj = (wave * C::W_PER_WAVE + r) % C::W_INSTR;  // BN = 32: waves 4-7 repeat the pieces of waves 0-3
-            const unsigned char *g = wbase + ((long long)nb * steps + s) * C::SLOT_BYTES + jj * 1024 + lane * 16;
+            const unsigned char *g = wbase + ((long long)nb * wsteps + s) * C::SLOT_BYTES + jj * 1024 + lane * 16;
             dma16(g, ring_lds + (unsigned)(slot * C::SLOT_BYTES + jj * 1024));
         }
     };
@@ -223,9 +237,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     struct Frags {
         f16x8 ah[RT], al[RT], bh[CT], bl[CT];
     };
-    auto load_frags = [&](Frags &f, int buf, int slot, int shift, int kk) {
+    auto load_frags = [&](Frags &f, int buf, int slot, int wtap, int shift, int kk) {
         const unsigned char *hb = halo + buf * hbuf_bytes;
-        const unsigned char *wb = ring + slot * C::SLOT_BYTES;
+        const unsigned char *wb = ring + slot * C::SLOT_BYTES + wtap * C::TAP_BYTES;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int hp = abase[i] + shift;
@@ -240,14 +254,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         }
     };
 
-    f32x16 acc[RT][CT];
+    f32x16 acc[NPH][RT][CT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+        for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ph][i][j][e] = 0.f;
     };
     int work = blockIdx.x;
     if (work >= nwork) return;
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     // weight requests run 3 steps ahead of the computation: (w_work, w_nb, w_s) is the NEXT step to request
     int w_work = work, w_nb = t_nb, w_s = 0, w_slot = 0;
     auto advance_w = [&]() {
-        if (++w_s == steps) {
+        if (++w_s == wsteps) {
             w_s = 0;
             w_work += gridDim.x;
             w_nb = w_work < nwork ? w_work / ntiles : w_nb;
@@ -307,27 +323,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     zero_acc();
     int row = 0, chunk = 0, cbuf = 0, slot = 0;  // the step being computed: (chunk, tap row dy = row - 1, dx), ring slot
     Frags f0, f1;
-    load_frags(f0, cbuf, slot, -P - 1, 0);
+    load_frags(f0, cbuf, slot, 0, DECONV ? 0 : -P - 1, 0);  // operands of the very first tap (k-step 0)
 
     // MFMAs of one k-step in two halves (by row-tile), so that the requests and the address arithmetic of a step can be
     // placed BETWEEN them: an in-order wave hides ~6 ALU / DMA instructions behind each 32-cycle MFMA, and the two waves of
     // a SIMD run in lock-step between barriers -- ~100 bookkeeping instructions in one lump idle the matrix pipe for both.
-    auto mma_part = [&](const Frags &f, int part) {
+    auto mma_part = [&](const Frags &f, int part, auto phc) {
+        constexpr int PH = decltype(phc)::value;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             if ((RT == 1 ? 0 : i) != part) continue;
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[PH][i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[PH][i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[PH][i][j], 0, 0, 0);
         }
     };
     // this wave's first weight piece of the slot image to request next, as a running per-lane pointer
     const int wjj0 = (wave * C::W_PER_WAVE) % C::W_INSTR;
     auto wptr_of = [&](int nb, int st) -> const unsigned char * {
-        return wbase + ((long long)nb * steps + st) * C::SLOT_BYTES + wjj0 * 1024 + lane * 16;
+        return wbase + ((long long)nb * wsteps + st) * C::SLOT_BYTES + wjj0 * 1024 + lane * 16;
     };
     const unsigned char *wp = wptr_of(w_work < nwork ? w_nb : t_nb, w_work < nwork ? w_s : 0);
     const unsigned char *wp_prev = wp;
@@ -354,12 +371,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         S3_SGB(0x008, 1);                                                                                         \
     }
     // one step = one tap: DXI = dx + 1 is a compile-time constant, the tap row is not
-#define S3_STEP(DXI, NBUF, NSHIFT)                                                                                \
+#define S3_STEP(ROW, DXI, SHIFT, PH, NBUF, NSHIFT)                                                                               \
     {                                                                                                             \
-        if (!S3_DBG(8)) load_frags(f1, cbuf, slot, srow + (DXI) - 1, 1);                                          \
-        mma_part(f0, 0);                                                                                          \
-        mma_part(f0, 1);                                                                                          \
-        { /* weights of step s + 3 -> ring slot w_slot */                                                         \
+        constexpr bool kSlotStart = C::TPS == 1 || (DXI) == 0; /* first tap of a ring slot: request the slot 3 ahead */ \
+        constexpr bool kSlotEnd = C::TPS == 1 || (DXI) == 2;   /* last tap of a ring slot: wait + barrier */      \
+        constexpr int kWTap = C::TPS == 3 ? (DXI) : 0;                                                            \
+        using PhC_ = std::integral_constant<int, (PH)>;                                                           \
+        if (!S3_DBG(8)) load_frags(f1, cbuf, slot, kWTap, (SHIFT), 1);                                            \
+        mma_part(f0, 0, PhC_{});                                                                                  \
+        mma_part(f0, 1, PhC_{});                                                                                  \
+        if constexpr (kSlotStart) { /* weights of the slot 3 ahead -> ring slot w_slot */                         \
             const unsigned wdst = ring_lds + (unsigned)(w_slot * C::SLOT_BYTES + wjj0 * 1024);                    \
             if (!S3_DBG(4)) {                                                                                     \
                 dma16(wp, wdst);                                                                                  \
@@ -371,33 +392,55 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             ++w_s;                                                                                                \
             w_slot = (w_slot + 1) & (kRing - 1);                                                                  \
         }                                                                                                         \
-        if (!S3_DBG(4)) { /* tap rows 0, 1: halo piece row * 3 + DXI of the next chunk; row 2: the weight piece again */ \
-            const unsigned char *hs_ = row == 0 ? hsrc[(DXI)] : hsrc[3 + (DXI)];                                  \
-            const int st_ = row == 0 ? hstep[(DXI)] : hstep[3 + (DXI)];                                           \
-            const unsigned hd_ = row == 0 ? h_dst[(DXI)] : h_dst[3 + (DXI)];                                      \
-            const void *gsel_ = row == 2 ? static_cast<const void *>(wp_prev) : static_cast<const void *>(hs_ + req_chunk * st_); \
-            const unsigned dsel_ = row == 2 ? wdst_prev : halo_lds + (unsigned)(req_buf * hbuf_bytes) + hd_;      \
-            dma16(gsel_, (unsigned)__builtin_amdgcn_readfirstlane((int)dsel_));                                   \
+        if (!S3_DBG(4)) {                                                                                         \
+            /* halo pieces of the NEXT chunk.  One tap per slot: piece row * 3 + DXI in tap rows 0, 1.  A tap row per slot: */ \
+            /* all six pieces in tap row 0 (two per tap), so that they have landed -- the waits come once per row -- before */ \
+            /* the last tap of row 2 reads the next chunk's first operands.  Where no piece is due the slot's first weight */ \
+            /* piece is requested again: every barrier interval issues the same number of DMA instructions per wave. */ \
+            _Pragma("unroll") for (int h_ = 0; h_ < C::H_PER_TAP; ++h_) {                                         \
+                constexpr int kP0 = C::TPS == 3 ? 2 * (DXI) : (DXI);                                              \
+                const bool due_ = C::TPS == 3 ? (ROW) == 0 : (ROW) < 2;                                           \
+                const int i0_ = kP0 + h_, i1_ = C::TPS == 3 ? i0_ : 3 + (DXI);                                    \
+                const unsigned char *hs_ = (ROW) == 0 ? hsrc[i0_] : hsrc[i1_];                                    \
+                const int st_ = (ROW) == 0 ? hstep[i0_] : hstep[i1_];                                             \
+                const unsigned hd_ = (ROW) == 0 ? h_dst[i0_] : h_dst[i1_];                                        \
+                const void *gsel_ = due_ ? static_cast<const void *>(hs_ + req_chunk * st_) : static_cast<const void *>(wp_prev); \
+                const unsigned dsel_ = due_ ? halo_lds + (unsigned)(req_buf * hbuf_bytes) + hd_ : wdst_prev;      \
+                dma16(gsel_, (unsigned)__builtin_amdgcn_readfirstlane((int)dsel_));                               \
+            }                                                                                                     \
         }                                                                                                         \
-        const int n_slot_ = (slot + 1) & (kRing - 1);                                                             \
-        if (!S3_DBG(8)) load_frags(f0, (NBUF), n_slot_, (NSHIFT), 0); /* operands of the next step (k-step 0) */   \
-        mma_part(f1, 0);                                                                                          \
-        mma_part(f1, 1);                                                                                          \
+        const int n_slot_ = kSlotEnd ? (slot + 1) & (kRing - 1) : slot;                                           \
+        constexpr int kNextWTap = C::TPS == 3 ? ((DXI) + 1) % 3 : 0;                                              \
+        if (!S3_DBG(8)) load_frags(f0, (NBUF), n_slot_, kNextWTap, (NSHIFT), 0); /* operands of the next step (k-step 0) */ \
+        mma_part(f1, 0, PhC_{});                                                                                  \
+        mma_part(f1, 1, PhC_{});                                                                                  \
         S3_PIPE()                                                                                                 \
         S3_PIPE()                                                                                                 \
-        /* everything requested before this step has landed (this wave's part); then everyone's */                \
-        if (!S3_DBG(3)) {                                                                                         \
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");                           \
-        } else {                                                                                                  \
-            if (!S3_DBG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPS) : "memory");                         \
-            if (!S3_DBG(2)) asm volatile("s_barrier" ::: "memory");                                               \
+        if constexpr (kSlotEnd) {                                                                                 \
+            /* everything requested before this barrier interval has landed (this wave's part); then everyone's */ \
+            if (!S3_DBG(3)) {                                                                                     \
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");                       \
+            } else {                                                                                              \
+                if (!S3_DBG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPS) : "memory");                     \
+                if (!S3_DBG(2)) asm volatile("s_barrier" ::: "memory");                                           \
+            }                                                                                                     \
         }                                                                                                         \
         slot = n_slot_;                                                                                           \
     }
 
+    // the request pointer (three slots ahead) has finished a work item's weights: on to the next one's.  (The steps of a work
+    // item are a multiple of 3 and the pointer starts 3 ahead: it can only run out after the third step of a tap row.)
+#define S3_WRAP()                                                        \
+    if (w_s == wsteps) {                                                 \
+        w_s = 0;                                                         \
+        w_work += gridDim.x;                                             \
+        w_nb = w_work < nwork ? w_work / ntiles : w_nb;                  \
+        wp = wptr_of(w_work < nwork ? w_nb : t_nb, 0);                   \
+    }
+
     while (true) {
         // ---- one tap row (dy = row - 1) of one 32-channel chunk: three steps ----
-        if (row == 0 && !req_tile_ready && !S3_DBG(4)) {
+        if ((DECONV || row == 0) && !req_tile_ready && !S3_DBG(4)) {
             // first request for a new tile: where do its halo pixels come from
             int nb_, b_, y0_, x0_, f0_;
             const int rw = req_work < nwork ? req_work : work;  // past the end: re-request this tile (harmless)
@@ -405,23 +448,40 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             set_halo_sources(b_, y0_, x0_, f0_);
             req_tile_ready = true;
         }
-        const int srow = (row - 1) * P;
-        S3_STEP(0, cbuf, srow + 0)
-        S3_STEP(1, cbuf, srow + 1)
-        int n_row = row + 1, n_chunk = chunk, n_cbuf = cbuf;
-        if (n_row == 3) {
+        int n_row, n_chunk = chunk, n_cbuf = cbuf;
+        bool last;
+        if constexpr (!DECONV) {
+            const int srow = (row - 1) * P;
+            S3_STEP(row, 0, srow - 1, 0, cbuf, srow + 0)
+            S3_STEP(row, 1, srow + 0, 0, cbuf, srow + 1)
+            n_row = row + 1;
+            if (n_row == 3) {
+                n_row = 0;
+                n_chunk = chunk + 1;
+                n_cbuf = cbuf ^ 1;
+            }
+            last = n_row == 0 && n_chunk == A.chunks;
+            S3_STEP(row, 2, srow + 1, 0, n_cbuf, (n_row - 1) * P - 1)
+        } else {
+            // one whole 32-channel chunk: taps t = 0..8 = (dy, dx, phase):
+            //   (0,0,0) (0,-1,0) (-1,0,0) (-1,-1,0) | (0,0,1) (-1,0,1) | (0,0,2) (0,-1,2) | (0,0,3)
             n_row = 0;
             n_chunk = chunk + 1;
             n_cbuf = cbuf ^ 1;
+            last = n_chunk == A.chunks;
+            S3_STEP(0, 0, 0, 0, cbuf, -1)
+            S3_STEP(0, 1, -1, 0, cbuf, -P)
+            S3_STEP(0, 2, -P, 0, cbuf, -P - 1)
+            S3_WRAP()
+            S3_STEP(1, 0, -P - 1, 0, cbuf, 0)
+            S3_STEP(1, 1, 0, 1, cbuf, -P)
+            S3_STEP(1, 2, -P, 1, cbuf, 0)
+            S3_WRAP()
+            S3_STEP(2, 0, 0, 2, cbuf, -1)
+            S3_STEP(2, 1, -1, 2, cbuf, 0)
+            S3_STEP(2, 2, 0, 3, n_cbuf, 0)
         }
-        const bool last = n_row == 0 && n_chunk == A.chunks;
-        S3_STEP(2, n_cbuf, (n_row - 1) * P - 1)
-        if (w_s == steps) {  // the request pointer (one tap row ahead) has finished a work item's weights: on to the next one's
-            w_s = 0;
-            w_work += gridDim.x;
-            w_nb = w_work < nwork ? w_work / ntiles : w_nb;
-            wp = wptr_of(w_work < nwork ? w_nb : t_nb, 0);
-        }
+        S3_WRAP()
         if (n_row == 0) {  // the chunk is finished: the request pointer moves on to the chunk after the next
             advance_req();
             if (req_chunk == 0) req_tile_ready = false;
@@ -437,10 +497,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             unsigned char *stage = halo + (cbuf ^ 1) * hbuf_bytes + wave * 4096;
             // output pixel of every tile position (2D: computed inline; FLAT: table filled by the first 256 threads)
             if (FLAT) {
-                if (tid < kMTile) outpix[tid] = flat_to_pix(t_f0 + tid, P, A.H, A.W, A.B);
+                if (tid < kMTile) {
+                    int pix = flat_to_pix(t_f0 + tid, P, A.H, A.W, A.B);
+                    if (DECONV && pix >= 0) {  // input pixel (b, y, x) -> output pixel (b, 2 y, 2 x) of the 2H x 2W grid
+                        const int x = pix % A.W, r = pix / A.W;  // r = b * H + y
+                        pix = (2 * r) * (2 * A.W) + 2 * x;
+                    }
+                    outpix[tid] = pix;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             const float winv = A.winv;
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int col = (wn * CT + j) * 32 + (lane & 31);
@@ -449,12 +518,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        float v = fmaf(acc[i][j][e], winv, bias);
+                        float v = fmaf(acc[ph][i][j][e], winv, bias);
                         if (A.relu) v = fmaxf(v, 0.f);
-                        acc[i][j][e] = fmaf(v, scale, shift_);
+                        acc[ph][i][j][e] = fmaf(v, scale, shift_);
                     }
             }
             const int n0 = t_nb * BN;
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+            const int ph_off = DECONV ? (ph >> 1) * 2 * A.W + (ph & 1) : 0;  // output phase (py, px) = (ph >> 1, ph & 1)
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int cbase = n0 + (wn * CT + j) * 32;  // first output channel of this column tile
@@ -465,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
                         // rows (pixels) e and e + 1 of this lane: (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-                        const float v0 = acc[i][j][e], v1 = acc[i][j][e + 1];
+                        const float v0 = acc[ph][i][j][e], v1 = acc[ph][i][j][e + 1];
                         const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
                         const h16x2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
                         const int r0 = (e & 3) + 8 * (e >> 2) + 4 * khalf;
@@ -485,17 +557,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                                 pix = outpix[rt * 32 + px];
                             } else {
                                 const int yy = t_y0 + rt;
-                                pix = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
+                                if (DECONV)
+                                    pix = yy < A.H ? (2 * (t_b * A.H + yy)) * (2 * A.W) + 2 * (t_x0 + px) : -1;
+                                else
+                                    pix = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
                             }
                             if (pix >= 0) {
                                 const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
                                 unsigned char *dst = static_cast<unsigned char *>(A.y) +
-                                                     ((long long)pix * A.ldy + A.yoff + cbase) * 4 + pc * 16;
+                                                     ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + pc * 16;
                                 *reinterpret_cast<uint4 *>(dst) = v;
                             }
                         }
                     }
-                    if (BN == 32 && A.head_w) {
+                    if (!DECONV && BN == 32 && A.head_w) {
                         // 1x1 head on the finished tile: lane = (pixel, half of the channels)
                         const int px = lane & 31, half = khalf;
                         const f16x8 *row = reinterpret_cast<const f16x8 *>(stage + px * 128 + half * 32);
@@ -526,11 +601,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                     }
                 }
                 // ---- fused MaxPooling2D(2x2): rows rt, rt+1 of this wave (RT = 2) -> 16 pooled pixels x 32 channels ----
-                if (!FLAT && RT == 2 && A.pool_y) {
+                if (!DECONV && !FLAT && RT == 2 && A.pool_y) {
 #pragma unroll
                     for (int e2 = 0; e2 < 8; ++e2) {
                         const int e = 2 * e2;
-                        const float m = fmaxf(fmaxf(acc[0][j][e], acc[0][j][e + 1]), fmaxf(acc[RT - 1][j][e], acc[RT - 1][j][e + 1]));
+                        const float m = fmaxf(fmaxf(acc[0][0][j][e], acc[0][0][j][e + 1]), fmaxf(acc[0][RT - 1][j][e], acc[0][RT - 1][j][e + 1]));
                         const int r0 = ((e & 3) + 8 * (e >> 2) + 4 * khalf) >> 1;  // pooled column 0..15
                         const __fp16 h = __builtin_amdgcn_cvt_pkrtz(m, 0.f)[0];
                         const __fp16 l = __builtin_amdgcn_cvt_pkrtz(m - (float)h, 0.f)[0];
@@ -553,6 +628,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                     }
                 }
             }
+            }  // phases
         }
         // ---- next work item ----
         work += gridDim.x;
@@ -576,7 +652,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 }
 
 static size_t s3_lds_bytes(int bn, int nj) {
-    return (size_t)4 * nj * 1024 + (size_t)kRing * bn * 128 + kMTile * 4 + (size_t)3 * bn * 4 + (32 * 4 + 4) * 4;
+    const size_t slot = (size_t)(bn == 32 ? 3 : 1) * bn * 128;  // S3Cfg::SLOT_BYTES
+    return (size_t)4 * nj * 1024 + (size_t)kRing * slot + kMTile * 4 + (size_t)3 * bn * 4 + (32 * 4 + 4) * 4;
 }
 
 bool conv_s3_supported(const ConvS3Args &k) {
@@ -585,9 +662,9 @@ bool conv_s3_supported(const ConvS3Args &k) {
     return k.W + 2 <= 50;                // flattened zero-framed stack (LDS: 256 + 2 (W + 2) + 2 halo pixels)
 }
 
-template <int BN, bool FLAT>
+template <int BN, bool FLAT, bool DECONV>
 static hipError_t s3_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
-    auto fn = conv_s3_kernel<BN, FLAT>;
+    auto fn = conv_s3_kernel<BN, FLAT, DECONV>;
     const size_t lds = s3_lds_bytes(BN, k.nj);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -596,15 +673,20 @@ static hipError_t s3_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
     return hipGetLastError();
 }
 
-int conv_s3_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32); }
+// channel-block size the kernel uses for a layer (the weight packing depends on it).  The transposed convolution keeps
+// four accumulator sets: 32 channels per block (64: 4 x 32 + 72 operand registers -> 256 VGPRs and 170 B of scratch).
+int conv_s3_block_channels(int Cout, int deconv) {
+    if (deconv) return 32;
+    return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
+}
 
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
     ConvS3Args k = k0;
     if (!conv_s3_supported(k)) return hipErrorInvalidValue;
-    const int bn = conv_s3_block_channels(k.Cout);
+    const int bn = conv_s3_block_channels(k.Cout, k.deconv);
     const bool flat = k.W % 32 != 0;
-    if (k.head_w && (bn != 32 || k.Cout != 32 || flat || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
-    if (k.pool_y && (flat || (k.H & 1) || (k.W & 1) || bn == 32)) return hipErrorInvalidValue;
+    if (k.head_w && (bn != 32 || k.Cout != 32 || flat || k.deconv || k.head_nc < 1 || k.head_nc > 4)) return hipErrorInvalidValue;
+    if (k.pool_y && (flat || k.deconv || (k.H & 1) || (k.W & 1) || bn == 32)) return hipErrorInvalidValue;
     k.chunks = k.Cin / 32;
     k.steps = k.chunks * 9;
     k.nb = k.Cout / bn;
@@ -625,14 +707,15 @@ hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     static const int dbg = [] { const char *e = std::getenv("QMRI_S3_DBG"); return e ? std::atoi(e) : 0; }();
     k.dbg = dbg;
     (void)hipGetLastError();
+    if (k.deconv) return flat ? s3_launch_t<32, true, true>(k, num_cu, stream) : s3_launch_t<32, false, true>(k, num_cu, stream);
     if (flat) {
-        if (bn == 128) return s3_launch_t<128, true>(k, num_cu, stream);
-        if (bn == 64) return s3_launch_t<64, true>(k, num_cu, stream);
-        return s3_launch_t<32, true>(k, num_cu, stream);
+        if (bn == 128) return s3_launch_t<128, true, false>(k, num_cu, stream);
+        if (bn == 64) return s3_launch_t<64, true, false>(k, num_cu, stream);
+        return s3_launch_t<32, true, false>(k, num_cu, stream);
     }
-    if (bn == 128) return s3_launch_t<128, false>(k, num_cu, stream);
-    if (bn == 64) return s3_launch_t<64, false>(k, num_cu, stream);
-    return s3_launch_t<32, false>(k, num_cu, stream);
+    if (bn == 128) return s3_launch_t<128, false, false>(k, num_cu, stream);
+    if (bn == 64) return s3_launch_t<64, false, false>(k, num_cu, stream);
+    return s3_launch_t<32, false, false>(k, num_cu, stream);
 }
 
 // =====================================================================================================================

@@ -153,6 +153,12 @@ def library_path() -> str:
     return _SO
 
 
+# DOSMA_AMD_LIB=<path>: load another build of the SAME library (e.g. one compiled with -DQMRI_S3_EXPERIMENTS for the timing
+# experiments of scripts/s3_experiments.sh).  Still the HIP library -- there is no other implementation to point this at.
+if os.environ.get("DOSMA_AMD_LIB"):
+    _SO = os.path.abspath(os.environ["DOSMA_AMD_LIB"])
+
+
 def _share_hip_runtime_with_torch():
     """One HIP runtime per process.
 

@@ -32,6 +32,29 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, extra_flags) -> str:
+    """A second library next to the product one (dosma_amd/libqmri_hip_<name>.so) compiled with extra hipcc flags --
+    used for timing experiments (-DQMRI_S3_EXPERIMENTS); selected at run time with DOSMA_AMD_LIB=<path>."""
+    bdir = os.path.join(HERE, "build", name)
+    os.makedirs(bdir, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(
+                [os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC)] + [os.path.getmtime(os.path.join(ROOT, "include", "qmri.h"))]):
+            continue
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *extra_flags,
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    out = os.path.join(HERE, f"libqmri_hip_{name}.so")
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return SO
@@ -79,4 +102,7 @@ def _build_locked(bdir: str, verbose: bool, force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_variant("exp", ["-DQMRI_S3_EXPERIMENTS"]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -55,10 +55,11 @@ constexpr int kRing = 4;           // weight ring slots
 // LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16 (M0), global source per lane.
 // Issued through inline asm so that hipcc neither counts it (it would drain vmcnt(0) before every ds_read it cannot
 // prove disjoint) nor waits for it: every wait in this file is a hand-counted s_waitcnt vmcnt(N).
+// (M0 is written and read inside ONE statement and not restored: nothing else in these kernels uses M0 -- gfx9+ LDS
+//  instructions do not -- and tests/test_abi.py checks the generated code for any other M0 reader.)
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
                  : "v"(gsrc), "s"(lds_dst_wave_base)
                  : "memory");
 }
@@ -96,7 +97,7 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 
 }  // namespace
 
-#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads)
+#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads | 16 no epilogue global stores | 32 no epilogue at all)
 #define S3_DBG(bit) (A.dbg & (bit))
 #else
 #define S3_DBG(bit) 0
@@ -347,8 +348,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         return wbase + ((long long)nb * wsteps + st) * C::SLOT_BYTES + wjj0 * 1024 + lane * 16;
     };
     const unsigned char *wp = wptr_of(w_work < nwork ? w_nb : t_nb, w_work < nwork ? w_s : 0);
-    const unsigned char *wp_prev = wp;
-    unsigned wdst_prev = 0;
 
     // pins: the LDS reads may not sink to their first use (hipcc's default, which exposes the LDS latency); ALU, MFMA and the
     // request statements float, so that the scheduler can hide them behind each other
@@ -386,27 +385,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 dma16(wp, wdst);                                                                                  \
                 if (C::W_PER_WAVE == 2) dma16(wp + 1024, wdst + 1024);                                            \
             }                                                                                                     \
-            wp_prev = wp;                                                                                         \
-            wdst_prev = wdst;                                                                                     \
             wp += C::SLOT_BYTES;                                                                                  \
             ++w_s;                                                                                                \
             w_slot = (w_slot + 1) & (kRing - 1);                                                                  \
         }                                                                                                         \
-        if (!S3_DBG(4)) {                                                                                         \
-            /* halo pieces of the NEXT chunk.  One tap per slot: piece row * 3 + DXI in tap rows 0, 1.  A tap row per slot: */ \
-            /* all six pieces in tap row 0 (two per tap), so that they have landed -- the waits come once per row -- before */ \
-            /* the last tap of row 2 reads the next chunk's first operands.  Where no piece is due the slot's first weight */ \
-            /* piece is requested again: every barrier interval issues the same number of DMA instructions per wave. */ \
+        /* halo pieces of the NEXT chunk.  One tap per slot: piece row * 3 + DXI in tap rows 0, 1.  A tap row per slot: all */ \
+        /* six pieces in tap row 0 (two per tap), so that they have landed -- the waits come once per row -- before the last */ \
+        /* tap of row 2 reads the next chunk's first operands.  Tap rows without pieces issue nothing: the counted wait at */ \
+        /* the end of the interval uses the matching count (requesting identical bytes again to keep ONE count cost 29 % of */ \
+        /* a 32-channel layer in DMA issue slots). */                                                               \
+        const bool due_ = C::TPS == 3 ? (ROW) == 0 : (ROW) < 2;                                                   \
+        if (due_ && !S3_DBG(4)) {                                                                                 \
             _Pragma("unroll") for (int h_ = 0; h_ < C::H_PER_TAP; ++h_) {                                         \
                 constexpr int kP0 = C::TPS == 3 ? 2 * (DXI) : (DXI);                                              \
-                const bool due_ = C::TPS == 3 ? (ROW) == 0 : (ROW) < 2;                                           \
                 const int i0_ = kP0 + h_, i1_ = C::TPS == 3 ? i0_ : 3 + (DXI);                                    \
                 const unsigned char *hs_ = (ROW) == 0 ? hsrc[i0_] : hsrc[i1_];                                    \
                 const int st_ = (ROW) == 0 ? hstep[i0_] : hstep[i1_];                                             \
                 const unsigned hd_ = (ROW) == 0 ? h_dst[i0_] : h_dst[i1_];                                        \
-                const void *gsel_ = due_ ? static_cast<const void *>(hs_ + req_chunk * st_) : static_cast<const void *>(wp_prev); \
-                const unsigned dsel_ = due_ ? halo_lds + (unsigned)(req_buf * hbuf_bytes) + hd_ : wdst_prev;      \
-                dma16(gsel_, (unsigned)__builtin_amdgcn_readfirstlane((int)dsel_));                               \
+                dma16(hs_ + req_chunk * st_, (unsigned)__builtin_amdgcn_readfirstlane(                           \
+                                                 (int)(halo_lds + (unsigned)(req_buf * hbuf_bytes) + hd_)));      \
             }                                                                                                     \
         }                                                                                                         \
         const int n_slot_ = kSlotEnd ? (slot + 1) & (kRing - 1) : slot;                                           \
@@ -418,11 +415,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         S3_PIPE()                                                                                                 \
         if constexpr (kSlotEnd) {                                                                                 \
             /* everything requested before this barrier interval has landed (this wave's part); then everyone's */ \
-            if (!S3_DBG(3)) {                                                                                     \
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");                       \
-            } else {                                                                                              \
+            if (S3_DBG(3)) {                                                                                      \
                 if (!S3_DBG(1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPS) : "memory");                     \
                 if (!S3_DBG(2)) asm volatile("s_barrier" ::: "memory");                                           \
+            } else if (due_) {                                                                                    \
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::DPS) : "memory");                       \
+            } else {                                                                                              \
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::W_PER_WAVE) : "memory");                \
             }                                                                                                     \
         }                                                                                                         \
         slot = n_slot_;                                                                                           \
@@ -493,7 +492,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 
         // ======================= epilogue of this work item =======================
         // staging: the halo buffer of the chunk that just finished (cbuf ^ 1 after the advance above), 4 KB + per wave
-        {
+        if (!S3_DBG(32)) {
             unsigned char *stage = halo + (cbuf ^ 1) * hbuf_bytes + wave * 4096;
             // output pixel of every tile position (2D: computed inline; FLAT: table filled by the first 256 threads)
             if (FLAT) {
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                                 else
                                     pix = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
                             }
-                            if (pix >= 0) {
+                            if (pix >= 0 && !S3_DBG(16)) {
                                 const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
                                 unsigned char *dst = static_cast<unsigned char *>(A.y) +
                                                      ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + pc * 16;

@@ -132,7 +132,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 
     const int steps = A.steps;                 // chunks * 9 per work item
     const int wsteps = steps / C::TPS;         // ring slots per work item
-    const int nwork = A.nwork;                 // channel blocks x tiles
     const int ntiles = A.ntiles;
 
     // ---- per-lane constants of the halo DMA: this wave's slot i is instruction j = wave + 8 i of the 2 NJ that
@@ -192,7 +191,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     // the byte step from chunk to chunk (0 for pieces that read the zero line)
     const unsigned char *hsrc[kSlots];
     int hstep[kSlots];
+    // 2D tiling: the halo geometry does not depend on the tile -- row / column of the piece's pixel inside the halo and its
+    // byte offset relative to the tile's first pixel are per-lane constants; a tile only adds its origin and the border test
+    int h_yx[kSlots], h_rel[kSlots];
+    if (!FLAT) {
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            const int hp = h_hp[i] < 0 ? 0 : h_hp[i];
+            const int hy = hp / kPitch2D, hx = hp - hy * kPitch2D;
+            h_yx[i] = h_hp[i] < 0 ? -1 : (hy | (hx << 8));
+            h_rel[i] = (int)((((long long)(hy - 1) * A.W + (hx - 1)) * A.ldx) * 4) + h_srcb[i];
+        }
+    }
     auto set_halo_sources = [&](int b, int y0, int x0, int f0) {
+        if (!FLAT) {
+            const unsigned char *origin = xbase + (((long long)(b * A.H + y0) * A.W + x0) * A.ldx + A.xoff) * 4;
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) {
+                const int yy = y0 + (h_yx[i] & 0xFF) - 1, xx = x0 + ((h_yx[i] >> 8) & 0xFF) - 1;
+                const bool ok = h_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+                hsrc[i] = ok ? origin + h_rel[i] : zero_line;
+                hstep[i] = ok ? 128 : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
             const int pix = halo_src_pix(i, b, y0, x0, f0);
@@ -266,7 +288,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[ph][i][j][e] = 0.f;
     };
+    // Work distribution.  Blocks are placed on XCD (blockIdx % 8) -- observed, used for speed only -- and every XCD has its
+    // own L2: with the plain round-robin walk two tiles that share halo rows run on different XCDs at the same time and the
+    // 1.33x halo over-fetch goes to the fabric.  With a grid that is a multiple of 8, XCD x walks the contiguous range
+    // [x, x + 1) * ceil(nwork / 8) of work items instead, its blocks interleaved inside it: neighbouring tiles (and one
+    // channel block's weights) stay in one L2.
+    int wstride = gridDim.x, w_end = A.nwork;
     int work = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && A.nwork >= 64) {
+        const int per_xcd = (A.nwork + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        wstride = gridDim.x >> 3;
+        work = xcd * per_xcd + (blockIdx.x >> 3);
+        w_end = (xcd + 1) * per_xcd < A.nwork ? (xcd + 1) * per_xcd : A.nwork;
+    }
+    const int nwork = w_end;  // (everything below tests "is there such a work item" against this block's range)
     if (work >= nwork) return;
     decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
 
@@ -282,7 +318,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     auto advance_w = [&]() {
         if (++w_s == wsteps) {
             w_s = 0;
-            w_work += gridDim.x;
+            w_work += wstride;
             w_nb = w_work < nwork ? w_work / ntiles : w_nb;
         }
         w_slot = (w_slot + 1) & (kRing - 1);
@@ -297,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         req_buf ^= 1;
         if (++req_chunk == A.chunks) {
             req_chunk = 0;
-            req_work += gridDim.x;
+            req_work += wstride;
         }
     };
     advance_req();
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #define S3_WRAP()                                                        \
     if (w_s == wsteps) {                                                 \
         w_s = 0;                                                         \
-        w_work += gridDim.x;                                             \
+        w_work += wstride;                                             \
         w_nb = w_work < nwork ? w_work / ntiles : w_nb;                  \
         wp = wptr_of(w_work < nwork ? w_nb : t_nb, 0);                   \
     }
@@ -630,7 +666,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             }  // phases
         }
         // ---- next work item ----
-        work += gridDim.x;
+        work += wstride;
         if (work >= nwork) break;
         const int prev_nb = t_nb;
         decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);

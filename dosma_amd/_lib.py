@@ -73,6 +73,24 @@ class QmriLinfitArgs(ctypes.Structure):
     ]
 
 
+class QmriPolylsArgs(ctypes.Structure):
+    _fields_ = [
+        ("y", ctypes.c_void_p), ("y_dtype", ctypes.c_int32), ("E", ctypes.c_int32),
+        ("N", ctypes.c_int64), ("ld", ctypes.c_int64),
+        ("P", ctypes.c_int32), ("skip_rules", ctypes.c_int32),
+        ("solve", ctypes.POINTER(ctypes.c_double)), ("design", ctypes.POINTER(ctypes.c_double)),
+        ("w", ctypes.POINTER(ctypes.c_double)),
+        ("use_y_bounds", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("y_lo", ctypes.c_double), ("y_hi", ctypes.c_double), ("r2_eps", ctypes.c_double),
+        ("popt", ctypes.c_void_p), ("r2", ctypes.c_void_p), ("resid", ctypes.c_void_p),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+POLY_MAX_PARAMS = 8
+MAX_ECHOES = 32
+
+
 class QmriUnet2dDesc(ctypes.Structure):
     _fields_ = [
         ("depth", ctypes.c_int32), ("base_features", ctypes.c_int32), ("n_classes", ctypes.c_int32),
@@ -133,7 +151,7 @@ PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2}
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
     "qmri_monoexp_fit_device", "qmri_monoexp_fit_host", "qmri_set_timing", "qmri_last_kernel_ms",
-    "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host",
+    "qmri_monoexp_kernel_name", "qmri_linfit_device", "qmri_linfit_host", "qmri_polyls_device", "qmri_polyls_host",
     "qmri_unet2d_create", "qmri_unet2d_set_precision", "qmri_unet2d_trace", "qmri_unet2d_forward", "qmri_unet2d_destroy",
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
@@ -223,6 +241,10 @@ def load():
         for name in ("qmri_linfit_device", "qmri_linfit_host"):
             fn = getattr(lib, name)
             fn.argtypes = [ctypes.POINTER(QmriLinfitArgs)]
+            fn.restype = ctypes.c_int
+        for name in ("qmri_polyls_device", "qmri_polyls_host"):
+            fn = getattr(lib, name)
+            fn.argtypes = [ctypes.POINTER(QmriPolylsArgs)]
             fn.restype = ctypes.c_int
         lib.qmri_unet2d_create.argtypes = [ctypes.POINTER(QmriUnet2dDesc), ctypes.POINTER(ctypes.c_void_p)]
         lib.qmri_unet2d_create.restype = ctypes.c_int
@@ -458,6 +480,49 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
     a.device = _dev(device)
     check(lib.qmri_linfit_host(ctypes.byref(a)))
+    return out
+
+
+def polyls_host(y, solve, design, *, w=None, per_sequence_rules=False, y_bounds=None, r2_eps=1e-8, want_resid=False,
+                device=None):
+    """General polynomial least squares per column of ``y`` (E, N) on the GPU: ``popt = solve @ y`` (P, E), fitted values
+    ``design @ popt`` for r2, weighted residual sum of squares.  Returns dict(popt (N, P), r2 (N,), [resid (N,)])."""
+    lib = load()
+    require_device()
+    y = np.ascontiguousarray(y)
+    E, N = y.shape
+    solve = np.ascontiguousarray(solve, dtype=np.float64)
+    design = np.ascontiguousarray(design, dtype=np.float64)
+    P = solve.shape[0]
+    if solve.shape != (P, E) or design.shape != (E, P):
+        raise ValueError(f"solve must be (P, {E}) and design ({E}, P)")
+    if P > POLY_MAX_PARAMS or E > MAX_ECHOES:
+        raise NotImplementedError(f"polyfit on the GPU takes deg + 1 <= {POLY_MAX_PARAMS} and at most {MAX_ECHOES} samples")
+    a = QmriPolylsArgs()
+    a.y, a.y_dtype, a.E, a.N, a.ld, a.P = _ptr(y), qdtype(y.dtype), E, N, N, P
+    dp = ctypes.POINTER(ctypes.c_double)
+    a.solve, a.design = solve.ctypes.data_as(dp), design.ctypes.data_as(dp)
+    keep = [solve, design]
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+        if w.shape[0] != E:
+            raise TypeError("expected x and w to have same length")
+        a.w = w.ctypes.data_as(dp)
+        keep.append(w)
+    a.skip_rules = 1 if per_sequence_rules else 0
+    a.y_lo, a.y_hi = -np.inf, np.inf
+    if y_bounds is not None:
+        a.use_y_bounds = 1
+        a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
+    a.r2_eps = float(r2_eps)
+    out = {"popt": np.empty((N, P)), "r2": np.empty(N)}
+    a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
+    if want_resid:
+        out["resid"] = np.empty(N)
+        a.resid = _ptr(out["resid"])
+    a.device = _dev(device)
+    check(lib.qmri_polyls_host(ctypes.byref(a)))
+    del keep
     return out
 
 

@@ -626,6 +626,79 @@ int qmri_linfit_host(const qmri_linfit_args *a) {
 }
 
 
+// ---- general polynomial least squares (linfit.hip: polyls_kernel) ---------------------------------------------------
+static int polyls_validate(const qmri_polyls_args *a) {
+    if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
+    if (!a->y || !a->solve || !a->design || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, solve, design, popt and r2 are required");
+    if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
+    if (a->P < 1 || a->P > QMRI_POLY_MAX_PARAMS) return fail(QMRI_ERR_UNSUPPORTED, "deg + 1 must be in [1, %d]", QMRI_POLY_MAX_PARAMS);
+    if (a->E < 1 || a->E > QMRI_MAX_ECHOES) return fail(QMRI_ERR_UNSUPPORTED, "E must be in [1, %d]", QMRI_MAX_ECHOES);
+    if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
+    return QMRI_OK;
+}
+
+int qmri_polyls_device(const qmri_polyls_args *a) {
+    const int rc = polyls_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    DeviceCtx *ctx = nullptr;
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(ctx_get(a->device, &ctx));
+    hipStream_t stream = static_cast<hipStream_t>(a->stream);
+    const int P = a->P, E = a->E;
+    std::vector<double> ops((size_t)2 * P * E + E);
+    std::memcpy(ops.data(), a->solve, sizeof(double) * P * E);
+    std::memcpy(ops.data() + (size_t)P * E, a->design, sizeof(double) * P * E);
+    for (int e = 0; e < E; ++e) ops[(size_t)2 * P * E + e] = a->w ? a->w[e] : 1.0;
+    AsyncScratch dops;
+    HIP_TRY(dops.alloc(ops.size() * sizeof(double), stream));
+    HIP_TRY(hipMemcpyAsync(dops.p, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `ops` is a pageable stack-lifetime buffer: the copy must have read it
+    qmri::PolylsKArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.y = a->y; k.ld = a->ld; k.N = a->N; k.E = E; k.P = P; k.y_dtype = a->y_dtype;
+    k.skip_rules = a->skip_rules; k.use_y_bounds = a->use_y_bounds; k.y_lo = a->y_lo; k.y_hi = a->y_hi;
+    k.r2_eps = a->r2_eps;
+    k.ops = static_cast<const double *>(dops.p);
+    k.popt = a->popt; k.r2 = a->r2; k.resid = a->resid;
+    HIP_TRY(qmri::polyls_launch(k, ctx->num_cu, stream));
+    return QMRI_OK;
+}
+
+int qmri_polyls_host(const qmri_polyls_args *a) {
+    const int rc = polyls_validate(a);
+    if (rc != QMRI_OK) return rc;
+    if (a->N == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(a->device));
+    const size_t es = dtype_size(a->y_dtype);
+    const size_t N = (size_t)a->N;
+    void *dy = nullptr;
+    double *dp = nullptr, *dr = nullptr, *ds = nullptr;
+    int status = QMRI_OK;
+    hipError_t e = hipMalloc(&dy, (size_t)a->E * N * es);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dp), N * a->P * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dr), N * 8);
+    if (e == hipSuccess && a->resid) e = hipMalloc(reinterpret_cast<void **>(&ds), N * 8);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(dy, N * es, a->y, (size_t)a->ld * es, N * es, (size_t)a->E, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        qmri_polyls_args d = *a;
+        d.y = dy; d.ld = a->N; d.popt = dp; d.r2 = dr; d.resid = ds; d.stream = nullptr;
+        status = qmri_polyls_device(&d);
+        if (status == QMRI_OK) {
+            e = hipMemcpy(a->popt, dp, N * a->P * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(a->r2, dr, N * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && a->resid) e = hipMemcpy(a->resid, ds, N * 8, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dy);
+    (void)hipFree(dp);
+    (void)hipFree(dr);
+    (void)hipFree(ds);
+    if (e != hipSuccess) return fail(QMRI_ERR_HIP, "polyls_host: %s", hipGetErrorString(e));
+    return status;
+}
+
 // ---- general lmdif (lm_generic.hip) ---------------------------------------------------------------------
 void qmri_lmfit_defaults(qmri_lmfit_args *a) {
     if (!a) return;

@@ -69,6 +69,23 @@ struct LinfitKArgs {
     double xmean, sxx;
     double x[QMRI_MAX_ECHOES];
 };
+// Kernel-argument block of the general polynomial least-squares kernel (linfit.hip: polyls_kernel).
+struct PolylsKArgs {
+    const void *y;
+    long long ld;
+    long long N;
+    int E, P;            // samples, parameters (deg + 1 <= QMRI_POLY_MAX_PARAMS)
+    int y_dtype;
+    int skip_rules;
+    int use_y_bounds;
+    double y_lo, y_hi;
+    double r2_eps;
+    const double *ops;   // DEVICE: [S (P x E) | D (E x P) | w (E)]
+    double *popt;        // [N][P]
+    double *r2;          // [N]
+    double *resid;       // nullable [N]
+};
+hipError_t polyls_launch(const PolylsKArgs &k, int num_cu, hipStream_t stream);
 // Kernel-argument block of the general lmdif kernel (lm_generic.hip).
 struct LmKArgs {
     const void *y;

@@ -6,7 +6,7 @@ BASELINE.json -- same names, arguments and error behaviour:
 * :func:`curve_fit`               (reference :755-870)   <- the seam: the per-voxel loop becomes ONE HIP launch
 * :class:`CurveFitter`            (reference :238-458)
 * :class:`MonoExponentialFit`     (reference :607-749)   <- init, fit and post-processing fused in the kernel
-* :func:`polyfit`, :class:`PolyFitter` (reference :461-604, 873-1013) for degree 1 (the log-linear fit)
+* :func:`polyfit`, :class:`PolyFitter` (reference :461-604, 873-1013): any degree, ``rcond`` / ``w`` / ``full`` / ``cov``
 * :func:`monoexponential`, :func:`biexponential` (reference :1016-1023)
 
 What runs where: everything per-voxel runs in ``libqmri_hip.so`` (include/qmri.h).  Python only does
@@ -228,25 +228,95 @@ def curve_fit(
     return out["popt"], out["r2"]
 
 
+def _polyfit_operator(x, deg, rcond, w):
+    """The linear map ``numpy.polyfit(x, Y, deg, rcond, w=w)`` applies to every column of Y, built the way numpy builds
+    it (numpy/lib/_polynomial_impl.py: weighted Vandermonde matrix, columns scaled to unit norm, lstsq with the rcond
+    cut-off on the singular values).  Returns dict(solve (P, E), design (E, P), rank, singular_values, rcond, vbase
+    (P, P) = inv(lhs^T lhs) of the scaled system un-scaled -- what ``cov=True`` multiplies with the residual variance)."""
+    order = int(deg) + 1
+    x = np.asarray(x, dtype=np.float64) + 0.0
+    if deg < 0:
+        raise ValueError("expected deg >= 0")
+    if x.ndim != 1:
+        raise TypeError("expected 1D vector for x")
+    if x.size == 0:
+        raise TypeError("expected non-empty vector for x")
+    if rcond is None:
+        rcond = len(x) * np.finfo(x.dtype).eps
+    design = np.vander(x, order)
+    lhs = design.copy()
+    if w is not None:
+        w = np.asarray(w, dtype=np.float64) + 0.0
+        if w.ndim != 1:
+            raise TypeError("expected a 1-d array for weights")
+        if w.shape[0] != x.shape[0]:
+            raise TypeError("expected w and y to have the same length")
+        lhs *= w[:, np.newaxis]
+    scale = np.sqrt((lhs * lhs).sum(axis=0))
+    lhs /= scale
+    u, sv, vt = np.linalg.svd(lhs, full_matrices=False)
+    keep = sv > rcond * sv[0]
+    rank = int(keep.sum())
+    inv_sv = np.where(keep, 1.0 / np.where(keep, sv, 1.0), 0.0)
+    pinv = (vt.T * inv_sv) @ u.T                      # (P, E): minimum-norm solution of the scaled system
+    solve = pinv / scale[:, np.newaxis]
+    if w is not None:
+        solve = solve * w[np.newaxis, :]
+    vbase = None
+    if rank == order:
+        vbase = np.linalg.inv(lhs.T @ lhs) / np.outer(scale, scale)
+    return dict(solve=solve, design=design, rank=rank, singular_values=sv, rcond=rcond, vbase=vbase, w=w)
+
+
 def polyfit(x, y, deg: int, rcond=None, full=False, w=None, cov=False, eps=1e-8, y_bounds=None,
             show_pbar=False, num_workers=None, chunksize: int = None):
-    """Least-squares polynomial fit of every column of ``y`` (reference :873-1013), degree 1 on the GPU.
+    """Least-squares polynomial fit of every column of ``y`` (reference :873-1013) on the GPU.
 
-    Returns ``popts`` (N, deg+1) in ``numpy.polyfit`` order (highest power first) and r2 (N,).
+    Returns ``popts`` (N, deg+1) in ``numpy.polyfit`` order (highest power first) and r2 (N,); with ``full=True`` also
+    ``residuals, rank, singular_values, rcond`` and with ``cov=True`` the covariance matrices ``V`` (deg+1, deg+1, N),
+    as ``numpy.polyfit`` returns them.  ``num_workers`` not None selects the reference's per-sequence rules (all-zero /
+    out-of-``y_bounds`` columns -> NaN, r2 0; :1095-1097); like the reference it cannot be combined with full / cov.
+    Degree 1 without numpy options runs on the closed-form kernel (linfit.hip); everything else is one (deg+1, E) linear
+    map per voxel on the general kernel, built on the host exactly as numpy builds it (:func:`_polyfit_operator`).
     """
-    if deg != 1 or full or cov or w is not None or rcond is not None:
-        raise NotImplementedError(
-            "polyfit: only deg=1 without weights/cov/full is implemented on the GPU "
-            "(the log-linear fit of the mono-exponential path); there is no CPU fallback.")
+    scatter_data = num_workers is not None
+    if (cov or full) and scatter_data:
+        raise ValueError("`cov` or `full` cannot be used with multiprocessing")
     x = np.asarray(x, dtype=np.float64).reshape(-1)
     y = np.asarray(y)
     if y.ndim == 1:
         y = y.reshape(y.shape + (1,))
     if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
         warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
-    out = _lib.linfit_host(x, _as_kernel_samples(y), r2_eps=eps, y_bounds=y_bounds,
-                           per_sequence_rules=num_workers is not None)
-    return out["popt"], out["r2"]
+    if x.shape[0] != y.shape[0]:
+        raise TypeError("expected x and y to have same length")
+    if deg == 1 and not (full or cov) and w is None and rcond is None:
+        out = _lib.linfit_host(x, _as_kernel_samples(y), r2_eps=eps, y_bounds=y_bounds, per_sequence_rules=scatter_data)
+        return out["popt"], out["r2"]
+
+    op = _polyfit_operator(x, deg, rcond, w)
+    order = int(deg) + 1
+    if op["rank"] != order and not full:
+        warnings.warn("Polyfit may be poorly conditioned", np.exceptions.RankWarning if hasattr(np, "exceptions") else RuntimeWarning,
+                      stacklevel=2)
+    out = _lib.polyls_host(_as_kernel_samples(y), op["solve"], op["design"], w=op["w"], per_sequence_rules=scatter_data,
+                           y_bounds=y_bounds if scatter_data else None, r2_eps=eps, want_resid=full or bool(cov))
+    popts, r_squared = out["popt"], out["r2"]
+    if full:
+        # numpy (lstsq) reports the residual sums only for a full-rank, over-determined system
+        resid = out["resid"] if (op["rank"] == order and x.shape[0] > order) else np.array([], dtype=np.float64)
+        return popts, r_squared, resid, op["rank"], op["singular_values"], op["rcond"]
+    if cov:
+        if op["vbase"] is None:
+            raise np.linalg.LinAlgError("Singular matrix")
+        if cov == "unscaled":
+            fac = 1  # numpy: Vbase[:, :, newaxis] * 1 -> shape (P, P, 1)
+        else:
+            if x.shape[0] <= order:
+                raise ValueError("the number of data points must exceed order to scale the covariance matrix")
+            fac = out["resid"] / (x.shape[0] - order)
+        return popts, r_squared, op["vbase"][:, :, np.newaxis] * fac
+    return popts, r_squared
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -600,7 +670,7 @@ class CurveFitter(_Fitter):
 
 
 class PolyFitter(_Fitter):
-    """Linear least squares polynomial fit per voxel (reference :461-604); degree 1 on the GPU."""
+    """Linear least squares polynomial fit per voxel (reference :461-604), any degree up to 7, on the GPU."""
 
     def __init__(self, deg: int, rcond: float = None, y_bounds=None, out_ufuncs=None,
                  out_bounds=None, r2_threshold="preferences", nan_to_num: float = None,

@@ -175,6 +175,41 @@ int qmri_linfit_device(const qmri_linfit_args *args); /* device pointers, asynch
 int qmri_linfit_host(const qmri_linfit_args *args);   /* host pointers, synchronous */
 
 /*
+ * ---- General polynomial least squares: numpy.polyfit(x, Y, deg, rcond, full, w, cov) per voxel -------------------
+ * Replaces the joint solve / per-sequence loop of the reference's polyfit() for any degree and for the numpy options the
+ * degree-1 kernel above does not take (/root/reference/dosma/core/fitting.py:873-1013; _polyfit :1076-1103).  The fit of
+ * every column is the SAME linear map of its samples, so the caller builds it once from x, w and rcond the way numpy does
+ * (weighted Vandermonde matrix, column scaling, SVD with the rcond cut-off) and hands over
+ *     solve  [P][E]   coefficients (highest power first) = solve @ y
+ *     design [E][P]   fitted values = design @ coefficients (the unweighted Vandermonde matrix; r2 as fitting.py:926-944)
+ *     w      [E]      weights of the residual sum of squares numpy reports with full=True / scales cov with (NULL = ones)
+ * Outputs: popt [N][P], r2 [N], resid [N] (nullable): sum_e (w_e (fit_e - y_e))^2.
+ */
+#define QMRI_POLY_MAX_PARAMS 8
+typedef struct qmri_polyls_args {
+    const void *y;        /* [E][ld] echo-major */
+    int32_t y_dtype;      /* qmri_dtype */
+    int32_t E;            /* P <= E <= QMRI_MAX_ECHOES */
+    int64_t N;
+    int64_t ld;
+    int32_t P;            /* deg + 1 <= QMRI_POLY_MAX_PARAMS */
+    int32_t skip_rules;   /* 1: all-zero / out-of-y_bounds columns -> (NaN..), r2 = 0 (the per-sequence branch, :1095-1097) */
+    const double *solve;  /* HOST [P][E] */
+    const double *design; /* HOST [E][P] */
+    const double *w;      /* HOST [E] or NULL */
+    int32_t use_y_bounds;
+    int32_t device;
+    double y_lo, y_hi;
+    double r2_eps;        /* 1e-8 */
+    double *popt;         /* [N][P] float64 */
+    double *r2;           /* [N] */
+    double *resid;        /* nullable [N] */
+    void *stream;
+} qmri_polyls_args;
+int qmri_polyls_device(const qmri_polyls_args *args); /* y / popt / r2 / resid device pointers, asynchronous */
+int qmri_polyls_host(const qmri_polyls_args *args);   /* host pointers, synchronous */
+
+/*
  * ---- General Levenberg-Marquardt fit (models other than the mono-exponential hot path) -------------------
  * Replaces curve_fit(func, x, y, p0, ftol=1e-5, maxfev=100) of the reference
  *   (/root/reference/dosma/core/fitting.py:755-870; per-voxel wrapper :1026-1073) for

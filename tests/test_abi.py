@@ -61,6 +61,9 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(qmri_region_stats_args), offsetof(qmri_region_stats_args, N),\n'
         "         offsetof(qmri_region_stats_args, label_keys), offsetof(qmri_region_stats_args, lo),\n"
         "         offsetof(qmri_region_stats_args, out), offsetof(qmri_region_stats_args, device));\n"
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(qmri_polyls_args), offsetof(qmri_polyls_args, P),\n'
+        "         offsetof(qmri_polyls_args, solve), offsetof(qmri_polyls_args, use_y_bounds),\n"
+        "         offsetof(qmri_polyls_args, popt), offsetof(qmri_polyls_args, stream));\n"
         "  return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -78,6 +81,8 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
     want += [ctypes.sizeof(M), M.x.offset, M.p0v.offset, M.ftol.offset, M.y_lo.offset, M.stream.offset]
     R = _lib.QmriRegionStatsArgs
     want += [ctypes.sizeof(R), R.N.offset, R.label_keys.offset, R.lo.offset, R.out.offset, R.device.offset]
+    Y = _lib.QmriPolylsArgs
+    want += [ctypes.sizeof(Y), Y.P.offset, Y.solve.offset, Y.use_y_bounds.offset, Y.popt.offset, Y.stream.offset]
     assert got == want
 
 

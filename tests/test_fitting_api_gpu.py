@@ -351,8 +351,64 @@ class TestPolyFitter:
         yhat = np.stack([ref[:, 0] * t + ref[:, 1] for t in x])
         r2_ref = 1 - ((yhat - y) ** 2).sum(0) / (((y - y.mean(0)) ** 2).sum(0) + 1e-8)
         assert np.allclose(r2, r2_ref, atol=1e-10)
-        with pytest.raises(NotImplementedError):
-            polyfit(x, y, 2)
+
+    def test_polyfit_args(self):
+        """reference TestPolyFit::test_polyfit_args (tests/core/test_fitting.py:165-183): the standard numpy.polyfit
+        arguments -- full=True and cov=True -- return what numpy returns; here also for degrees 2 and 3, weights, rcond
+        and the "unscaled" covariance, on noisy data (the reference's data is noise-free)."""
+        x = np.asarray([0.5, 1.0, 2.0, 4.0, 5.5, 7.0])
+        n = 1000
+        coef = RNG.standard_normal((4, n))
+        y = np.stack([coef[0] * t ** 3 + coef[1] * t ** 2 + coef[2] * t + coef[3] for t in x]) + 0.05 * RNG.standard_normal((6, n))
+        w = RNG.uniform(0.5, 2.0, 6)
+        for deg in (1, 2, 3):
+            for ww in (None, w):
+                popt_exp, res_exp, rank_exp, sv_exp, rcond_exp = np.polyfit(x, y, deg=deg, full=True, w=ww)
+                popt, r2, res, rank, sv, rcond = polyfit(x, y, deg=deg, full=True, w=ww)
+                assert np.allclose(popt, popt_exp.T, rtol=1e-9, atol=1e-11)
+                assert np.allclose(res, res_exp, rtol=1e-8) and rank == rank_exp
+                assert np.allclose(sv, sv_exp) and np.allclose(rcond, rcond_exp)
+                yhat = np.vander(x, deg + 1) @ popt_exp
+                r2_ref = 1 - ((yhat - y) ** 2).sum(0) / (((y - y.mean(0)) ** 2).sum(0) + 1e-8)
+                assert np.allclose(r2, r2_ref, atol=1e-9)
+                for cov in (True, "unscaled"):
+                    popt_exp, V_exp = np.polyfit(x, y, deg=deg, cov=cov, w=ww)
+                    popt, _, V = polyfit(x, y, deg=deg, cov=cov, w=ww)
+                    assert np.allclose(popt, popt_exp.T, rtol=1e-9, atol=1e-11)
+                    assert V.shape == V_exp.shape and np.allclose(V, V_exp, rtol=1e-8, atol=1e-14)
+        # a loose rcond cuts singular values: the minimum-norm solution numpy returns, and its rank
+        popt_exp, _, rank_exp, _, _ = np.polyfit(x, y, deg=3, full=True, rcond=0.05)
+        popt, _, _, rank, _, _ = polyfit(x, y, deg=3, full=True, rcond=0.05)
+        assert rank == rank_exp < 4 and np.allclose(popt, popt_exp.T, rtol=1e-8, atol=1e-10)
+        # single sequence, int16 samples, float32 samples
+        p1, _ = polyfit(x, y[:, 0], deg=2)
+        assert p1.shape == (1, 3) and np.allclose(p1[0], np.polyfit(x, y[:, 0], 2))
+        yi = np.round(y * 100).astype(np.int16)
+        assert np.allclose(polyfit(x, yi, deg=2)[0], np.polyfit(x, yi.astype(np.float64), 2).T, rtol=1e-9, atol=1e-9)
+        with pytest.raises(ValueError):
+            polyfit(x, y, deg=2, full=True, num_workers=0)  # reference :954-955
+        with pytest.raises(ValueError):
+            polyfit(x[:3], y[:3], deg=2, cov=True)  # numpy: the number of data points must exceed order
+
+    def test_per_sequence_rules_and_degree_2_fitter(self):
+        """num_workers not None = the reference's per-sequence branch (_polyfit, :1076-1103): all-zero and out-of-bounds
+        sequences -> NaN, r2 = 0; the joint branch fits them like any other column."""
+        x = np.asarray([1.0, 2.0, 3.0, 4.0, 6.0])
+        n = 300
+        c = RNG.standard_normal((3, n))
+        y = np.stack([c[0] * t * t + c[1] * t + c[2] for t in x])
+        y[:, :10] = 0.0
+        y[:, 10] = 1e4
+        with pytest.warns(UserWarning):
+            popt, r2 = polyfit(x, y, deg=2, num_workers=0, y_bounds=(-500, 500))
+        assert np.isnan(popt[:11]).all() and (r2[:11] == 0).all()
+        assert np.allclose(popt[11:], c[:, 11:].T, atol=1e-9) and np.allclose(r2[11:], 1.0)
+        popt_j, _ = polyfit(x, y, deg=2)  # joint: numpy fits the zero columns to zeros
+        assert np.allclose(popt_j[:10], 0.0) and np.allclose(popt_j[11:], c[:, 11:].T, atol=1e-9)
+        shape = (6, 5, 10)
+        vols = [MedicalVolume(v.reshape(shape), np.eye(4)) for v in y]
+        pm, rm = PolyFitter(deg=2, r2_threshold=None).fit(x, vols)
+        assert pm.shape == shape + (3,) and np.allclose(pm.volume.reshape(-1, 3)[11:], c[:, 11:].T, atol=1e-9)
 
     def test_basic_and_mask(self):
         x, y, a, b = gen_affine((10, 10, 20))

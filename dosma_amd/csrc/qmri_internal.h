@@ -189,6 +189,9 @@ hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
                            long long ldy, int yoff, hipStream_t stream);
 hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream);
+hipError_t maxpoolk_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y,
+                                 hipStream_t stream);
+hipError_t maxpoolk_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y, hipStream_t stream);  // bf16 layout
 hipError_t head_split_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC, float *logits,
                              unsigned char *mask, hipStream_t stream);
 hipError_t split_cast_launch(const void *x, long long npix, int C, void *y, int to_split, hipStream_t stream);

@@ -231,6 +231,20 @@ void pack_deconv_fused(const float *k, int Cin, int Cout, ConvLayer &L, std::vec
     }
 }
 
+// Conv2DTranspose 3x3 strides 3 SAME (the reference's branch for odd sizes, oaiunet2d.py:250-261): out[3 o + k] = in[o] w[k]
+// -- the kernel positions do not overlap, so output phase (ky, kx) is ONE tap at the input pixel itself: a 1x1 convolution
+// written to the output pixels (3 y + ky, 3 x + kx).  Keras kernel (kh, kw, Cout, Cin).
+void pack_deconv3_phase(const float *k, int Cin, int Cout, int ky, int kx, ConvLayer &L, std::vector<float> &wk) {
+    L.Cin = Cin;
+    L.Cout = Cout;
+    L.ntaps = 1;
+    L.dy[0] = L.dx[0] = 0;
+    wk.assign((size_t)Cout * Cin, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            wk[(size_t)co * Cin + (size_t)(ci / 32) * 32 + ci % 32] = k[(((size_t)ky * 3 + kx) * Cout + co) * Cin + ci];
+}
+
 qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int xoff, int B, int H, int W,
                           void *y, long long ldy, int yoff, int Ho, int Wo, int sy, int sx, int py, int px) {
     qmri::ConvKArgs k;
@@ -272,6 +286,9 @@ bool s3_width_ok(int W) { return W % 32 == 0 || W + 2 <= 50; }  // what conv_s3_
 struct Unet {
     int depth = 0, ncls = 0, H = 0, W = 0, maxB = 0, device = 0, split3 = 1, num_cu = 256;
     std::string trace;  // kernel family of every layer of the last forward batch (tests assert the dispatch)
+    std::vector<int> Hl, Wl;   // image size at level l
+    std::vector<int> fac;      // pooling / unpooling factor between level l and l + 1: 2, or 3 where the height is odd
+    std::vector<std::unique_ptr<ConvLayer>> updec3;  // [level * 9 + phase]: stride-3 transposed convolution, one tap per phase
     std::vector<int> nf;
     DevBuf c1_w, c1_b;  // first layer fp32: [9][nf0], [nf0]
     std::vector<std::unique_ptr<ConvLayer>> down1, down2, up1, up2;  // index by level
@@ -303,11 +320,20 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     if (d->base_features < 32 || d->base_features % 32)
         return ufail(QMRI_ERR_UNSUPPORTED, "base_features must be a multiple of 32 (MFMA K tile)");
     if (d->n_classes < 1 || d->n_classes > 4) return ufail(QMRI_ERR_UNSUPPORTED, "n_classes must be 1..4");
-    const int div = 1 << (d->depth - 1);
-    if (d->H <= 0 || d->W <= 0 || d->H % div || d->W % div)
-        return ufail(QMRI_ERR_UNSUPPORTED,
-                     "H and W must be divisible by %d: odd sizes take the reference's 3x3 pooling branch "
-                     "(oaiunet2d.py:236-241), which is not implemented", div);
+    if (d->H <= 0 || d->W <= 0) return ufail(QMRI_ERR_ARG, "H and W must be positive");
+    std::vector<int> Hl(1, d->H), Wl(1, d->W), fac;
+    for (int l = 0; l + 1 < d->depth; ++l) {
+        // oaiunet2d.py:234-243: MaxPooling2D((2, 2)) where the height is even, (3, 3) where it is odd -- on BOTH axes; the
+        // Concatenate with the (strides = pool size) Conv2DTranspose on the way up (:250-264) then needs both axes to divide
+        const int f = Hl[l] % 2 == 0 ? 2 : 3;
+        if (Hl[l] % f || Wl[l] % f)
+            return ufail(QMRI_ERR_ARG,
+                         "the reference's graph does not build for %d x %d slices: level %d is %d x %d and is pooled by %d "
+                         "(height even -> 2, odd -> 3; oaiunet2d.py:234-264), which must divide both", d->H, d->W, l, Hl[l], Wl[l], f);
+        fac.push_back(f);
+        Hl.push_back(Hl[l] / f);
+        Wl.push_back(Wl[l] / f);
+    }
     if (d->max_batch < 1) return ufail(QMRI_ERR_ARG, "max_batch must be >= 1");
     const int expect = d->depth * 8 + (d->depth - 1) * 10 + 2;
     if (d->n_tensors != expect || !d->tensors)
@@ -322,6 +348,9 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->ncls = d->n_classes;
     U->H = d->H;
     U->W = d->W;
+    U->Hl = Hl;
+    U->Wl = Wl;
+    U->fac = fac;
     U->maxB = d->max_batch;
     U->device = d->device;
     U->split3 = d->precision != 0;
@@ -353,6 +382,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->up2.resize(d->depth);
     U->updec.resize((size_t)d->depth);
     U->updec_ph.resize((size_t)d->depth * 4);
+    U->updec3.resize((size_t)d->depth * 9);
     {
         // QMRI_DECONV_SPLIT: bit mask of levels whose transposed convolution runs as four per-phase convolutions
         const char *e = std::getenv("QMRI_DECONV_SPLIT");
@@ -375,14 +405,14 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             U->down1[l]->relu = 1;
             pack_conv3x3(k1, Cin, C, *U->down1[l], wk);
             U_TRY(U->down1[l]->upload(wk, b1, nullptr, nullptr));
-            U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
+            U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
         }
         fold_bn(C, sc, sh);
         U->down2[l].reset(new ConvLayer);
         U->down2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->down2[l], wk);
         U_TRY(U->down2[l]->upload(wk, b2, &sc, &sh));
-        U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
+        U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
     }
     for (int l = d->depth - 2; l >= 0; --l) {
         const int C = U->nf[l], Cup = U->nf[l + 1];
@@ -394,7 +424,16 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             L->relu = 0;
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
-            U_TRY(L->upload_parity(wk, s3_width_ok(U->W >> (l + 1))));  // tiles of the INPUT grid (level l + 1)
+            U_TRY(L->upload_parity(wk, U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1])));  // tiles of the INPUT grid (level l + 1)
+            if (U->fac[l] == 3)
+                for (int ph = 0; ph < 9; ++ph) {
+                    auto &P = U->updec3[(size_t)l * 9 + ph];
+                    P.reset(new ConvLayer);
+                    P->relu = 0;
+                    pack_deconv3_phase(kd, Cup, C, ph / 3, ph % 3, *P, wk);
+                    U_TRY(P->upload(wk, bd, nullptr, nullptr));
+                    U_TRY(P->upload_parity(wk, false));
+                }
             if (U->split_levels >> l & 1u)
                 for (int ph = 0; ph < 4; ++ph) {
                     auto &P = U->updec_ph[(size_t)l * 4 + ph];
@@ -409,13 +448,13 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         U->up1[l]->relu = 1;
         pack_conv3x3(k1, 2 * C, C, *U->up1[l], wk);
         U_TRY(U->up1[l]->upload(wk, b1, nullptr, nullptr));
-        U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
+        U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
         fold_bn(C, sc, sh);
         U->up2[l].reset(new ConvLayer);
         U->up2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->up2[l], wk);
         U_TRY(U->up2[l]->upload(wk, b2, &sc, &sh));
-        U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->W >> l)));
+        U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
     }
     // head: Keras (1,1,C0,NC) == [C0][NC]
     U_TRY(U->head_w.alloc((size_t)U->nf[0] * U->ncls * 4));
@@ -431,7 +470,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U->pool.resize(d->depth);
     U->upout.resize(d->depth);
     for (int l = 0; l < d->depth; ++l) {
-        const long long pix = B * (U->H >> l) * (U->W >> l);
+        const long long pix = B * U->Hl[l] * U->Wl[l];
         U->tmp[l].reset(new DevBuf);
         U_TRY(U->tmp[l]->alloc((size_t)pix * U->nf[l] * 4));
         if (l < d->depth - 1) {
@@ -447,7 +486,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     }
     {
         const int l = d->depth - 1;
-        U_TRY(U->bottom.alloc((size_t)B * (U->H >> l) * (U->W >> l) * U->nf[l] * 4));
+        U_TRY(U->bottom.alloc((size_t)B * U->Hl[l] * U->Wl[l] * U->nf[l] * 4));
     }
     U_TRY(U->stats.alloc(4 * sizeof(double)));
     *handle = U.release();
@@ -531,7 +570,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
     const int D = U->depth;
     char nm[64];
     for (int l = 0; l < D; ++l) {
-        const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
+        const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l];
         void *t1 = U->tmp[l]->p;
         if (l == 0) {
             U_TRY(qmri::c1_split_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(), C, t1, C, 0, st));
@@ -544,7 +583,13 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
         }
         snprintf(nm, sizeof(nm), "down%d.conv2", l);
         int rc;
-        if (l < D - 1)  // block output (post-BN) = the skip = 2nd half of the level's concat buffer; pooled copy -> next level
+        if (l < D - 1 && U->fac[l] == 3) {  // odd height: MaxPooling2D((3, 3)) as its own kernel
+            rc = conv3x3_parity(U, nm, *U->down2[l], t1, C, 0, Bt, H, W, U->cat[l]->p, 2 * C, C, nullptr, 0, false, nullptr, nullptr, st);
+            if (rc == QMRI_OK) {
+                U_TRY(qmri::maxpoolk_split_launch(U->cat[l]->p, 2 * C, C, Bt, H, W, C, 3, U->pool[l + 1]->p, st));
+                U->trace += "pool3:split;";
+            }
+        } else if (l < D - 1)  // block output (post-BN) = the skip = 2nd half of the level's concat buffer; pooled copy -> next level
             rc = conv3x3_parity(U, nm, *U->down2[l], t1, C, 0, Bt, H, W, U->cat[l]->p, 2 * C, C, U->pool[l + 1]->p, C, false, nullptr,
                                 nullptr, st);
         else
@@ -553,20 +598,31 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
     }
     const void *src = U->bottom.p;
     for (int l = D - 2; l >= 0; --l) {
-        const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
+        const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l], Cup = U->nf[l + 1];
         void *cat = U->cat[l]->p;
-        {
+        if (U->fac[l] == 3) {
+            for (int ph = 0; ph < 9; ++ph) {
+                const ConvLayer &L = *U->updec3[(size_t)l * 9 + ph];
+                auto k = conv_args(L, src, Cup, 0, Bt, U->Hl[l + 1], U->Wl[l + 1], cat, 2 * C, 0, H, W, 3, 3, ph / 3, ph % 3);
+                k.w_hi = L.h_hi.as<__bf16>();
+                k.w_lo = L.h_lo.as<__bf16>();
+                k.winv = L.winv;
+                U_TRY(qmri::conv_igemm_launch(k, 1, st));
+            }
+            snprintf(nm, sizeof(nm), "up%d.deconv:igemm/stride3;", l);
+            U->trace += nm;
+        } else {
             const ConvLayer &L = *U->updec[(size_t)l];
             if (L.w_s3.p) {
                 qmri::ConvS3Args k;
                 std::memset(&k, 0, sizeof(k));
-                k.x = src; k.ldx = Cup; k.B = Bt; k.H = H / 2; k.W = W / 2;
+                k.x = src; k.ldx = Cup; k.B = Bt; k.H = U->Hl[l + 1]; k.W = U->Wl[l + 1];
                 k.Cin = L.Cin; k.Cout = L.Cout; k.deconv = 1;
                 k.w = L.w_s3.p; k.winv = L.winv;
                 k.bias = L.bias.as<float>();
                 k.y = cat; k.ldy = 2 * C; k.yoff = 0;
                 U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
-                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/bn%d;", l, (W / 2) % 32 ? "flat" : "2d", qmri::conv_s3_block_channels(L.Cout, 1));
+                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/bn%d;", l, U->Wl[l + 1] % 32 ? "flat" : "2d", qmri::conv_s3_block_channels(L.Cout, 1));
             } else {
                 auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
                 k.w_hi = L.h_hi.as<__bf16>();
@@ -600,7 +656,7 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     const int ab = 1;  // activations stored as bf16
     // ---- contracting path ----
     for (int l = 0; l < D; ++l) {
-        const int H = U->H >> l, W = U->W >> l, C = U->nf[l];
+        const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l];
         void *t1 = U->tmp[l]->p;
         // first layer computed inside conv2's halo stage (its feature map never goes to HBM): +1.5 %
         // end to end with a dedicated kernel instantiation; QMRI_FUSE_C1=0 turns it off
@@ -618,14 +674,18 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
             // block output (post-BN) goes to the 2nd half of this level's concat buffer = the skip
             void *cat = U->cat[l]->p;
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, cat, 2 * C, C, H, W, 1, 1, 0, 0);
-            k.pool_y = U->pool[l + 1]->p;  // MaxPooling2D fused into the producing epilogue
-            k.pool_ld = C;
+            if (U->fac[l] == 2) {
+                k.pool_y = U->pool[l + 1]->p;  // MaxPooling2D((2, 2)) fused into the producing epilogue
+                k.pool_ld = C;
+            }
             if (fuse_c1) {
                 k.c1_x = U->in.as<float>();
                 k.c1_w = U->c1_w.as<float>();
                 k.c1_b = U->c1_b.as<float>();
             }
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            if (U->fac[l] == 3)  // odd height: MaxPooling2D((3, 3)) (oaiunet2d.py:236-241) as its own kernel
+                U_TRY(qmri::maxpoolk_launch(cat, 2 * C, C, Bt, H, W, C, 3, U->pool[l + 1]->p, st));
         } else {
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, H, W, 1, 1, 0, 0);
             U_TRY(qmri::conv_igemm_launch(k, s3, st));
@@ -634,9 +694,15 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     // ---- expanding path ----
     const void *src = U->bottom.p;
     for (int l = D - 2; l >= 0; --l) {
-        const int H = U->H >> l, W = U->W >> l, C = U->nf[l], Cup = U->nf[l + 1];
+        const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l], Cup = U->nf[l + 1];
         void *cat = U->cat[l]->p;
-        if (U->split_levels >> l & 1u) {
+        if (U->fac[l] == 3) {
+            for (int ph = 0; ph < 9; ++ph) {
+                auto k = conv_args(*U->updec3[(size_t)l * 9 + ph], src, Cup, 0, Bt, U->Hl[l + 1], U->Wl[l + 1], cat, 2 * C, 0, H, W,
+                                   3, 3, ph / 3, ph % 3);
+                U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            }
+        } else if (U->split_levels >> l & 1u) {
             for (int ph = 0; ph < 4; ++ph) {
                 auto k = conv_args(*U->updec_ph[(size_t)l * 4 + ph], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2,
                                    ph >> 1, ph & 1);

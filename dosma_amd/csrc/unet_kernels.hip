@@ -808,6 +808,40 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const AT *__restrict__ x,
     }
 }
 
+// MaxPooling2D(k x k) on the bf16 layout, any k (the reference's 3 x 3 branch for odd heights, oaiunet2d.py:236-241)
+__global__ __launch_bounds__(256) void maxpoolk_bf16_kernel(const __bf16 *__restrict__ x, long long ldx, int xoff, int B, int H,
+                                                            int W, int C, int K, __bf16 *__restrict__ y) {
+    const int Ho = H / K, Wo = W / K, cg = C / 4;
+    const long long total = (long long)B * Ho * Wo * cg;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cg) * 4;
+        const long long p = idx / cg;
+        const int xo = (int)(p % Wo);
+        const long long t = p / Wo;
+        const int yo = (int)(t % Ho);
+        const long long b = t / Ho;
+        float o[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int q = 0; q < K * K; ++q) {
+            const __bf16 *src = x + ((b * H + K * yo + q / K) * W + K * xo + q % K) * ldx + xoff + c;
+            float v[4];
+            load4(src, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], v[i]);
+        }
+        store4(y + p * C + c, o);
+    }
+}
+hipError_t maxpoolk_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y, hipStream_t stream) {
+    const long long total = (long long)B * (H / K) * (W / K) * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpoolk_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const __bf16 *>(x), ldx, xoff,
+                       B, H, W, C, K, static_cast<__bf16 *>(y));
+    return hipGetLastError();
+}
+
 hipError_t maxpool2_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y,
                            int act_bf16, hipStream_t stream) {
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);

@@ -821,10 +821,10 @@ __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__
     }
 }
 
-// MaxPooling2D(2x2) (oaiunet2d.py:234-243), split in (pixel stride ldx, offset xoff) -> compact split out
+// MaxPooling2D(k x k), k = 2 or 3 (oaiunet2d.py:234-243), split in (pixel stride ldx, offset xoff) -> compact split out
 __global__ __launch_bounds__(256) void maxpool2_split_kernel(const unsigned char *__restrict__ x, long long ldx, int xoff, int B,
-                                                             int H, int W, int C, unsigned char *__restrict__ y) {
-    const int Ho = H / 2, Wo = W / 2, groups = C / 8;
+                                                             int H, int W, int C, int K, unsigned char *__restrict__ y) {
+    const int Ho = H / K, Wo = W / K, groups = C / 8;
     const long long total = (long long)B * Ho * Wo * groups;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(idx % groups);
@@ -833,11 +833,10 @@ __global__ __launch_bounds__(256) void maxpool2_split_kernel(const unsigned char
         const long long t = p / Wo;
         const int yo = (int)(t % Ho);
         const long long b = t / Ho;
-        const long long p00 = (b * H + 2 * yo) * W + 2 * xo;
+        const long long p00 = (b * H + K * yo) * W + K * xo;
         float m[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long pp = p00 + (q >> 1) * W + (q & 1);
+        for (int q = 0; q < K * K; ++q) {
+            const long long pp = p00 + (q / K) * W + (q % K);
             const unsigned char *src = x + (pp * ldx + xoff) * 4 + split_group_off(g);
             float v[8];
             join8(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 64), v);
@@ -924,11 +923,15 @@ hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, 
                        Cout, static_cast<unsigned char *>(y), ldy, yoff);
     return hipGetLastError();
 }
-hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream) {
+hipError_t maxpoolk_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y,
+                                 hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool2_split_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, stream,
-                       static_cast<const unsigned char *>(x), ldx, xoff, B, H, W, C, static_cast<unsigned char *>(y));
+    hipLaunchKernelGGL(maxpool2_split_kernel, dim3(grid_for((long long)B * (H / K) * (W / K) * (C / 8))), dim3(256), 0, stream,
+                       static_cast<const unsigned char *>(x), ldx, xoff, B, H, W, C, K, static_cast<unsigned char *>(y));
     return hipGetLastError();
+}
+hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream) {
+    return maxpoolk_split_launch(x, ldx, xoff, B, H, W, C, 2, y, stream);
 }
 hipError_t head_split_launch(const void *x, long long npix, int Cin, const float *w, const float *bias, int NC, float *logits,
                              unsigned char *mask, hipStream_t stream) {

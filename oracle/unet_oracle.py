@@ -11,7 +11,9 @@ documented TF/Keras layer semantics:
   layout ``(kh, kw, Cin, Cout)`` (oaiunet2d.py:213-226, 266-279);
 * ``BatchNormalization(axis=-1, momentum=0.95, epsilon=0.001)`` in inference mode, AFTER the second ReLU
   of each block: ``gamma * (x - mean) / sqrt(var + 1e-3) + beta`` (:228, :281); ``Dropout(0)`` = identity;
-* ``MaxPooling2D((2,2))`` stride 2 (:234-243; sizes here are even at every level);
+* ``MaxPooling2D((2,2))`` where the height is even, ``MaxPooling2D((3,3))`` where it is odd (:234-243; Keras' default
+  stride = pool size, padding "valid"), and on the way up ``Conv2DTranspose(..., strides=(3,3))`` for those levels
+  (:250-261): out[3o + k] = in[o] w[k];
 * ``Conv2DTranspose(C, (3,3), padding="same", strides=(2,2))`` (:259-261): the gradient of a SAME
   stride-2 3x3 convolution, i.e. ``out[i] = sum_{o,k: 2o+k=i} in[o] w[k]`` for i in [0, 2H), kernel layout
   ``(kh, kw, Cout, Cin)``; equals ``torch.conv_transpose2d(stride=2, padding=0)`` cropped to ``[:2H, :2W]``;
@@ -97,6 +99,19 @@ def make_weights(seed=0, nf=NF, n_classes=4, dtype=np.float32, bn="he"):
     return w
 
 
+def level_factors(H, W, depth=len(NF)):
+    """Pooling factor between level d and d + 1 (oaiunet2d.py:234-243): 2 where the height is even, 3 where it is odd --
+    applied to both axes; the graph only builds (Concatenate, :257-264) if the factor divides both."""
+    out = []
+    for d in range(depth - 1):
+        f = 2 if H % 2 == 0 else 3
+        if H % f or W % f:
+            raise ValueError(f"the graph does not build for this size: level {d} is {H} x {W}, pooled by {f}")
+        out.append(f)
+        H, W = H // f, W // f
+    return out
+
+
 def whiten_volume(x, eps=0.0):
     """seg_model.py:114-127 (numpy semantics: float32 input -> float32 pairwise mean/std)."""
     x = np.asarray(x)
@@ -128,14 +143,13 @@ def forward(w, x, nf=NF, dtype="float32", return_features=False):
         shift = t(w[f"{name}_beta"]) - t(w[f"{name}_mean"]) * scale
         return h * scale[None, :, None, None] + shift[None, :, None, None]
 
-    def deconv(h, name):
+    def deconv(h, name, stride):
         k = t(w[f"{name}_kernel"]).permute(3, 2, 0, 1)  # (kh,kw,Cout,Cin) -> (Cin,Cout,kh,kw)
-        out = F.conv_transpose2d(h, k, t(w[f"{name}_bias"]), stride=2, padding=0)
-        return out[:, :, : 2 * h.shape[2], : 2 * h.shape[3]]
+        out = F.conv_transpose2d(h, k, t(w[f"{name}_bias"]), stride=stride, padding=0)
+        return out[:, :, : stride * h.shape[2], : stride * h.shape[3]]
 
     h = t(x)[:, None, :, :]
-    if h.shape[2] % (2 ** (len(nf) - 1)) or h.shape[3] % (2 ** (len(nf) - 1)):
-        raise ValueError("H and W must be divisible by 32 (even size at every pooling level)")
+    factors = level_factors(h.shape[2], h.shape[3], len(nf))
     skips = []
     with torch.no_grad():
         for d in range(len(nf)):
@@ -145,9 +159,9 @@ def forward(w, x, nf=NF, dtype="float32", return_features=False):
             skips.append(h)
             feats[f"down{d}"] = h
             if d < len(nf) - 1:
-                h = F.max_pool2d(h, 2)
+                h = F.max_pool2d(h, factors[d])
         for d in range(len(nf) - 2, -1, -1):
-            up = deconv(h, f"up{d}_deconv")
+            up = deconv(h, f"up{d}_deconv", factors[d])
             feats[f"up{d}_deconv"] = up
             h = torch.cat([up, skips[d]], dim=1)
             h = conv3(h, f"up{d}_conv1")

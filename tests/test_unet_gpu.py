@@ -134,8 +134,30 @@ def test_whitening_and_batching_are_consistent(small_net):
     assert np.abs(la - lc).max() < 1e-3
     with pytest.raises(ValueError):
         a.forward_host(vol[:, :16, :])
-    with pytest.raises(NotImplementedError):
-        L.Unet2dEngine(tensors, 48, 48)  # not divisible by 32 -> reference's 3x3 pooling branch
+    with pytest.raises(ValueError):
+        L.Unet2dEngine(tensors, 50, 50)  # 50 -> 25 (odd) is pooled by 3, which does not divide it: the reference's graph
+                                         # does not build either (Concatenate of 24 x 24 with 25 x 25, oaiunet2d.py:257-264)
+    with pytest.raises(ValueError):
+        L.Unet2dEngine(tensors, 64, 63)  # even height -> (2, 2) pooling on both axes, odd width
+
+
+@pytest.mark.parametrize("precision,tol", [("fp16x3", 1e-3), ("bf16", 0.25)])
+def test_odd_sizes_take_the_3x3_pooling_branch(small_net, precision, tol):
+    """oaiunet2d.py:234-261: MaxPooling2D((3, 3)) / Conv2DTranspose(strides=(3, 3)) where the level's height is odd.
+    72 x 144: levels 72, 36, 18, 9 (odd: pooled by 3), 3 (odd: by 3), 1."""
+    w, tensors = small_net
+    assert uo.level_factors(72, 144) == [2, 2, 2, 3, 3]
+    rng = np.random.default_rng(72)
+    vol = (rng.standard_normal((3, 72, 144)) * 90 + 200).astype(np.float32)
+    eng = L.Unet2dEngine(tensors, 72, 144, max_batch=2, precision=precision)
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    ref = uo.forward(w, uo.whiten_volume(vol.astype(np.float64)).astype(np.float32), dtype="float64")
+    assert logits.shape == ref.shape == (3, 72, 144, 4)
+    assert np.abs(logits - ref).max() < tol, np.abs(logits - ref).max()
+    if precision == "fp16x3":
+        tr = eng.trace()
+        assert "pool3:split" in tr and any(t.startswith("up3.deconv:igemm/stride3") for t in tr)
+    eng.close()
 
 
 # ----------------------------------------------------------------------------- drop-in model classes

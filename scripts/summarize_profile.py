@@ -50,32 +50,40 @@ out = {
 json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
 out["valu_lane_instr_per_launch"] = sq["SQ_INSTS_VALU"] * out["lanes_active_per_valu_instr"]
 json.dump(out, open(f"profiles/{tag}_counters.json", "w"), indent=1)
+rnd = tag[:3]  # "r02"
+sha = open(os.path.join(src, "kernel_hash.txt")).read().strip() if os.path.exists(os.path.join(src, "kernel_hash.txt")) else None
 json.dump({"hbm_bytes_per_launch": rd + wr, "valu_lane_instr_per_launch": out["valu_lane_instr_per_launch"],
-           "source": f"profiles/{tag}_counters.json"},
-          open("profiles/r01_hbm_traffic.json", "w"), indent=1)
+           "source": f"profiles/{tag}_counters.json", "kernel_source_sha1": sha,
+           "pmc": {"valu_busy_frac": out["valu_busy_frac"], "lanes_active_per_valu_instr": out["lanes_active_per_valu_instr"],
+                   "traffic_over_algorithmic": out["traffic_over_algorithmic"]}},
+          open(f"profiles/{rnd}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 
-# ---- UNet2D leg ----
+# ---- UNet2D leg (parity mode fp16x3, one 160-slice volume per forward) ----
 import collections, subprocess
 ut = os.path.join(src, "unet_stats", "u_kernel_trace.csv")
 if os.path.exists(ut):
     shutil.copy(os.path.join(src, "unet_stats", "u_kernel_stats.csv"), f"profiles/{tag}_unet_kernel_stats.csv")
-    layers = subprocess.check_output([sys.executable, "scripts/unet_layers.py", ut]).decode()
+    layers = subprocess.check_output([sys.executable, "scripts/unet_trace.py", ut, "160"]).decode()
     open(f"profiles/{tag}_unet_layers.txt", "w").write(
-        "# rocprofv3 --kernel-trace of scripts/prof_unet.py (bf16, 384x384, batch 32): last forward batch\n" + layers)
+        "# rocprofv3 --kernel-trace of scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160: last forward\n"
+        "# TF = ALGORITHMIC flops of the layer / kernel time (the parity mode issues 3 MFMAs per product)\n" + layers)
     rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
-            if "conv_igemm" in r["Kernel_Name"]]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-27:]  # 12 + 15 conv_igemm dispatches per forward batch
+            if "conv_s3_kernel" in r["Kernel_Name"]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # 20 convolutions + 5 transposed convolutions per forward
     agg = collections.Counter()
     for r in rows:
         if int(r["Dispatch_Id"]) in ids:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
-    gui = agg["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
-    u = {"tag": tag, "workload": "UNet2D forward, 32 slices of 384x384, plain bf16 mode, 27 conv_igemm dispatches (one forward batch)",
+    cycles = agg["SQ_BUSY_CYCLES"] / 32  # summed over the 32 shader engines
+    u = {"tag": tag, "workload": "UNet2D forward, 160 slices of 384x384, parity mode fp16x3: the 25 conv_s3_kernel dispatches of one forward",
          "counters": dict(agg),
-         "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4),
-         "mfma_gflop_issued": agg["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / 1e9,
-         "mfma_gflop_algorithmic": 70.79 * 32,
+         "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
+         "mfma_instructions": agg["SQ_INSTS_MFMA"],
+         "mfma_gflop_issued": agg["SQ_INSTS_MFMA"] * 32768 / 1e9,
+         "mfma_gflop_algorithmic_x3": 3 * (70.79 - 2 * 0.042) * 160,
+         "lds_bank_conflict_over_active": agg["SQ_LDS_BANK_CONFLICT"] / max(agg["SQ_LDS_IDX_ACTIVE"], 1.0),
+         "wave_wait_frac": agg["SQ_WAIT_ANY"] / max(agg["SQ_WAVE_CYCLES"], 1.0),
          "unet2d_bench": bench.get("unet2d")}
     json.dump(u, open(f"profiles/{tag}_unet_counters.json", "w"), indent=1)
-    print(json.dumps({k: u[k] for k in ("MfmaUtil", "mfma_gflop_issued", "mfma_gflop_algorithmic")}))
+    print(json.dumps({k: u[k] for k in ("MfmaUtil", "mfma_gflop_issued", "mfma_gflop_algorithmic_x3", "wave_wait_frac")}))

@@ -3,6 +3,7 @@ ctypes mirrors of the argument structs have the C compiler's layout.  No compute
 import ctypes
 import os
 import re
+import shutil
 import subprocess
 import sys
 
@@ -147,3 +148,22 @@ def test_product_never_imports_the_oracle():
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules); "
             "assert 'scipy.optimize' not in sys.modules" % ROOT)
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_lds_dma_statements_own_m0(tmp_path):
+    """unet_s3.hip issues its LDS-DMA through inline asm that writes M0 (the LDS destination base) and does not restore
+    it.  That is only sound if nothing else in those kernels reads M0: check the generated gfx950 assembly -- every line
+    that mentions m0 must be one of the statement's own `s_mov_b32 m0, ...` writes."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "dosma_amd", "csrc", "unet_s3.hip")
+    out = tmp_path / "unet_s3.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "dosma_amd", "csrc"), src, "-o", str(out)])
+    lines = [ln.strip() for ln in out.read_text().splitlines()]
+    m0 = [ln for ln in lines if "m0" in ln.split(";")[0].replace("vm0", "") and not ln.startswith((".", ";", "//"))]
+    assert m0, "expected the DMA statements' M0 writes in the assembly"
+    others = [ln for ln in m0 if not ln.startswith("s_mov_b32 m0,")]
+    assert not others, others[:5]
+    assert sum("global_load_lds_dwordx4" in ln for ln in lines) >= 20

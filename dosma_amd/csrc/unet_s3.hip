@@ -97,7 +97,7 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 
 }  // namespace
 
-#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads | 16 no epilogue global stores | 32 no epilogue at all)
+#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads | 16 no epilogue global stores | 32 no epilogue at all | 64 no MFMAs)
 #define S3_DBG(bit) (A.dbg & (bit))
 #else
 #define S3_DBG(bit) 0
@@ -114,10 +114,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     constexpr int NPH = DECONV ? 4 : 1;
     static_assert(!DECONV || C::TPS == 1 || BN == 32, "");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int NJ = A.nj;                       // DMA instructions (16 pixels each) per halo plane
-    const int plane_bytes = NJ * 1024;
-    const int hbuf_bytes = 2 * plane_bytes;
-    unsigned char *halo = smem;                                  // [2 buffers][2 planes][NJ * 16 pixels][64 B]
+    const int NJ = A.nj;                       // DMA instructions (8 pixels x 128 B each) per halo buffer
+    const int hbuf_bytes = NJ * 1024;
+    unsigned char *halo = smem;                                  // [2 buffers][NJ * 8 pixels][hi 64 B | lo 64 B, swizzled]
     unsigned char *ring = smem + 2 * hbuf_bytes;                 // [kRing][2 planes][BN][64 B]
     int *outpix = reinterpret_cast<int *>(ring + kRing * C::SLOT_BYTES);  // [256] output pixel of a tile position, or -1
     float *prm = reinterpret_cast<float *>(outpix + kMTile);     // bias | scale | shift, [BN] each
@@ -134,23 +133,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     const int wsteps = steps / C::TPS;         // ring slots per work item
     const int ntiles = A.ntiles;
 
-    // ---- per-lane constants of the halo DMA: this wave's slot i is instruction j = wave + 8 i of the 2 NJ that
-    // make up a halo buffer: plane j / NJ, pixels (j % NJ) * 16 + lane / 4, LDS position lane & 3 holds source piece
-    // q = pos ^ ((hp >> 2) & 3) (the swizzle lives on the SOURCE address and on the ds_read address)
+    // ---- per-lane constants of the halo DMA: this wave's slot i is instruction j = wave + 8 i of the NJ that make up a
+    // halo buffer.  One instruction moves 8 WHOLE pixel-chunks: 8 consecutive lanes fetch the 128 contiguous bytes
+    // (64 B of hi parts, 64 B of lo parts) of one pixel -- full cache lines on the source side (half lines, fetched by
+    // two different instructions, cost the texture-address path twice).  LDS image: pixel p at p * 128; its eight
+    // 16-byte pieces (plane P in {hi, lo}, K piece q) sit at position ((P ^ (p >> 1 & 1)) * 4 + (q ^ (p >> 2 & 3))) -- the
+    // swizzle lives on the SOURCE address and on the ds_read address; with 2 pixels per 256-byte bank row the 16 lanes of
+    // a ds_read_b128 group (16 consecutive pixels, one plane, one q) then hit 16 different 16-byte slots.
     constexpr int kSlots = 6;
     int h_hp[kSlots], h_srcb[kSlots];  // halo pixel (or -1: beyond the halo), byte offset inside the pixel-chunk
     unsigned h_dst[kSlots];            // LDS byte offset of the instruction inside a halo buffer
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
         int j = wave + kWaves * i;
-        if (j >= 2 * NJ) j = wave;  // no such piece: repeat this wave's first one (same bytes to the same place)
-        const int plane = j >= NJ ? 1 : 0;
-        const int jj = j - plane * NJ;
-        const int hp = jj * 16 + (lane >> 2);
-        const int q = (lane & 3) ^ ((hp >> 2) & 3);
+        if (j >= NJ) j = wave;  // no such piece: repeat this wave's first one (same bytes to the same place)
+        const int hp = j * 8 + (lane >> 3);
+        const int p8 = lane & 7;
+        const int plane = (p8 >> 2) ^ ((hp >> 1) & 1);
+        const int q = (p8 & 3) ^ ((hp >> 2) & 3);
         h_hp[i] = hp < hpix ? hp : -1;
         h_srcb[i] = plane * 64 + q * 16;
-        h_dst[i] = (unsigned)(plane * plane_bytes + jj * 1024);
+        h_dst[i] = (unsigned)(j * 1024);
     }
 
     // ---- work item -> tile geometry ----
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int hp = abase[i] + shift;
-            const int off = hp * 64 + (((kk * 2 + khalf) ^ ((hp >> 2) & 3)) * 16);
+            const int off = hp * 128 + ((hp >> 1) & 1) * 64 + (((kk * 2 + khalf) ^ ((hp >> 2) & 3)) * 16);
             f.ah[i] = *reinterpret_cast<const f16x8 *>(hb + off);
-            f.al[i] = *reinterpret_cast<const f16x8 *>(hb + plane_bytes + off);
+            f.al[i] = *reinterpret_cast<const f16x8 *>(hb + (off ^ 64));
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     // a SIMD run in lock-step between barriers -- ~100 bookkeeping instructions in one lump idle the matrix pipe for both.
     auto mma_part = [&](const Frags &f, int part, auto phc) {
         constexpr int PH = decltype(phc)::value;
+        if (S3_DBG(64)) return;  // (experiments: no MFMAs)
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             if ((RT == 1 ? 0 : i) != part) continue;
@@ -627,10 +631,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                         if (half == 0 && yy < A.H) {
                             const long long pix = (long long)(t_b * A.H + yy) * A.W + t_x0 + px;
                             const int NC = A.head_nc;
-                            for (int c = 0; c < NC; ++c) {
-                                const float zz = z[c] + hw[128 + c];
-                                if (A.logits) A.logits[pix * NC + c] = zz;
-                                if (A.mask) A.mask[pix * NC + c] = zz > 0.f ? 1 : 0;
+                            float zz[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) zz[c] = z[c] + hw[128 + c];
+                            if (NC == 4) {  // one 16-byte store of the pixel's logits, one 4-byte store of its mask bytes
+                                if (A.logits) *reinterpret_cast<float4 *>(A.logits + pix * 4) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                                if (A.mask)
+                                    *reinterpret_cast<unsigned *>(A.mask + pix * 4) =
+                                        (zz[0] > 0.f ? 1u : 0u) | (zz[1] > 0.f ? 0x100u : 0u) | (zz[2] > 0.f ? 0x10000u : 0u) |
+                                        (zz[3] > 0.f ? 0x1000000u : 0u);
+                            } else {
+                                for (int c = 0; c < NC; ++c) {
+                                    if (A.logits) A.logits[pix * NC + c] = zz[c];
+                                    if (A.mask) A.mask[pix * NC + c] = zz[c] > 0.f ? 1 : 0;
+                                }
                             }
                         }
                     }
@@ -688,7 +702,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 
 static size_t s3_lds_bytes(int bn, int nj) {
     const size_t slot = (size_t)(bn == 32 ? 3 : 1) * bn * 128;  // S3Cfg::SLOT_BYTES
-    return (size_t)4 * nj * 1024 + (size_t)kRing * slot + kMTile * 4 + (size_t)3 * bn * 4 + (32 * 4 + 4) * 4;
+    return (size_t)2 * nj * 1024 + (size_t)kRing * slot + kMTile * 4 + (size_t)3 * bn * 4 + (32 * 4 + 4) * 4;
 }
 
 bool conv_s3_supported(const ConvS3Args &k) {
@@ -730,13 +744,13 @@ hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         const long long span = (long long)k.B * (k.H + 1) * k.P - k.P;  // flat positions [P, B (H+1) P)
         k.ntiles = (int)((span + kMTile - 1) / kMTile);
         k.tiles_x = k.tiles_y = 0;
-        k.nj = (kMTile + 2 * k.P + 2 + 15) / 16;
+        k.nj = (kMTile + 2 * k.P + 2 + 7) / 8;
     } else {
         k.P = kPitch2D;
         k.tiles_x = k.W / 32;
         k.tiles_y = (k.H + 7) / 8;
         k.ntiles = k.B * k.tiles_x * k.tiles_y;
-        k.nj = (kHalo2D + 15) / 16;
+        k.nj = (kHalo2D + 7) / 8;
     }
     k.nwork = k.nb * k.ntiles;
     static const int dbg = [] { const char *e = std::getenv("QMRI_S3_DBG"); return e ? std::atoi(e) : 0; }();

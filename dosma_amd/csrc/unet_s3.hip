@@ -263,15 +263,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     struct Frags {
         f16x8 ah[RT], al[RT], bh[CT], bl[CT];
     };
-    auto load_frags = [&](Frags &f, int buf, int slot, int wtap, int shift, int kk) {
+    // LDS byte offsets of the A fragments, per distinct tap shift: the halo geometry is tile-invariant (per-lane pixel
+    // abase[i] + shift), so the swizzled offsets are computed ONCE per kernel instead of per read (they were ~320 of the
+    // ~670 VALU instructions a 32-channel tile cost per wave).  Convolution: 9 shifts (dy, dx); transposed: 4 ({0,-1} x {0,-1}).
+    constexpr bool kUnrollChunk = DECONV || BN < 128;  // BN = 128 keeps a tap-row loop (register budget), see the main loop
+    constexpr int NSH = !kUnrollChunk ? 1 : (DECONV ? 4 : 9);
+    // (k-step 1 is the k-step-0 offset ^ 32: the piece index q = 2 kk + khalf only flips bit 1; the lo plane is ^ 64)
+    int aoff[NSH][RT];
+#pragma unroll
+    for (int t = 0; t < NSH; ++t) {
+        const int shift = DECONV ? -((t >> 1) * P) - (t & 1) : (t / 3 - 1) * P + (t % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int hp = abase[i] + shift;
+            aoff[t][i] = hp * 128 + ((hp >> 1) & 1) * 64 + ((khalf ^ ((hp >> 2) & 3)) * 16);
+        }
+    }
+    // shift id of tap t: convolution t itself; transposed convolution (packed phase order, pack_deconv_fused):
+    //   taps (dy, dx) = (0,0) (0,-1) (-1,0) (-1,-1) | (0,0) (-1,0) | (0,0) (0,-1) | (0,0)  ->  id = 2 * (dy == -1) + (dx == -1)
+#define S3_SHIFT_ID(T) (DECONV ? ((T) == 1 || (T) == 7 ? 1 : (T) == 2 || (T) == 5 ? 2 : (T) == 3 ? 3 : 0) : (T))
+    auto load_frags = [&](Frags &f, int buf, int slot, int wtap, const int (&ao)[RT], int kk) {
         const unsigned char *hb = halo + buf * hbuf_bytes;
         const unsigned char *wb = ring + slot * C::SLOT_BYTES + wtap * C::TAP_BYTES;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const int hp = abase[i] + shift;
-            const int off = hp * 128 + ((hp >> 1) & 1) * 64 + (((kk * 2 + khalf) ^ ((hp >> 2) & 3)) * 16);
-            f.ah[i] = *reinterpret_cast<const f16x8 *>(hb + off);
-            f.al[i] = *reinterpret_cast<const f16x8 *>(hb + (off ^ 64));
+            const int o = ao[i] ^ (kk * 32);
+            f.ah[i] = *reinterpret_cast<const f16x8 *>(hb + o);
+            f.al[i] = *reinterpret_cast<const f16x8 *>(hb + (o ^ 64));
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -361,9 +379,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     zero_acc();
-    int row = 0, chunk = 0, cbuf = 0, slot = 0;  // the step being computed: (chunk, tap row dy = row - 1, dx), ring slot
+    int chunk = 0, cbuf = 0, slot = 0;  // the chunk being computed, its halo buffer, the ring slot of the current step
+    int row = 0;                        // (row-loop variant only) tap row dy = row - 1 being computed
     Frags f0, f1;
-    load_frags(f0, cbuf, slot, 0, DECONV ? 0 : -P - 1, 0);  // operands of the very first tap (k-step 0)
+    load_frags(f0, cbuf, slot, 0, aoff[0], 0);  // operands of the very first tap (k-step 0)
 
     // MFMAs of one k-step in two halves (by row-tile), so that the requests and the address arithmetic of a step can be
     // placed BETWEEN them: an in-order wave hides ~6 ALU / DMA instructions behind each 32-cycle MFMA, and the two waves of
@@ -410,13 +429,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         S3_SGB(0x008, 1);                                                                                         \
     }
     // one step = one tap: DXI = dx + 1 is a compile-time constant, the tap row is not
-#define S3_STEP(ROW, DXI, SHIFT, PH, NBUF, NSHIFT)                                                                               \
+#define S3_STEP(ROW, DXI, AOC, AON, PH, NBUF)                                                                               \
     {                                                                                                             \
         constexpr bool kSlotStart = C::TPS == 1 || (DXI) == 0; /* first tap of a ring slot: request the slot 3 ahead */ \
         constexpr bool kSlotEnd = C::TPS == 1 || (DXI) == 2;   /* last tap of a ring slot: wait + barrier */      \
         constexpr int kWTap = C::TPS == 3 ? (DXI) : 0;                                                            \
         using PhC_ = std::integral_constant<int, (PH)>;                                                           \
-        if (!S3_DBG(8)) load_frags(f1, cbuf, slot, kWTap, (SHIFT), 1);                                            \
+        if (!S3_DBG(8)) load_frags(f1, cbuf, slot, kWTap, (AOC), 1);                            \
         mma_part(f0, 0, PhC_{});                                                                                  \
         mma_part(f0, 1, PhC_{});                                                                                  \
         if constexpr (kSlotStart) { /* weights of the slot 3 ahead -> ring slot w_slot */                         \
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         }                                                                                                         \
         const int n_slot_ = kSlotEnd ? (slot + 1) & (kRing - 1) : slot;                                           \
         constexpr int kNextWTap = C::TPS == 3 ? ((DXI) + 1) % 3 : 0;                                              \
-        if (!S3_DBG(8)) load_frags(f0, (NBUF), n_slot_, kNextWTap, (NSHIFT), 0); /* operands of the next step (k-step 0) */ \
+        if (!S3_DBG(8)) load_frags(f0, (NBUF), n_slot_, kNextWTap, (AON), 0); /* next step, k-step 0 */ \
         mma_part(f1, 0, PhC_{});                                                                                  \
         mma_part(f1, 1, PhC_{});                                                                                  \
         S3_PIPE()                                                                                                 \
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 
     while (true) {
         // ---- one tap row (dy = row - 1) of one 32-channel chunk: three steps ----
-        if ((DECONV || row == 0) && !req_tile_ready && !S3_DBG(4)) {
+        if ((kUnrollChunk || row == 0) && !req_tile_ready && !S3_DBG(4)) {
             // first request for a new tile: where do its halo pixels come from
             int nb_, b_, y0_, x0_, f0_;
             const int rw = req_work < nwork ? req_work : work;  // past the end: re-request this tile (harmless)
@@ -487,45 +506,62 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             set_halo_sources(b_, y0_, x0_, f0_);
             req_tile_ready = true;
         }
-        int n_row, n_chunk = chunk, n_cbuf = cbuf;
+        int n_row, n_chunk, n_cbuf;
         bool last;
-        if constexpr (!DECONV) {
-            const int srow = (row - 1) * P;
-            S3_STEP(row, 0, srow - 1, 0, cbuf, srow + 0)
-            S3_STEP(row, 1, srow + 0, 0, cbuf, srow + 1)
+        if constexpr (kUnrollChunk) {
+            // one whole 32-channel chunk, taps unrolled (tap-dependent addresses, halo pieces and -- for the transposed
+            // convolution -- the accumulator set are compile-time):
+            //   convolution           t = 3 (dy + 1) + (dx + 1), one accumulator set
+            //   transposed (phase)    (0,0,0) (0,-1,0) (-1,0,0) (-1,-1,0) | (0,0,1) (-1,0,1) | (0,0,2) (0,-1,2) | (0,0,3)
+            n_row = 0;
+            n_chunk = chunk + 1;
+            n_cbuf = cbuf ^ 1;
+            last = n_chunk == A.chunks;
+#define S3_T(T, PH, NBUF) S3_STEP((T) / 3, (T) % 3, aoff[S3_SHIFT_ID(T)], aoff[S3_SHIFT_ID(((T) + 1) % 9)], PH, NBUF)
+            S3_T(0, 0, cbuf)
+            S3_T(1, 0, cbuf)
+            S3_T(2, 0, cbuf)
+            S3_WRAP()
+            S3_T(3, 0, cbuf)
+            S3_T(4, DECONV ? 1 : 0, cbuf)
+            S3_T(5, DECONV ? 1 : 0, cbuf)
+            S3_WRAP()
+            S3_T(6, DECONV ? 2 : 0, cbuf)
+            S3_T(7, DECONV ? 2 : 0, cbuf)
+            S3_T(8, DECONV ? 3 : 0, n_cbuf)
+#undef S3_T
+        } else {
+            // 128-channel blocks: one tap ROW per trip (the unrolled chunk needs > 256 VGPRs there); the row's three
+            // A offsets (+ the first of the next row) are recomputed per row -- 24 MFMAs per tap amortise it
             n_row = row + 1;
+            n_chunk = chunk;
+            n_cbuf = cbuf;
             if (n_row == 3) {
                 n_row = 0;
                 n_chunk = chunk + 1;
                 n_cbuf = cbuf ^ 1;
             }
             last = n_row == 0 && n_chunk == A.chunks;
-            S3_STEP(row, 2, srow + 1, 0, n_cbuf, (n_row - 1) * P - 1)
-        } else {
-            // one whole 32-channel chunk: taps t = 0..8 = (dy, dx, phase):
-            //   (0,0,0) (0,-1,0) (-1,0,0) (-1,-1,0) | (0,0,1) (-1,0,1) | (0,0,2) (0,-1,2) | (0,0,3)
-            n_row = 0;
-            n_chunk = chunk + 1;
-            n_cbuf = cbuf ^ 1;
-            last = n_chunk == A.chunks;
-            S3_STEP(0, 0, 0, 0, cbuf, -1)
-            S3_STEP(0, 1, -1, 0, cbuf, -P)
-            S3_STEP(0, 2, -P, 0, cbuf, -P - 1)
-            S3_WRAP()
-            S3_STEP(1, 0, -P - 1, 0, cbuf, 0)
-            S3_STEP(1, 1, 0, 1, cbuf, -P)
-            S3_STEP(1, 2, -P, 1, cbuf, 0)
-            S3_WRAP()
-            S3_STEP(2, 0, 0, 2, cbuf, -1)
-            S3_STEP(2, 1, -1, 2, cbuf, 0)
-            S3_STEP(2, 2, 0, 3, n_cbuf, 0)
+            int arow[4][RT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int shift = t < 3 ? (row - 1) * P + (t - 1) : (n_row - 1) * P - 1;
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const int hp = abase[i] + shift;
+                    arow[t][i] = hp * 128 + ((hp >> 1) & 1) * 64 + ((khalf ^ ((hp >> 2) & 3)) * 16);
+                }
+            }
+            S3_STEP(row, 0, arow[0], arow[1], 0, cbuf)
+            S3_STEP(row, 1, arow[1], arow[2], 0, cbuf)
+            S3_STEP(row, 2, arow[2], arow[3], 0, n_cbuf)
+            row = n_row;
         }
         S3_WRAP()
         if (n_row == 0) {  // the chunk is finished: the request pointer moves on to the chunk after the next
             advance_req();
             if (req_chunk == 0) req_tile_ready = false;
         }
-        row = n_row;
         chunk = n_chunk;
         cbuf = n_cbuf;
         if (!last) continue;

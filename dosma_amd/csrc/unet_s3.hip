@@ -834,40 +834,67 @@ __device__ __forceinline__ void join8(const uint4 &hi, const uint4 &lo, float (&
 __device__ __forceinline__ long long split_group_off(int g) { return (long long)(g >> 2) * 128 + (g & 3) * 16; }
 
 // Conv2D(C, 3x3, SAME) on ONE input channel + bias + ReLU (oaiunet2d.py:213-219 on the image), fp32 VALU, split output
+// A thread owns 8 output channels of one image column over a strip of kC1Rows rows: its 72 weights stay in registers and the
+// 3x3 window slides down (3 loads per pixel instead of 9 + 18 weight loads -- the first version was load-issue bound).
+constexpr int kC1Rows = 16;
 __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__ x, int B, int H, int W,
                                                        const float *__restrict__ w /*[9][C]*/, const float *__restrict__ bias,
                                                        int Cout, unsigned char *__restrict__ y, long long ldy, int yoff) {
     const int groups = Cout / 8;
-    const long long total = (long long)B * H * W * groups;
+    const int strips = (H + kC1Rows - 1) / kC1Rows;
+    const long long total = (long long)B * strips * W * groups;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(idx % groups);
-        const long long pix = idx / groups;
-        const int xw = (int)(pix % W);
-        const long long t = pix / W;
-        const int yh = (int)(t % H);
-        const float *img = x + (t / H) * (long long)H * W;
-        float acc[8];
+        long long t = idx / groups;
+        const int xw = (int)(t % W);
+        t /= W;
+        const int y0 = (int)(t % strips) * kC1Rows;
+        const long long b = t / strips;
+        const float *img = x + b * (long long)H * W;
+        float wt[9][8], bs[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = bias[g * 8 + c];
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+            for (int c = 0; c < 8; ++c) wt[k][c] = w[k * Cout + g * 8 + c];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int yy = yh + kh - 1, xx = xw + kw - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                    const float v = img[(long long)yy * W + xx];
-                    const float *wt = w + (kh * 3 + kw) * Cout + g * 8;
+        for (int c = 0; c < 8; ++c) bs[c] = bias[g * 8 + c];
+        const bool xl = xw > 0, xr = xw + 1 < W;
+        auto load_row = [&](int yy, float (&r)[3]) {
+            const bool in = yy >= 0 && yy < H;
+            const float *row = img + (long long)yy * W + xw;
+            r[0] = in && xl ? row[-1] : 0.f;
+            r[1] = in ? row[0] : 0.f;
+            r[2] = in && xr ? row[1] : 0.f;
+        };
+        float win[3][3];
+        load_row(y0 - 1, win[0]);
+        load_row(y0, win[1]);
+#pragma unroll 4
+        for (int r = 0; r < kC1Rows; ++r) {
+            const int yh = y0 + r;
+            if (yh >= H) break;
+            load_row(yh + 1, win[2]);
+            float acc[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
-                }
+            for (int c = 0; c < 8; ++c) acc[c] = bs[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(win[k / 3][k % 3], wt[k][c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
+            uint4 hi, lo;
+            split8(acc, hi, lo);
+            const long long pix = (b * H + yh) * W + xw;
+            unsigned char *dst = y + (pix * ldy + yoff) * 4 + split_group_off(g);
+            *reinterpret_cast<uint4 *>(dst) = hi;
+            *reinterpret_cast<uint4 *>(dst + 64) = lo;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                win[0][q] = win[1][q];
+                win[1][q] = win[2][q];
             }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
-        uint4 hi, lo;
-        split8(acc, hi, lo);
-        unsigned char *dst = y + (pix * ldy + yoff) * 4 + split_group_off(g);
-        *reinterpret_cast<uint4 *>(dst) = hi;
-        *reinterpret_cast<uint4 *>(dst + 64) = lo;
+        }
     }
 }
 
@@ -969,7 +996,7 @@ unsigned grid_for(long long total) {
 hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
                            long long ldy, int yoff, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(c1_split_kernel, dim3(grid_for((long long)B * H * W * (Cout / 8))), dim3(256), 0, stream, x, B, H, W, w, bias,
+    hipLaunchKernelGGL(c1_split_kernel, dim3(grid_for((long long)B * ((H + kC1Rows - 1) / kC1Rows) * W * (Cout / 8))), dim3(256), 0, stream, x, B, H, W, w, bias,
                        Cout, static_cast<unsigned char *>(y), ldy, yoff);
     return hipGetLastError();
 }

@@ -768,14 +768,12 @@ int qmri_lmfit_device(const qmri_lmfit_args *a, int32_t *nonfinite_flag) {
     k.info = a->info;
     k.nfev = a->nfev;
     for (int i = 0; i < a->E; ++i) k.x[i] = a->x[i];
-    AsyncScratch flag_scratch;  // per-launch flag word when the caller does not collect it
-    if (nonfinite_flag) {
-        k.nonfinite = nonfinite_flag;
-    } else {
-        HIP_TRY(flag_scratch.alloc(64, stream));
-        k.nonfinite = static_cast<int *>(flag_scratch.p);
-    }
-    HIP_TRY(qmri::lm_generic_launch(k, a->model, ctx->num_cu, stream));
+    AsyncScratch scratch;  // per-launch: [0, 8) the pull counter, [8, 12) the flag word when the caller does not collect it
+    HIP_TRY(scratch.alloc(64, stream));
+    HIP_TRY(hipMemsetAsync(scratch.p, 0, 16, stream));
+    unsigned long long *counter = static_cast<unsigned long long *>(scratch.p);
+    k.nonfinite = nonfinite_flag ? nonfinite_flag : reinterpret_cast<int *>(counter + 1);
+    HIP_TRY(qmri::lm_generic_launch(k, a->model, ctx->num_cu, counter, stream));
     return QMRI_OK;
 }
 

@@ -107,7 +107,8 @@ struct LmKArgs {
     double x[QMRI_MAX_ECHOES];
 };
 int lm_generic_nparams(int model);
-hipError_t lm_generic_launch(const LmKArgs &k, int model, int num_cu, hipStream_t stream);
+// counter: one zeroed 8-byte device word per launch (E <= 12: the pulling kernel), or nullptr (general-E kernel)
+hipError_t lm_generic_launch(const LmKArgs &k, int model, int num_cu, unsigned long long *counter, hipStream_t stream);
 // masked launches: classify tiles, fill the empty ones, list the others (list: [tiles] u32, count: 1 u32, zeroed)
 hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu, hipStream_t stream);
 hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);

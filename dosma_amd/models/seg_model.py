@@ -59,9 +59,10 @@ class HipSegModel(SegModel):
     precision = "fp16x3"
     #: slices per pass through the network on the GPU.  The reference's ``batch_size`` (Keras ``predict(batch_size=)``,
     #: ``preferences.segmentation_batch_size`` = 16) only chunks the work -- results do not depend on it -- and is kept
-    #: as an attribute for compatibility; the engine uses the larger of the two (16 -> 64: +30 % throughput; the
-    #: activation buffers of 64 slices of 384 x 384 are ~2.5 GB in bf16, ~5 GB in the parity mode)
-    gpu_batch = 64
+    #: as an attribute for compatibility; the engine uses the larger of the two.  The persistent convolution kernels want
+    #: the whole volume in one pass (the 12 x 12 level of 16 slices is 10 tiles for 256 CUs): 160 slices of 384 x 384 need
+    #: ~25 GB of activation buffers in the parity mode, ~12 GB in bf16, of the 288 GB
+    gpu_batch = 160
     device = None  # None: dosma_amd.set_default_device / DOSMA_AMD_DEVICE (0)
 
     def build_model(self, input_shape, weights_path=None):

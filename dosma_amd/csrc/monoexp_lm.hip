@@ -41,6 +41,10 @@ constexpr int kSub = 256;        // voxels per tile (per wave): 4 per lane -> 16
 #ifndef QMRI_REFILL
 #define QMRI_REFILL 16
 #endif
+#ifndef QMRI_SMALL_E_BLOCKS
+#define QMRI_SMALL_E_BLOCKS 2  // blocks of 4 waves per CU the EMAX <= 8 variants are register-bounded for (measured with 3:
+                               // 168 VGPRs + 102 spilled to scratch, 1.17e9 instead of 1.89e9 voxel-fits/s)
+#endif
 #ifndef QMRI_MIN_WAVES
 #define QMRI_MIN_WAVES 1
 #endif
@@ -441,7 +445,7 @@ __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
 // losing the second wave.  EMAX = 16: 14.0 ms instead of 16.8 for the exact-size variant (148 spills), but 52.9 instead
 // of 18.8 for the partial one (340 spills); EMAX = 32 does not fit either way.
 template <int EMAX, bool FULL, typename LT>
-__global__ __launch_bounds__(256, (EMAX <= 8 || (EMAX <= 16 && FULL)) ? 2 : QMRI_MIN_WAVES) void monoexp_lm_kernel(
+__global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16 && FULL) ? 2 : QMRI_MIN_WAVES)) void monoexp_lm_kernel(
     const FitKArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;

@@ -113,6 +113,25 @@ hipError_t lm_generic_launch(const LmKArgs &k, int model, int num_cu, unsigned l
 hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu, hipStream_t stream);
 hipError_t linfit_launch(const LinfitKArgs &k, int num_cu, hipStream_t stream);
 
+// First encoder block of the parity-mode U-Net in one kernel (unet_enc0.hip): image -> skip tensor + pooled map.
+struct Enc0Args {
+    const float *x;        // [B][H][W] input slices (whitened where the model asks for it)
+    int B, H, W;           // H % 8 == 0, W % 32 == 0
+    const void *c1_img;    // first convolution as an MFMA A operand: [64 lanes][hi 8 | lo 8] fp16 of 2^k * (taps 0..8, bias, 0...)
+    float c1_winv;         // 2^-k
+    const void *w2;        // second convolution: conv_s3_kernel's weight image for 32 -> 32 channels (9 x 4096 B)
+    float winv2;
+    const float *bias2, *scale2, *shift2;  // [32]: bias, BatchNorm scale / shift
+    void *y;               // skip tensor (split layout), pixel stride ldy channels, channel offset yoff
+    long long ldy;
+    int yoff;
+    void *pool_y;          // pooled map (split layout), pixel stride pool_ld channels
+    int pool_ld;
+};
+size_t enc0_lds_bytes();
+bool enc0_supported(const Enc0Args &k);
+hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream);
+
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).
 struct ConvKArgs {
     const void *x;       // NHWC input (fp32, or bf16 in plain-bf16 mode), pixel stride ldx (elements), channel offset xoff

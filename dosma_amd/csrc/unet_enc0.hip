@@ -1,0 +1,285 @@
+// unet_enc0.hip -- the first encoder block of the parity-mode ("fp16x3") U-Net as ONE kernel, gfx950 only:
+//
+//     Conv2D(32, 3x3) on the single-channel image + ReLU -> Conv2D(32, 3x3) + ReLU -> BatchNorm -> [skip] -> MaxPooling2D(2x2)
+//     /root/reference/dosma/models/oaiunet2d.py:213-243 (level 0 of the contracting path)
+//
+// Why: at 384 x 384 x 160 slices a 32-channel split feature map is 3 GB.  As three kernels (first convolution, conv_s3_kernel,
+// pooling) the block moved 12.75 GB through HBM -- the first feature map written and read back, the block output read back
+// for pooling -- at 3.3-3.9 TB/s: it was bound by that traffic, not by the matrix pipes.  Here the first feature map exists only
+// as the halo image of the second convolution in LDS and the pooled map is made from the staged output tile: 0.1 GB in
+// (the image), 3.75 GB out.
+//
+// One persistent block of 8 waves per CU; a tile is 8 rows x 32 columns of one slice.  Per tile:
+//   patch   12 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)            -> LDS
+//   conv 1  on the 10 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
+//           split into fp16 hi + lo parts like everywhere else (three MFMAs per 32 pixels); ReLU; split; halo image
+//           (zero outside the slice: that is conv 2's SAME padding)
+//   conv 2  nine taps x two k-steps x (hi hi + hi lo + lo hi); its 36 KB of weights are LDS-RESIDENT (no ring, no
+//           request stream, no counted waits); A = weights, B = pixels, so that a lane of the accumulator tile holds
+//           ONE pixel and a register one channel
+//   out     bias, ReLU, BatchNorm affine, split; [pixel][hi 64 B | lo 64 B] image through a wave window in LDS (eight 8-byte
+//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 0-3
+//           pool the staged tile 2 x 2 and store the next level's input
+#include <hip/hip_runtime.h>
+
+#include "qmri_internal.h"
+
+namespace qmri {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kPitch = 34;              // halo row pitch of the 8 x 32 tile
+constexpr int kHalo = 10 * kPitch;      // 340 halo pixels
+constexpr int kHaloBytes = 11 * 32 * 128;  // eleven 32-pixel groups (the last one is partly beyond the halo)
+constexpr int kPatchW = 36, kPatchH = 12;
+constexpr int kWBytes = 9 * 4096;       // conv 2 weights: [tap][plane][32 channels][64 B], conv_s3_kernel's slot image
+constexpr int kStageBytes = kWaves * 4096;
+
+// LDS position of the 16-byte piece (plane, q = channels 8 q .. 8 q + 7) of halo pixel hp
+__device__ __forceinline__ int halo_off(int hp, int plane, int q) {
+    return hp * 128 + (((plane ^ ((hp >> 1) & 1)) * 4 + (q ^ ((hp >> 2) & 3))) * 16);
+}
+// staging window of a wave: pixel px (0..31), piece p8 = plane * 4 + q at position p8 ^ ((px >> 1) & 7)
+__device__ __forceinline__ int stage_off(int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); }
+
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// LDS traffic only: the skip / pooled stores of a tile stay in flight across the barriers (__syncthreads would drain them)
+#define S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *wlds = smem;                         // conv 2 weights
+    unsigned char *halo = wlds + kWBytes;               // conv 1 output on the halo
+    unsigned char *stage = halo + kHaloBytes;           // output tile, one 4 KB window per wave
+    float *patch = reinterpret_cast<float *>(stage + kStageBytes);  // [12][36] input pixels
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgrp = lane >> 5;
+
+    // ---- once per block: resident weights, per-lane operand constants ----
+    for (int i = tid; i < kWBytes / 16; i += kThreads)
+        reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w2)[i];
+    // conv 1 as a 32 (channels) x 16 (taps) A operand: lane = (channel l31, taps 8 kgrp ..), hi and lo parts
+    const f16x8 c1h = reinterpret_cast<const f16x8 *>(A.c1_img)[lane * 2];
+    const f16x8 c1l = reinterpret_cast<const f16x8 *>(A.c1_img)[lane * 2 + 1];
+    // epilogue parameters of this lane's 16 channels: register e <-> channel (e & 3) + 8 (e >> 2) + 4 kgrp
+    float pb[16], ps[16], pt[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ch = (e & 3) + 8 * (e >> 2) + 4 * kgrp;
+        pb[e] = A.bias2[ch];
+        ps[e] = A.scale2[ch];
+        pt[e] = A.shift2[ch];
+    }
+    // conv 2, A operand (weights): byte offset of this lane's piece inside a tap image, k-step 0 (k-step 1: ^ 32; lo: + 2048)
+    const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
+    // conv 2, B operand (pixels): halo pixel of this lane's output pixel for tap (0, 0): row wave, column l31
+    const int hp0 = (wave + 1) * kPitch + l31 + 1;
+    int boff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
+
+    const int tiles_x = A.W / 32, tiles_y = A.H / 8;
+    const int per_img = tiles_x * tiles_y;
+    const int ntiles = A.B * per_img;
+    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / tiles_x;
+        y0 = ty * 8;
+        x0 = (r - ty * tiles_x) * 32;
+    };
+    // this thread's pixel of the 12 x 36 input patch of a tile (threads 0 .. 431), zero outside the slice
+    auto load_patch = [&](int t) -> float {
+        if (t >= ntiles || tid >= kPatchW * kPatchH) return 0.f;
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+        const int r = tid / kPatchW, c = tid - r * kPatchW;
+        const int yy = y0 - 2 + r, xx = x0 - 2 + c;
+        if ((unsigned)yy >= (unsigned)A.H || (unsigned)xx >= (unsigned)A.W) return 0.f;
+        return A.x[((long long)b * A.H + yy) * A.W + xx];
+    };
+    // conv 1 on one group of 32 consecutive halo pixels -> halo image
+    auto conv1_group = [&](int g, int y0, int x0) {
+        const int hp = g * 32 + l31;
+        const int r = hp / kPitch, c = hp - r * kPitch;  // halo row / column (pixels beyond the halo: r = 10, harmless)
+        float tp[8];
+        if (kgrp == 0) {  // taps 0..7: (r + dy, c + dx) of the patch, whose origin is (y0 - 2, x0 - 2)
+            const float *p = patch + r * kPatchW + c;
+            tp[0] = p[0]; tp[1] = p[1]; tp[2] = p[2];
+            tp[3] = p[kPatchW]; tp[4] = p[kPatchW + 1]; tp[5] = p[kPatchW + 2];
+            tp[6] = p[2 * kPatchW]; tp[7] = p[2 * kPatchW + 1];
+        } else {          // tap 8, the constant-one tap of the bias, six zeros
+            tp[0] = r < 10 ? patch[(r + 2) * kPatchW + c + 2] : 0.f;
+            tp[1] = 1.f;
+#pragma unroll
+            for (int i = 2; i < 8; ++i) tp[i] = 0.f;
+        }
+        unsigned bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2(tp[2 * i], tp[2 * i + 1], bh[i], bl[i]);
+        const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+        const f16x8 xl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1l, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1h, xh, acc, 0, 0, 0);
+        // this lane: halo pixel hp, channels (e & 3) + 8 (e >> 2) + 4 kgrp
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool inside = hp < kHalo && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+        const float sc = inside ? A.c1_winv : 0.f;  // outside the slice: conv 2's zero padding
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h0, l0, h1, l1;
+            split2(fmaxf(acc[4 * q] * sc, 0.f), fmaxf(acc[4 * q + 1] * sc, 0.f), h0, l0);
+            split2(fmaxf(acc[4 * q + 2] * sc, 0.f), fmaxf(acc[4 * q + 3] * sc, 0.f), h1, l1);
+            *reinterpret_cast<uint2 *>(halo + halo_off(hp, 0, q) + 8 * kgrp) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(halo + halo_off(hp, 1, q) + 8 * kgrp) = make_uint2(l0, l1);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int t_b, t_y0, t_x0;
+    tile_origin(tile, t_b, t_y0, t_x0);
+    // prologue: patch and conv 1 of the first tile
+    if (tid < kPatchW * kPatchH) patch[tid] = load_patch(tile);
+    __syncthreads();
+    for (int g = wave; g < 11; g += kWaves) conv1_group(g, t_y0, t_x0);
+    __syncthreads();
+
+    while (true) {
+        const int next = tile + gridDim.x;
+        const float pnext = load_patch(next);  // in flight during the MFMA loop
+
+        // ---------------- conv 2: 8 x 32 pixels x 32 channels, K = 9 taps x 32 ----------------
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const unsigned char *wt = wlds + t * 4096;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f16x8 wh = *reinterpret_cast<const f16x8 *>(wt + (woff ^ (kk * 32)));
+                const f16x8 wl = *reinterpret_cast<const f16x8 *>(wt + 2048 + (woff ^ (kk * 32)));
+                const int o = boff[t] ^ (kk * 32);
+                const f16x8 xh = *reinterpret_cast<const f16x8 *>(halo + o);
+                const f16x8 xl = *reinterpret_cast<const f16x8 *>(halo + (o ^ 64));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+            }
+        }
+        S_BARRIER();  // A: every wave is done with the halo image (and with the staging windows of the previous tile)
+
+        // ---------------- output: bias, ReLU, BatchNorm, split, staged image ----------------
+        if (tid < kPatchW * kPatchH) patch[tid] = pnext;
+        unsigned char *win = stage + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * q + i;
+                v[i] = fmaf(fmaxf(fmaf(acc[e], A.winv2, pb[e]), 0.f), ps[e], pt[e]);
+            }
+            unsigned h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
+        }
+        S_BARRIER();  // B: patch of the next tile and all staging windows visible
+
+        // ---------------- conv 1 of the next tile; skip stores and pooling of this one ----------------
+        int n_b = 0, n_y0 = 0, n_x0 = 0;
+        if (next < ntiles) {
+            tile_origin(next, n_b, n_y0, n_x0);
+            for (int g = wave; g < 11; g += kWaves) conv1_group(g, n_y0, n_x0);
+        }
+        {
+            // skip tensor: row t_y0 + wave, 32 pixels x 128 B; 8 lanes = one pixel-chunk (pieces permuted by the window swizzle)
+            const long long row = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0;
+            unsigned char *ybase = static_cast<unsigned char *>(A.y) + (row * A.ldy + A.yoff) * 4;
+            uint4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int px = t * 8 + (lane >> 3);
+                v[t] = *reinterpret_cast<const uint4 *>(win + px * 128 + (lane & 7) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int px = t * 8 + (lane >> 3);
+                const int p8 = (lane & 7) ^ ((px >> 1) & 7);
+                *reinterpret_cast<uint4 *>(ybase + (long long)px * A.ldy * 4 + p8 * 16) = v[t];
+            }
+        }
+        if (wave < 4) {
+            // MaxPooling2D(2 x 2): pooled row wave <- staged rows 2 wave, 2 wave + 1; lane = (pooled pixel, 8-channel group)
+            const int pp = lane >> 2, g = lane & 3;
+            float m[8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned char *w2 = stage + (2 * wave + (s >> 1)) * 4096;
+                const int px = 2 * pp + (s & 1);
+                const uint4 hi = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, g));
+                const uint4 lo = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, 4 + g));
+                const unsigned hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const h16x2 a = __builtin_bit_cast(h16x2, hh[i]), b = __builtin_bit_cast(h16x2, ll[i]);
+                    const float v0 = (float)a[0] + (float)b[0], v1 = (float)a[1] + (float)b[1];
+                    m[2 * i] = s == 0 ? v0 : fmaxf(m[2 * i], v0);
+                    m[2 * i + 1] = s == 0 ? v1 : fmaxf(m[2 * i + 1], v1);
+                }
+            }
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split2(m[2 * i], m[2 * i + 1], h[i], l[i]);
+            const long long prow = ((long long)t_b * (A.H / 2) + (t_y0 / 2) + wave) * (A.W / 2) + (t_x0 / 2) + pp;
+            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + prow * A.pool_ld * 4 + g * 16;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        t_b = n_b;
+        t_y0 = n_y0;
+        t_x0 = n_x0;
+        S_BARRIER();  // C: halo image of the next tile complete
+    }
+}
+
+}  // namespace
+
+// (one patch row more than is used: the partly empty eleventh halo group reads a row 12 that it then discards)
+size_t enc0_lds_bytes() { return (size_t)kWBytes + kHaloBytes + kStageBytes + (size_t)kPatchW * (kPatchH + 1) * 4; }
+
+bool enc0_supported(const Enc0Args &k) { return k.H % 8 == 0 && k.W % 32 == 0 && k.B > 0; }
+
+hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
+    if (!enc0_supported(k)) return hipErrorInvalidValue;
+    const size_t lds = enc0_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(enc0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const long long ntiles = (long long)k.B * (k.H / 8) * (k.W / 32);
+    const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(enc0_kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, k);
+    return hipGetLastError();
+}
+
+}  // namespace qmri

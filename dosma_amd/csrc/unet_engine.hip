@@ -291,6 +291,8 @@ struct Unet {
     std::vector<std::unique_ptr<ConvLayer>> updec3;  // [level * 9 + phase]: stride-3 transposed convolution, one tap per phase
     std::vector<int> nf;
     DevBuf c1_w, c1_b;  // first layer fp32: [9][nf0], [nf0]
+    DevBuf c1_img;      // the same as an MFMA A operand (unet_enc0.hip): [64 lanes][hi 8 | lo 8] fp16 of 2^k * (9 taps, bias, 0 ..)
+    float c1_winv = 1.f;
     std::vector<std::unique_ptr<ConvLayer>> down1, down2, up1, up2;  // index by level
     std::vector<std::unique_ptr<ConvLayer>> updec;                   // [level]: fused 4-phase transposed conv
     std::vector<std::unique_ptr<ConvLayer>> updec_ph;                // [level * 4 + phase]: the same as four strided-output convolutions (optional)
@@ -400,6 +402,21 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             U_TRY(hipMemcpy(U->c1_w.p, k1, (size_t)9 * C * 4, hipMemcpyHostToDevice));
             U_TRY(U->c1_b.alloc((size_t)C * 4));
             U_TRY(hipMemcpy(U->c1_b.p, b1, (size_t)C * 4, hipMemcpyHostToDevice));
+            if (C == 32) {  // K = 16 operand of the fused first block: taps 0..8, the bias on a constant-one tap, zeros
+                std::vector<float> all(k1, k1 + 9 * C);
+                all.insert(all.end(), b1, b1 + C);
+                const int sh = weight_shift(all);
+                U->c1_winv = std::ldexp(1.f, -sh);
+                std::vector<unsigned short> img(64 * 16, 0);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int ch = lane & 31, k = (lane >> 5) * 8 + i;
+                        const float v = k < 9 ? k1[k * C + ch] : k == 9 ? b1[ch] : 0.f;
+                        split_f16_host(std::ldexp(v, sh), img[lane * 16 + i], img[lane * 16 + 8 + i]);
+                    }
+                U_TRY(U->c1_img.alloc(img.size() * 2));
+                U_TRY(hipMemcpy(U->c1_img.p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+            }
         } else {
             U->down1[l].reset(new ConvLayer);
             U->down1[l]->relu = 1;
@@ -572,6 +589,22 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
     for (int l = 0; l < D; ++l) {
         const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l];
         void *t1 = U->tmp[l]->p;
+        // the whole first block in one kernel (QMRI_ENC0=0: the three-kernel route, kept for A/B runs and odd sizes)
+        static const bool want_enc0 = !(std::getenv("QMRI_ENC0") && std::atoi(std::getenv("QMRI_ENC0")) == 0);
+        if (l == 0 && want_enc0 && D > 1 && C == 32 && U->fac[0] == 2 && U->c1_img.p && U->down2[0]->w_s3.p && H % 8 == 0 && W % 32 == 0) {
+            const ConvLayer &L2 = *U->down2[0];
+            qmri::Enc0Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.x = U->in.as<float>(); k.B = Bt; k.H = H; k.W = W;
+            k.c1_img = U->c1_img.p; k.c1_winv = U->c1_winv;
+            k.w2 = L2.w_s3.p; k.winv2 = L2.winv;
+            k.bias2 = L2.bias.as<float>(); k.scale2 = L2.scale.as<float>(); k.shift2 = L2.shift.as<float>();
+            k.y = U->cat[0]->p; k.ldy = 2 * C; k.yoff = C;
+            k.pool_y = U->pool[1]->p; k.pool_ld = C;
+            U_TRY(qmri::enc0_launch(k, U->num_cu, st));
+            U->trace += "down0:enc0;";
+            continue;
+        }
         if (l == 0) {
             U_TRY(qmri::c1_split_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(), C, t1, C, 0, st));
             U->trace += "down0.conv1:c1/split;";

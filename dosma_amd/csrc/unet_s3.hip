@@ -64,6 +64,17 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst_wave_ba
                  : "memory");
 }
 
+// 16-byte feature-map store with the non-temporal hint: the output of a layer streams past the L2 instead of evicting the
+// weights and halo lines every other block is about to re-read from it
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(void *dst, const uint4 &v) {
+    u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(dst));
+}
+
+#ifdef QMRI_S3_EXPERIMENTS
+__device__ unsigned long long s3_tstat[8];  // QMRI_S3_DBG & 1024: cycles in [0] main loop [1] epilogue [2] tile switch [3] work items [4] affine part
+#endif
 template <int BN>
 struct S3Cfg {
     static constexpr int WN = BN >= 64 ? 2 : 1;          // waves along the channel axis
@@ -97,8 +108,9 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 
 }  // namespace
 
-#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads | 16 no epilogue global stores | 32 no epilogue at all | 64 no MFMAs)
+#ifdef QMRI_S3_EXPERIMENTS  // timing experiments of DESIGN.md section 6 (QMRI_S3_DBG = 1 no vmcnt wait | 2 no barrier | 4 no requests | 8 no LDS reads | 16 no epilogue global stores | 32 no epilogue at all | 64 no MFMAs | 128 stores into a 4 MB window | 256 one store of four)
 #define S3_DBG(bit) (A.dbg & (bit))
+#define S3_NOW() __builtin_amdgcn_s_memtime()
 #else
 #define S3_DBG(bit) 0
 #endif
@@ -125,6 +137,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef QMRI_S3_EXPERIMENTS
+    if (S3_DBG(512)) {  // experiment: eight phase groups of CUs, started (dbg >> 16) x 1024 cycles apart
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned)(A.dbg >> 16) * 1024ull;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const int wn = wave % C::WN, wm = wave / C::WN;
     const int P = FLAT ? A.P : kPitch2D;       // LDS / flat pitch of one image row
     const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
@@ -496,6 +515,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         wp = wptr_of(w_work < nwork ? w_nb : t_nb, 0);                   \
     }
 
+#ifdef QMRI_S3_EXPERIMENTS
+    unsigned long long ts_loop = S3_DBG(1024) ? S3_NOW() : 0ull;
+#endif
     while (true) {
         // ---- one tap row (dy = row - 1) of one 32-channel chunk: three steps ----
         if ((kUnrollChunk || row == 0) && !req_tile_ready && !S3_DBG(4)) {
@@ -565,6 +587,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         chunk = n_chunk;
         cbuf = n_cbuf;
         if (!last) continue;
+#ifdef QMRI_S3_EXPERIMENTS
+        const unsigned long long ts_main = S3_DBG(1024) ? S3_NOW() : 0ull;
+        unsigned long long ts_aff = ts_main;
+#endif
 
         // ======================= epilogue of this work item =======================
         // staging: the halo buffer of the chunk that just finished (cbuf ^ 1 after the advance above), 4 KB + per wave
@@ -582,6 +608,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            // output pixel of this lane's four stores per row-tile (lane >> 3 = pixel within a group of 8), once per work item
+            int opix[RT][4];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rt = wm * RT + i, px = t * 8 + (lane >> 3);
+                    if (FLAT) {
+                        opix[i][t] = outpix[rt * 32 + px];
+                    } else {
+                        const int yy = t_y0 + rt;
+                        if (DECONV)
+                            opix[i][t] = yy < A.H ? (2 * (t_b * A.H + yy)) * (2 * A.W) + 2 * (t_x0 + px) : -1;
+                        else
+                            opix[i][t] = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
+                    }
+                }
             const float winv = A.winv;
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph)
@@ -599,6 +642,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                     }
             }
             const int n0 = t_nb * BN;
+#ifdef QMRI_S3_EXPERIMENTS
+            if (S3_DBG(1024)) ts_aff = S3_NOW();
+#endif
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
             const int ph_off = DECONV ? (ph >> 1) * 2 * A.W + (ph & 1) : 0;  // output phase (py, px) = (ph >> 1, ph & 1)
@@ -624,24 +670,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (A.y) {
+                        // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk; the LDS reads are unconditional and
+                        // issued together (ONE wait), only the global stores are predicated
+                        uint4 v[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const int id = t * 64 + lane, px = id >> 3, pc = id & 7;
-                            int pix;
-                            if (FLAT) {
-                                pix = outpix[rt * 32 + px];
-                            } else {
-                                const int yy = t_y0 + rt;
-                                if (DECONV)
-                                    pix = yy < A.H ? (2 * (t_b * A.H + yy)) * (2 * A.W) + 2 * (t_x0 + px) : -1;
-                                else
-                                    pix = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
-                            }
+                            const int pix = opix[i][t];
                             if (pix >= 0 && !S3_DBG(16)) {
-                                const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
-                                unsigned char *dst = static_cast<unsigned char *>(A.y) +
-                                                     ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + pc * 16;
-                                *reinterpret_cast<uint4 *>(dst) = v;
+                                long long doff = ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + (lane & 7) * 16;
+                                if (S3_DBG(128)) doff &= (1ll << 22) - 16;  // experiment: every store lands in one 4 MB window
+                                if (S3_DBG(256) && t) continue;              // experiment: one store of four
+                                nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
                             }
                         }
                     }
@@ -708,7 +749,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                             const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
                             const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + px;
                             unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + pc * 16;
-                            *reinterpret_cast<uint4 *>(dst) = v;
+                            nt_store16(dst, v);
                         }
                     }
                 }
@@ -716,6 +757,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             }  // phases
         }
         // ---- next work item ----
+#ifdef QMRI_S3_EXPERIMENTS
+        const unsigned long long ts_ep = S3_DBG(1024) ? S3_NOW() : 0ull;
+#endif
         work += wstride;
         if (work >= nwork) break;
         const int prev_nb = t_nb;
@@ -732,6 +776,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+#ifdef QMRI_S3_EXPERIMENTS
+        if (S3_DBG(1024)) {
+            const unsigned long long ts_next = S3_NOW();
+            if (tid == 0) {
+                atomicAdd(&s3_tstat[0], ts_main - ts_loop);
+                atomicAdd(&s3_tstat[1], ts_ep - ts_main);
+                atomicAdd(&s3_tstat[2], ts_next - ts_ep);
+                atomicAdd(&s3_tstat[3], 1ull);
+                atomicAdd(&s3_tstat[4], ts_aff - ts_main);
+            }
+            ts_loop = ts_next;
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
 }
@@ -789,7 +846,10 @@ hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         k.nj = (kHalo2D + 7) / 8;
     }
     k.nwork = k.nb * k.ntiles;
-    static const int dbg = [] { const char *e = std::getenv("QMRI_S3_DBG"); return e ? std::atoi(e) : 0; }();
+    static const int dbg = [] {
+        const char *e = std::getenv("QMRI_S3_DBG"), *d = std::getenv("QMRI_S3_DELAY");
+        return (e ? std::atoi(e) : 0) | (d ? std::atoi(d) << 16 : 0);
+    }();
     k.dbg = dbg;
     (void)hipGetLastError();
     if (k.deconv) return flat ? s3_launch_t<32, true, true>(k, num_cu, stream) : s3_launch_t<32, false, true>(k, num_cu, stream);
@@ -1031,3 +1091,14 @@ hipError_t split_cast_launch(const void *x, long long npix, int C, void *y, int 
 }
 
 }  // namespace qmri
+
+#ifdef QMRI_S3_EXPERIMENTS
+extern "C" int qmri_s3_debug_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::s3_tstat), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(qmri::s3_tstat), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

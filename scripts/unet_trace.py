@@ -21,9 +21,13 @@ def s3_2d(w):
 
 
 ops = []
+enc0 = any("enc0_kernel" in r["Kernel_Name"] for r in ks)  # the first block as one kernel (unet_enc0.hip)
 for l in range(6):
     h = HW >> l
     cin = 1 if l == 0 else nf[l - 1]
+    if l == 0 and enc0:
+        ops.append(("down0 (fused)", h * h * 9 * (nf[0] + nf[0] * nf[0])))
+        continue
     ops.append((f"down{l}.conv1", h * h * 9 * cin * nf[l]))
     ops.append((f"down{l}.conv2", h * h * 9 * nf[l] * nf[l]))
     if l < 5:

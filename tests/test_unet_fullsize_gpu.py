@@ -39,18 +39,21 @@ def ref384(net):
 
 
 def _expect_families(trace, H, W):
-    """conv_s3_kernel wherever it tiles the level (convolutions and transposed convolutions), the general kernel elsewhere."""
+    """The first encoder block as one kernel (enc0) where 8 x 32 tiles cover the slice; conv_s3_kernel wherever it tiles the
+    level (convolutions and transposed convolutions), the general kernel elsewhere."""
     by = dict(t.split(":", 1) for t in trace if ":" in t and not t.startswith(("pool", "head")))
+    fused0 = H % 8 == 0 and W % 32 == 0
     for lvl in range(6):
         wl = W >> lvl
         fam = "s3/2d" if wl % 32 == 0 else ("s3/flat" if wl + 2 <= 50 else "igemm")
-        for name in ([f"down{lvl}.conv2"] + ([f"down{lvl}.conv1"] if lvl else []) + ([f"up{lvl}.conv1", f"up{lvl}.conv2"] if lvl < 5 else [])):
+        for name in (([f"down{lvl}.conv2"] if lvl or not fused0 else []) + ([f"down{lvl}.conv1"] if lvl else [])
+                     + ([f"up{lvl}.conv1", f"up{lvl}.conv2"] if lvl < 5 else [])):
             assert by[name].startswith(fam), (name, by[name], fam)
         if lvl < 5:  # the transposed convolution tiles the INPUT grid (level lvl + 1)
             win = W >> (lvl + 1)
             famd = "s3/2d" if win % 32 == 0 else ("s3/flat" if win + 2 <= 50 else "igemm")
             assert by[f"up{lvl}.deconv"].startswith(famd), (lvl, by[f"up{lvl}.deconv"], famd)
-    assert by["down0.conv1"] == "c1/split"
+    assert (by["down0"] == "enc0") if fused0 else (by["down0.conv1"] == "c1/split")
     assert by["up0.conv2"].endswith("+head")  # the last feature map never goes to HBM
     assert by["down1.conv2"].endswith("+pool") and by["down2.conv2"].endswith("+pool")
 

@@ -9,16 +9,17 @@
 // as the halo image of the second convolution in LDS and the pooled map is made from the staged output tile: 0.1 GB in
 // (the image), 3.75 GB out.
 //
-// One persistent block of 8 waves per CU; a tile is 8 rows x 32 columns of one slice.  Per tile:
-//   patch   12 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)            -> LDS
-//   conv 1  on the 10 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
+// Persistent blocks of 4 waves, TWO per CU (the phases of a tile are sequential inside a block: while one block is in its MFMA
+// loop the other one runs its VALU / LDS / store phases); a tile is 4 rows x 32 columns of one slice.  Per tile:
+//   patch   8 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)            -> LDS
+//   conv 1  on the 6 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
 //           split into fp16 hi + lo parts like everywhere else (three MFMAs per 32 pixels); ReLU; split; halo image
 //           (zero outside the slice: that is conv 2's SAME padding)
 //   conv 2  nine taps x two k-steps x (hi hi + hi lo + lo hi); its 36 KB of weights are LDS-RESIDENT (no ring, no
 //           request stream, no counted waits); A = weights, B = pixels, so that a lane of the accumulator tile holds
 //           ONE pixel and a register one channel
 //   out     bias, ReLU, BatchNorm affine, split; [pixel][hi 64 B | lo 64 B] image through a wave window in LDS (eight 8-byte
-//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 0-3
+//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 0-1
 //           pool the staged tile 2 x 2 and store the next level's input
 #include <hip/hip_runtime.h>
 
@@ -32,12 +33,13 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kWaves = 8;
+constexpr int kWaves = 8;               // = rows of a tile
 constexpr int kThreads = kWaves * 64;
-constexpr int kPitch = 34;              // halo row pitch of the 8 x 32 tile
-constexpr int kHalo = 10 * kPitch;      // 340 halo pixels
-constexpr int kHaloBytes = 11 * 32 * 128;  // eleven 32-pixel groups (the last one is partly beyond the halo)
-constexpr int kPatchW = 36, kPatchH = 12;
+constexpr int kPitch = 34;              // halo row pitch of the kWaves x 32 tile
+constexpr int kHalo = (kWaves + 2) * kPitch;       // halo pixels
+constexpr int kGroups = (kHalo + 31) / 32;         // 32-pixel groups of the first convolution (the last one is partly empty)
+constexpr int kHaloBytes = kHalo * 128;
+constexpr int kPatchW = 36, kPatchH = kWaves + 4;
 constexpr int kWBytes = 9 * 4096;       // conv 2 weights: [tap][plane][32 channels][64 B], conv_s3_kernel's slot image
 constexpr int kStageBytes = kWaves * 4096;
 
@@ -54,6 +56,18 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+
+#ifdef QMRI_S3_EXPERIMENTS
+__device__ unsigned long long enc0_tstat[8];  // cycles of wave 0: [0] MFMA loop [1] barrier A [2] output staging [3] barrier B [4] conv 1 + stores + pool [5] barrier C [6] tiles
+#define ENC0_T(i)                                                      \
+    {                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        tacc[i] += now_ - tmark;                                       \
+        tmark = now_;                                                  \
+    }
+#else
+#define ENC0_T(i)
+#endif
 
 // LDS traffic only: the skip / pooled stores of a tile stay in flight across the barriers (__syncthreads would drain them)
 #define S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -93,30 +107,35 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
 
-    const int tiles_x = A.W / 32, tiles_y = A.H / 8;
+    const int tiles_x = A.W / 32, tiles_y = A.H / kWaves;
     const int per_img = tiles_x * tiles_y;
     const int ntiles = A.B * per_img;
     auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
         b = t / per_img;
         const int r = t - b * per_img;
         const int ty = r / tiles_x;
-        y0 = ty * 8;
+        y0 = ty * kWaves;
         x0 = (r - ty * tiles_x) * 32;
     };
-    // this thread's pixel of the 12 x 36 input patch of a tile (threads 0 .. 431), zero outside the slice
-    auto load_patch = [&](int t) -> float {
-        if (t >= ntiles || tid >= kPatchW * kPatchH) return 0.f;
+    // pixel i of the (kWaves + 4) x 36 input patch of a tile, zero outside the slice (a thread owns pixels tid and tid + kThreads)
+    auto load_patch = [&](int t, int i) -> float {
+        if (t >= ntiles || i >= kPatchW * kPatchH) return 0.f;
         int b, y0, x0;
         tile_origin(t, b, y0, x0);
-        const int r = tid / kPatchW, c = tid - r * kPatchW;
+        const int r = i / kPatchW, c = i - r * kPatchW;
         const int yy = y0 - 2 + r, xx = x0 - 2 + c;
         if ((unsigned)yy >= (unsigned)A.H || (unsigned)xx >= (unsigned)A.W) return 0.f;
         return A.x[((long long)b * A.H + yy) * A.W + xx];
     };
+    static_assert(kPatchW * kPatchH <= 2 * kThreads, "two patch pixels per thread");
+    auto store_patch = [&](float v0, float v1) {
+        patch[tid] = v0;
+        if (tid + kThreads < kPatchW * kPatchH) patch[tid + kThreads] = v1;
+    };
     // conv 1 on one group of 32 consecutive halo pixels -> halo image
     auto conv1_group = [&](int g, int y0, int x0) {
         const int hp = g * 32 + l31;
-        const int r = hp / kPitch, c = hp - r * kPitch;  // halo row / column (pixels beyond the halo: r = 10, harmless)
+        const int r = hp / kPitch, c = hp - r * kPitch;  // halo row / column (pixels beyond the halo: r = kWaves + 2, discarded)
         float tp[8];
         if (kgrp == 0) {  // taps 0..7: (r + dy, c + dx) of the patch, whose origin is (y0 - 2, x0 - 2)
             const float *p = patch + r * kPatchW + c;
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             tp[3] = p[kPatchW]; tp[4] = p[kPatchW + 1]; tp[5] = p[kPatchW + 2];
             tp[6] = p[2 * kPatchW]; tp[7] = p[2 * kPatchW + 1];
         } else {          // tap 8, the constant-one tap of the bias, six zeros
-            tp[0] = r < 10 ? patch[(r + 2) * kPatchW + c + 2] : 0.f;
+            tp[0] = r < kWaves + 2 ? patch[(r + 2) * kPatchW + c + 2] : 0.f;
             tp[1] = 1.f;
 #pragma unroll
             for (int i = 2; i < 8; ++i) tp[i] = 0.f;
@@ -142,6 +161,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
         const bool inside = hp < kHalo && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
         const float sc = inside ? A.c1_winv : 0.f;  // outside the slice: conv 2's zero padding
+        if (hp < kHalo)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned h0, l0, h1, l1;
@@ -157,36 +177,61 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     int t_b, t_y0, t_x0;
     tile_origin(tile, t_b, t_y0, t_x0);
     // prologue: patch and conv 1 of the first tile
-    if (tid < kPatchW * kPatchH) patch[tid] = load_patch(tile);
+    store_patch(load_patch(tile, tid), load_patch(tile, tid + kThreads));
     __syncthreads();
-    for (int g = wave; g < 11; g += kWaves) conv1_group(g, t_y0, t_x0);
+    for (int g = wave; g < kGroups; g += kWaves) conv1_group(g, t_y0, t_x0);
     __syncthreads();
 
+#ifdef QMRI_S3_EXPERIMENTS
+    unsigned long long tmark = __builtin_amdgcn_s_memtime();
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (registers: one atomic per block at the very end)
+#endif
     while (true) {
         const int next = tile + gridDim.x;
-        const float pnext = load_patch(next);  // in flight during the MFMA loop
+        const float pn0 = load_patch(next, tid), pn1 = load_patch(next, tid + kThreads);  // in flight during the MFMA loop
 
-        // ---------------- conv 2: 8 x 32 pixels x 32 channels, K = 9 taps x 32 ----------------
+        // ---------------- conv 2: kWaves x 32 pixels x 32 channels, K = 9 taps x 32 ----------------
+        // Software pipeline, spelled out for the scheduler (hipcc's own order is read, wait for it, multiply): the four
+        // operands of half-step h + 2 are read while the three MFMAs of half-step h run, two reads per MFMA gap.
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        struct Frag {
+            f16x8 wh, wl, xh, xl;
+        };
+        auto load_frag = [&](Frag &f, int t, int kk) {
+            const unsigned char *wt = wlds + t * 4096 + (woff ^ (kk * 32));
+            const int o = boff[t] ^ (kk * 32);
+            f.wh = *reinterpret_cast<const f16x8 *>(wt);
+            f.xh = *reinterpret_cast<const f16x8 *>(halo + o);
+            f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
+            f.xl = *reinterpret_cast<const f16x8 *>(halo + (o ^ 64));
+        };
+        auto mma = [&](const Frag &f) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xl, acc, 0, 0, 0);
+        };
+#define ENC0_PIPE()                                     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        Frag f[3];  // half-step h (tap h / 2, k-step h % 2) lives in f[h % 3]; its operands are read two half-steps ahead
+        load_frag(f[0], 0, 0);
+        load_frag(f[1], 0, 1);
+        __builtin_amdgcn_sched_barrier(0);  // the head start stays a head start: the groups below count from here
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const unsigned char *wt = wlds + t * 4096;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const f16x8 wh = *reinterpret_cast<const f16x8 *>(wt + (woff ^ (kk * 32)));
-                const f16x8 wl = *reinterpret_cast<const f16x8 *>(wt + 2048 + (woff ^ (kk * 32)));
-                const int o = boff[t] ^ (kk * 32);
-                const f16x8 xh = *reinterpret_cast<const f16x8 *>(halo + o);
-                const f16x8 xl = *reinterpret_cast<const f16x8 *>(halo + (o ^ 64));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
-            }
+        for (int h = 0; h < 18; ++h) {
+            if (h + 2 < 18) load_frag(f[(h + 2) % 3], (h + 2) / 2, (h + 2) % 2);
+            mma(f[h % 3]);
+            ENC0_PIPE()
         }
+#undef ENC0_PIPE
+        ENC0_T(0)
         S_BARRIER();  // A: every wave is done with the halo image (and with the staging windows of the previous tile)
 
+        ENC0_T(1)
         // ---------------- output: bias, ReLU, BatchNorm, split, staged image ----------------
-        if (tid < kPatchW * kPatchH) patch[tid] = pnext;
+        store_patch(pn0, pn1);
         unsigned char *win = stage + wave * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -202,13 +247,15 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
             *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
         }
+        ENC0_T(2)
         S_BARRIER();  // B: patch of the next tile and all staging windows visible
 
+        ENC0_T(3)
         // ---------------- conv 1 of the next tile; skip stores and pooling of this one ----------------
         int n_b = 0, n_y0 = 0, n_x0 = 0;
         if (next < ntiles) {
             tile_origin(next, n_b, n_y0, n_x0);
-            for (int g = wave; g < 11; g += kWaves) conv1_group(g, n_y0, n_x0);
+            for (int g = wave; g < kGroups; g += kWaves) conv1_group(g, n_y0, n_x0);
         }
         {
             // skip tensor: row t_y0 + wave, 32 pixels x 128 B; 8 lanes = one pixel-chunk (pieces permuted by the window swizzle)
@@ -227,7 +274,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                 *reinterpret_cast<uint4 *>(ybase + (long long)px * A.ldy * 4 + p8 * 16) = v[t];
             }
         }
-        if (wave < 4) {
+        if (wave < kWaves / 2) {
             // MaxPooling2D(2 x 2): pooled row wave <- staged rows 2 wave, 2 wave + 1; lane = (pooled pixel, 8-channel group)
             const int pp = lane >> 2, g = lane & 3;
             float m[8];
@@ -254,28 +301,38 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l[0], l[1], l[2], l[3]);
         }
+        ENC0_T(4)
         if (next >= ntiles) break;
         tile = next;
         t_b = n_b;
         t_y0 = n_y0;
         t_x0 = n_x0;
-        S_BARRIER();  // C: halo image of the next tile complete
+        S_BARRIER();  // C:
+        ENC0_T(5)
+#ifdef QMRI_S3_EXPERIMENTS
+        tacc[6] += 1;
+#endif halo image of the next tile complete
     }
+#ifdef QMRI_S3_EXPERIMENTS
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&enc0_tstat[i], tacc[i]);
+#endif
 }
 
 }  // namespace
 
-// (one patch row more than is used: the partly empty eleventh halo group reads a row 12 that it then discards)
+// (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
+// 36864 + 26112 + 16384 + 1296 = 80656 B: two blocks fit the 160 KB of a CU
 size_t enc0_lds_bytes() { return (size_t)kWBytes + kHaloBytes + kStageBytes + (size_t)kPatchW * (kPatchH + 1) * 4; }
 
-bool enc0_supported(const Enc0Args &k) { return k.H % 8 == 0 && k.W % 32 == 0 && k.B > 0; }
+bool enc0_supported(const Enc0Args &k) { return k.H % kWaves == 0 && k.W % 32 == 0 && k.B > 0; }
 
 hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
     if (!enc0_supported(k)) return hipErrorInvalidValue;
     const size_t lds = enc0_lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(enc0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const long long ntiles = (long long)k.B * (k.H / 8) * (k.W / 32);
+    const long long ntiles = (long long)k.B * (k.H / kWaves) * (k.W / 32);
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
     hipLaunchKernelGGL(enc0_kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, k);
@@ -283,3 +340,14 @@ hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
 }
 
 }  // namespace qmri
+
+#ifdef QMRI_S3_EXPERIMENTS
+extern "C" int qmri_enc0_debug_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::enc0_tstat), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(qmri::enc0_tstat), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

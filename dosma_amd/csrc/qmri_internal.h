@@ -132,6 +132,25 @@ size_t enc0_lds_bytes();
 bool enc0_supported(const Enc0Args &k);
 hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream);
 
+// Last convolution of the parity-mode U-Net + the 1x1 classifier in one kernel (unet_enc0.hip: out0_kernel).
+struct Out0Args {
+    const void *x;         // 32-channel input (split layout), pixel stride ldx channels, channel offset xoff
+    long long ldx;
+    int xoff;
+    int B, H, W;           // H % 8 == 0, W % 32 == 0
+    const void *w;         // conv_s3_kernel's weight image for 32 -> 32 channels (9 x 4096 B)
+    float winv;
+    const float *bias, *scale, *shift;  // [32]
+    const float *head_w;   // [32][nc]
+    const float *head_b;   // [nc]
+    int nc;                // 1..4 classes
+    float *logits;         // nullable [B*H*W][nc]
+    unsigned char *mask;   // nullable [B*H*W][nc]: logit > 0
+};
+size_t out0_lds_bytes();
+bool out0_supported(const Out0Args &k);
+hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream);
+
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).
 struct ConvKArgs {
     const void *x;       // NHWC input (fp32, or bf16 in plain-bf16 mode), pixel stride ldx (elements), channel offset xoff

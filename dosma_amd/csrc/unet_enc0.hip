@@ -319,6 +319,213 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out0_kernel -- the LAST convolution of the network with the classifier on its back, same skeleton:
+//     Conv2D(32, 3x3) + ReLU -> BatchNorm -> Conv2D(n_classes <= 4, 1x1) [-> logit > 0]     oaiunet2d.py:266-289, 305-308
+// The 32-channel input (a split tensor in HBM) arrives by LDS-DMA, the halo of tile t + 1 while tile t is multiplied (two halo
+// buffers, ONE barrier per tile); the weights are LDS-resident; the classifier runs on the fp32 accumulators -- a lane holds
+// 16 channels of ONE pixel, its partner lane (+32) the other 16 -- so the last feature map is never split, staged or stored.
+__device__ uint4 g_zero16_out0;  // source of halo pieces outside the slice (zero padding)
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst_wave_base) {  // see unet_s3.hip
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst_wave_base) : "memory");
+}
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)(lds_void *)p; }
+
+constexpr int kO_Waves = 8;
+constexpr int kO_Threads = kO_Waves * 64;
+constexpr int kO_Halo = (kO_Waves + 2) * kPitch;       // 340 halo pixels
+constexpr int kO_NJ = (kO_Halo + 7) / 8;               // 43 DMA instructions of 8 pixel-chunks
+constexpr int kO_HaloBytes = kO_NJ * 1024;
+constexpr int kO_PerWave = (kO_NJ + kO_Waves - 1) / kO_Waves;  // 6
+
+__global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *wlds = smem;                       // weights, 9 x 4096 B
+    unsigned char *halo = wlds + kWBytes;             // two halo buffers
+    float *hw = reinterpret_cast<float *>(halo + 2 * kO_HaloBytes);  // classifier: [32 channels][4], then bias [4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgrp = lane >> 5;
+
+    for (int i = tid; i < kWBytes / 16; i += kO_Threads)
+        reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
+    for (int i = tid; i < 32 * 4 + 4; i += kO_Threads) {
+        const int NC = A.nc;
+        float v;
+        if (i < 128) {
+            const int ch = i >> 2, c = i & 3;
+            v = c < NC ? A.head_w[ch * NC + c] : 0.f;
+        } else {
+            v = i - 128 < NC ? A.head_b[i - 128] : 0.f;
+        }
+        hw[i] = v;
+    }
+    float pb[16], ps[16], pt[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ch = (e & 3) + 8 * (e >> 2) + 4 * kgrp;
+        pb[e] = A.bias[ch];
+        ps[e] = A.scale[ch];
+        pt[e] = A.shift[ch];
+    }
+    const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
+    const int hp0 = (wave + 1) * kPitch + l31 + 1;
+    int boff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
+
+    // this lane's share of the halo requests: instruction j = wave + 8 i moves pixels 8 j .. 8 j + 7, lane = (pixel, piece);
+    // the swizzle of the LDS image lives on the SOURCE address (the DMA writes lane * 16 linearly)
+    int d_yx[kO_PerWave], d_src[kO_PerWave];
+#pragma unroll
+    for (int i = 0; i < kO_PerWave; ++i) {
+        const int j = wave + kO_Waves * i;
+        const int hp = j * 8 + (lane >> 3), p8 = lane & 7;
+        const int plane = (p8 >> 2) ^ ((hp >> 1) & 1), q = (p8 & 3) ^ ((hp >> 2) & 3);
+        const int hy = hp / kPitch, hx = hp - hy * kPitch;
+        d_yx[i] = (j < kO_NJ && hp < kO_Halo) ? (hy | (hx << 8)) : -1;
+        d_src[i] = plane * 64 + q * 16;
+    }
+    const unsigned halo_lds = lds_off(halo);
+    const unsigned char *zero_line = reinterpret_cast<const unsigned char *>(&g_zero16_out0);
+    const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
+
+    const int tiles_x = A.W / 32, tiles_y = A.H / kO_Waves;
+    const int per_img = tiles_x * tiles_y;
+    const int ntiles = A.B * per_img;
+    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / tiles_x;
+        y0 = ty * kO_Waves;
+        x0 = (r - ty * tiles_x) * 32;
+    };
+    auto request_halo = [&](int t, int buf) {
+        int b, y0, x0;
+        tile_origin(t, b, y0, x0);
+#pragma unroll
+        for (int i = 0; i < kO_PerWave; ++i) {
+            const int j = wave + kO_Waves * i;
+            if (j < kO_NJ) {  // (wave-uniform)
+                const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
+                const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+                const unsigned char *src = ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff) * 4 + d_src[i] : zero_line;
+                dma16(src, halo_lds + (unsigned)(buf * kO_HaloBytes + j * 1024));
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int t_b, t_y0, t_x0;
+    tile_origin(tile, t_b, t_y0, t_x0);
+    request_halo(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+
+#ifdef QMRI_S3_EXPERIMENTS
+    unsigned long long tmark = __builtin_amdgcn_s_memtime();
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    while (true) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) request_halo(next, buf ^ 1);  // lands while this tile is multiplied
+        ENC0_T(0)
+        const unsigned char *hb = halo + buf * kO_HaloBytes;
+
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        struct Frag {
+            f16x8 wh, wl, xh, xl;
+        };
+        auto load_frag = [&](Frag &f, int t, int kk) {
+            const unsigned char *wt = wlds + t * 4096 + (woff ^ (kk * 32));
+            const int o = boff[t] ^ (kk * 32);
+            f.wh = *reinterpret_cast<const f16x8 *>(wt);
+            f.xh = *reinterpret_cast<const f16x8 *>(hb + o);
+            f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
+            f.xl = *reinterpret_cast<const f16x8 *>(hb + (o ^ 64));
+        };
+        auto mma = [&](const Frag &f) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xl, acc, 0, 0, 0);
+        };
+        Frag f[3];
+        load_frag(f[0], 0, 0);
+        load_frag(f[1], 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 18; ++h) {
+            if (h + 2 < 18) load_frag(f[(h + 2) % 3], (h + 2) / 2, (h + 2) % 2);
+            mma(f[h % 3]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+
+        ENC0_T(1)
+        // ---- bias, ReLU, BatchNorm; classifier on this lane's 16 channels; the partner lane adds the other 16 ----
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = fmaf(fmaxf(fmaf(acc[e], A.winv, pb[e]), 0.f), ps[e], pt[e]);
+            const float4 w4 = *reinterpret_cast<const float4 *>(hw + ((e & 3) + 8 * (e >> 2) + 4 * kgrp) * 4);
+            z[0] = fmaf(v, w4.x, z[0]);
+            z[1] = fmaf(v, w4.y, z[1]);
+            z[2] = fmaf(v, w4.z, z[2]);
+            z[3] = fmaf(v, w4.w, z[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
+        if (kgrp == 0) {
+            const long long pix = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0 + l31;
+            const int NC = A.nc;
+            float zz[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zz[c] = z[c] + hw[128 + c];
+            if (NC == 4) {
+                if (A.logits) *reinterpret_cast<float4 *>(A.logits + pix * 4) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                if (A.mask)
+                    *reinterpret_cast<unsigned *>(A.mask + pix * 4) = (zz[0] > 0.f ? 1u : 0u) | (zz[1] > 0.f ? 0x100u : 0u) |
+                                                                      (zz[2] > 0.f ? 0x10000u : 0u) | (zz[3] > 0.f ? 0x1000000u : 0u);
+            } else {
+                for (int c = 0; c < NC; ++c) {
+                    if (A.logits) A.logits[pix * NC + c] = zz[c];
+                    if (A.mask) A.mask[pix * NC + c] = zz[c] > 0.f ? 1 : 0;
+                }
+            }
+        }
+        ENC0_T(2)
+        if (next >= ntiles) break;
+        tile = next;
+        tile_origin(tile, t_b, t_y0, t_x0);
+        buf ^= 1;
+        // the next halo has landed (this wave's part; then everyone's) and every wave is done with the old buffer.  The wait is
+        // COUNTED: the logits / mask stores issued after the requests stay in flight (vmcnt(0) would expose their latency per tile)
+        if (A.nc == 4 && A.logits && A.mask)
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (A.nc == 4 && (A.logits || A.mask))
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        ENC0_T(3)
+#ifdef QMRI_S3_EXPERIMENTS
+        tacc[6] += 1;
+#endif
+    }
+#ifdef QMRI_S3_EXPERIMENTS
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&enc0_tstat[i], tacc[i]);  // (shared with enc0_kernel: read and reset between layers)
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 // (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
@@ -336,6 +543,22 @@ hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
     hipLaunchKernelGGL(enc0_kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, k);
+    return hipGetLastError();
+}
+
+size_t out0_lds_bytes() { return (size_t)kWBytes + 2 * (size_t)kO_HaloBytes + (32 * 4 + 4) * 4; }
+
+bool out0_supported(const Out0Args &k) { return k.H % kO_Waves == 0 && k.W % 32 == 0 && k.B > 0 && k.nc >= 1 && k.nc <= 4; }
+
+hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream) {
+    if (!out0_supported(k)) return hipErrorInvalidValue;
+    const size_t lds = out0_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(out0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const long long ntiles = (long long)k.B * (k.H / kO_Waves) * (k.W / 32);
+    const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(out0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
     return hipGetLastError();
 }
 

@@ -672,6 +672,22 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
         if (rc != QMRI_OK) return rc;
         void *out = U->upout[l]->p;
         snprintf(nm, sizeof(nm), "up%d.conv2", l);
+        // the last convolution + classifier as one kernel with LDS-resident weights (QMRI_OUT0=0: conv_s3_kernel + fused head)
+        static const bool want_out0 = !(std::getenv("QMRI_OUT0") && std::atoi(std::getenv("QMRI_OUT0")) == 0);
+        if (l == 0 && want_out0 && C == 32 && U->up2[0]->w_s3.p && H % 8 == 0 && W % 32 == 0) {
+            const ConvLayer &L2 = *U->up2[0];
+            qmri::Out0Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.x = t1; k.ldx = C; k.xoff = 0; k.B = Bt; k.H = H; k.W = W;
+            k.w = L2.w_s3.p; k.winv = L2.winv;
+            k.bias = L2.bias.as<float>(); k.scale = L2.scale.as<float>(); k.shift = L2.shift.as<float>();
+            k.head_w = U->head_w.as<float>(); k.head_b = U->head_b.as<float>(); k.nc = U->ncls;
+            k.logits = logits; k.mask = mask;
+            U_TRY(qmri::out0_launch(k, U->num_cu, st));
+            U->trace += "up0.conv2:out0+head;";
+            src = out;
+            continue;
+        }
         rc = conv3x3_parity(U, nm, *U->up2[l], t1, C, 0, Bt, H, W, out, C, 0, nullptr, 0, l == 0, logits, mask, st);
         if (rc != QMRI_OK) return rc;
         src = out;

@@ -150,15 +150,16 @@ def test_product_never_imports_the_oracle():
     subprocess.check_call([sys.executable, "-c", code])
 
 
-def test_lds_dma_statements_own_m0(tmp_path):
-    """unet_s3.hip issues its LDS-DMA through inline asm that writes M0 (the LDS destination base) and does not restore
-    it.  That is only sound if nothing else in those kernels reads M0: check the generated gfx950 assembly -- every line
-    that mentions m0 must be one of the statement's own `s_mov_b32 m0, ...` writes."""
+@pytest.mark.parametrize("source,min_dma", [("unet_s3.hip", 20), ("unet_enc0.hip", 6)])
+def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
+    """unet_s3.hip / unet_enc0.hip issue their LDS-DMA through inline asm that writes M0 (the LDS destination base) and does
+    not restore it.  That is only sound if nothing else in those kernels reads M0: check the generated gfx950 assembly --
+    every line that mentions m0 must be one of the statement's own `s_mov_b32 m0, ...` writes."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "dosma_amd", "csrc", "unet_s3.hip")
-    out = tmp_path / "unet_s3.s"
+    src = os.path.join(ROOT, "dosma_amd", "csrc", source)
+    out = tmp_path / (source + ".s")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
                            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "dosma_amd", "csrc"), src, "-o", str(out)])
     lines = [ln.strip() for ln in out.read_text().splitlines()]
@@ -166,4 +167,4 @@ def test_lds_dma_statements_own_m0(tmp_path):
     assert m0, "expected the DMA statements' M0 writes in the assembly"
     others = [ln for ln in m0 if not ln.startswith("s_mov_b32 m0,")]
     assert not others, others[:5]
-    assert sum("global_load_lds_dwordx4" in ln for ln in lines) >= 20
+    assert sum("global_load_lds_dwordx4" in ln for ln in lines) >= min_dma

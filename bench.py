@@ -452,7 +452,7 @@ def main():
     ap.add_argument("--unet-batch", type=int, default=160,
                     help="slices per pass through the network (default: the whole 160-slice volume)")
     ap.add_argument("--cfg5-volumes-per-gpu", type=int, default=8)
-    ap.add_argument("--cfg5-unet-batch", type=int, default=32)
+    ap.add_argument("--cfg5-unet-batch", type=int, default=160)
     ap.add_argument("--print-kernel-hash", action="store_true")
     args = ap.parse_args()
     if args.print_kernel_hash:

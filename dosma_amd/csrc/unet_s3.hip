@@ -64,8 +64,8 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst_wave_ba
                  : "memory");
 }
 
-// 16-byte feature-map store with the non-temporal hint: the output of a layer streams past the L2 instead of evicting the
-// weights and halo lines every other block is about to re-read from it
+// 16-byte feature-map store with the non-temporal hint (a layer's output is not read again by this kernel).  Measured
+// neutral on the whole network (35.4 ms either way): kept as the statement of intent, not as an optimisation
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store16(void *dst, const uint4 &v) {
     u32x4 t = {v.x, v.y, v.z, v.w};

@@ -69,19 +69,20 @@ if os.path.exists(ut):
         "# rocprofv3 --kernel-trace of scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160: last forward\n"
         "# TF = ALGORITHMIC flops of the layer / kernel time (the parity mode issues 3 MFMAs per product)\n" + layers)
     rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
-            if "conv_s3_kernel" in r["Kernel_Name"]]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # 20 convolutions + 5 transposed convolutions per forward
+            if any(k in r["Kernel_Name"] for k in ("conv_s3_kernel", "enc0_kernel", "out0_kernel"))]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # per forward: enc0 + 18 convolutions + 5 transposed + out0
     agg = collections.Counter()
     for r in rows:
         if int(r["Dispatch_Id"]) in ids:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
     cycles = agg["SQ_BUSY_CYCLES"] / 32  # summed over the 32 shader engines
-    u = {"tag": tag, "workload": "UNet2D forward, 160 slices of 384x384, parity mode fp16x3: the 25 conv_s3_kernel dispatches of one forward",
+    u = {"tag": tag, "workload": "UNet2D forward, 160 slices of 384x384, parity mode fp16x3: the 25 MFMA-kernel dispatches of one forward "
+                                 "(enc0_kernel, 23 x conv_s3_kernel, out0_kernel)",
          "counters": dict(agg),
          "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
          "mfma_instructions": agg["SQ_INSTS_MFMA"],
          "mfma_gflop_issued": agg["SQ_INSTS_MFMA"] * 32768 / 1e9,
-         "mfma_gflop_algorithmic_x3": 3 * (70.79 - 2 * 0.042) * 160,
+         "mfma_gflop_algorithmic_x3": 3 * 70.79 * 160,
          "lds_bank_conflict_over_active": agg["SQ_LDS_BANK_CONFLICT"] / max(agg["SQ_LDS_IDX_ACTIVE"], 1.0),
          "wave_wait_frac": agg["SQ_WAIT_ANY"] / max(agg["SQ_WAVE_CYCLES"], 1.0),
          "unet2d_bench": bench.get("unet2d")}

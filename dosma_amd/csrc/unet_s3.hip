@@ -413,11 +413,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         for (int i = 0; i < RT; ++i) {
             if ((RT == 1 ? 0 : i) != part) continue;
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[PH][i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[PH][i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[PH][i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[PH][i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[PH][i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[PH][i][j], 0, 0, 0);
         }
     };
     // this wave's first weight piece of the slot image to request next, as a running per-lane pointer
@@ -608,43 +608,51 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            // output pixel of this lane's four stores per row-tile (lane >> 3 = pixel within a group of 8), once per work item
-            int opix[RT][4];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rt = wm * RT + i, px = t * 8 + (lane >> 3);
-                    if (FLAT) {
-                        opix[i][t] = outpix[rt * 32 + px];
-                    } else {
-                        const int yy = t_y0 + rt;
-                        if (DECONV)
-                            opix[i][t] = yy < A.H ? (2 * (t_b * A.H + yy)) * (2 * A.W) + 2 * (t_x0 + px) : -1;
-                        else
-                            opix[i][t] = yy < A.H ? (t_b * A.H + yy) * A.W + t_x0 + px : -1;
-                    }
-                }
-            const float winv = A.winv;
-#pragma unroll
-            for (int ph = 0; ph < NPH; ++ph)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const int col = (wn * CT + j) * 32 + (lane & 31);
-                const float bias = prm[col], scale = prm[BN + col], shift_ = prm[2 * BN + col];
+            // output pixel of this lane's store t of row-tile i (lane >> 3 = pixel within a group of 8).  FLAT: from the table, once
+            // per work item; 2D: a row base (tile origin: scalar registers) + the column, recomputed per use -- eight VGPRs held across
+            // the epilogue were enough to push the halo source pointers of the main loop into scratch
+            int opix_flat[FLAT ? RT : 1][4];
+            if (FLAT) {
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = fmaf(acc[ph][i][j][e], winv, bias);
-                        if (A.relu) v = fmaxf(v, 0.f);
-                        acc[ph][i][j][e] = fmaf(v, scale, shift_);
-                    }
+                    for (int t = 0; t < 4; ++t) opix_flat[i][t] = outpix[(wm * RT + i) * 32 + t * 8 + (lane >> 3)];
             }
+            auto out_pixel = [&](int i, int t) -> int {
+                if (FLAT) return opix_flat[i][t];
+                const int yy = t_y0 + wm * RT + i, xx = t_x0 + t * 8 + (lane >> 3);
+                if (yy >= A.H) return -1;
+                return DECONV ? (2 * (t_b * A.H + yy)) * (2 * A.W) + 2 * xx : (t_b * A.H + yy) * A.W + xx;
+            };
+            const float winv = A.winv;
+            // bias, ReLU, BatchNorm affine in place, one accumulator tile at a time (interleaving the tiles keeps two versions of
+            // every 16-register tile alive: 256 VGPRs + spills); the parameters of four channels are one float4 broadcast
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            // bias, ReLU, BatchNorm affine of four neighbouring channels (one float4 broadcast each from LDS).  The accumulators
+            // are never modified: every consumer (staging, classifier, pooling) applies the affine to the values it takes.  (Updating
+            // the 16-register tiles in place, four elements at a time, kept two versions of every tile alive: 256 VGPRs, the main
+            // loop's halo pointers in scratch -- and every scratch reload in the MFMA loop is a vmcnt(0) among the counted waits.)
+            struct Prm4 {
+                f32x4 b, s, t;
+            };
+            auto load_prm = [&](int j, int q) -> Prm4 {
+                Prm4 p;
+                const float *pp = prm + (wn * CT + j) * 32 + 8 * q + 4 * khalf;
+                p.b = *reinterpret_cast<const f32x4 *>(pp);
+                p.s = *reinterpret_cast<const f32x4 *>(pp + BN);
+                p.t = *reinterpret_cast<const f32x4 *>(pp + 2 * BN);
+                return p;
+            };
+            auto affine = [&](float a, const Prm4 &p, int r) -> float {
+                float v = fmaf(a, winv, p.b[r]);
+                if (A.relu) v = fmaxf(v, 0.f);
+                return fmaf(v, p.s[r], p.t[r]);
+            };
             const int n0 = t_nb * BN;
-#ifdef QMRI_S3_EXPERIMENTS
-            if (S3_DBG(1024)) ts_aff = S3_NOW();
-#endif
+            const int px_l = lane & 31;
+            // staging window: pixel px, 16-byte piece p8 = plane * 4 + q at position p8 ^ ((px >> 1) & 7) (the 8-byte writes of
+            // 32 lanes then spread over 16 bank groups instead of 2)
+            auto stage_piece = [&](int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); };
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
             const int ph_off = DECONV ? (ph >> 1) * 2 * A.W + (ph & 1) : 0;  // output phase (py, px) = (ph >> 1, ph & 1)
@@ -653,60 +661,63 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 const int cbase = n0 + (wn * CT + j) * 32;  // first output channel of this column tile
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
-                    const int rt = wm * RT + i;
                     // ---- [32 pixels][32 hi | 32 lo] image of the tile in the wave's window ----
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};  // (classifier partial sums, BN = 32 with a fused head only)
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        // rows (pixels) e and e + 1 of this lane: (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-                        const float v0 = acc[ph][i][j][e], v1 = acc[ph][i][j][e + 1];
-                        const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-                        const h16x2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
-                        const int r0 = (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                        __fp16 *p0 = reinterpret_cast<__fp16 *>(stage + r0 * 128) + (lane & 31);
-                        p0[0] = h[0];
-                        p0[32] = l[0];
-                        p0[64] = h[1];       // next pixel row (+128 B)
-                        p0[64 + 32] = l[1];
+                    for (int q = 0; q < 4; ++q) {
+                        const Prm4 p = load_prm(j, q);
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = affine(acc[ph][i][j][4 * q + r], p, r);
+                        if (!DECONV && BN == 32 && A.head_w) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float4 w4 = *reinterpret_cast<const float4 *>(hw + (8 * q + 4 * khalf + r) * 4);
+                                z[0] = fmaf(v[r], w4.x, z[0]);
+                                z[1] = fmaf(v[r], w4.y, z[1]);
+                                z[2] = fmaf(v[r], w4.z, z[2]);
+                                z[3] = fmaf(v[r], w4.w, z[3]);
+                            }
+                        }
+                        if (A.y) {
+                            const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                            const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+                            const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, q) + 8 * khalf) =
+                                make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, 4 + q) + 8 * khalf) =
+                                make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+                        }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (A.y) {
-                        // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk; the LDS reads are unconditional and
-                        // issued together (ONE wait), only the global stores are predicated
+                        // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window
+                        // swizzle); the LDS reads are issued together (ONE wait), only the global stores are predicated
+#pragma unroll
+                        for (int t0 = 0; t0 < 4; t0 += 2) {
                         uint4 v[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
+                        for (int t = t0; t < t0 + 2; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int pix = opix[i][t];
+                        for (int t = t0; t < t0 + 2; ++t) {
+                            const int pix = out_pixel(i, t);
+                            const int p8 = (lane & 7) ^ (((t * 8 + (lane >> 3)) >> 1) & 7);
                             if (pix >= 0 && !S3_DBG(16)) {
-                                long long doff = ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + (lane & 7) * 16;
+                                long long doff = ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
                                 if (S3_DBG(128)) doff &= (1ll << 22) - 16;  // experiment: every store lands in one 4 MB window
                                 if (S3_DBG(256) && t) continue;              // experiment: one store of four
                                 nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
                             }
                         }
+                        }
                     }
                     if (!DECONV && BN == 32 && A.head_w) {
-                        // 1x1 head on the finished tile: lane = (pixel, half of the channels)
-                        const int px = lane & 31, half = khalf;
-                        const f16x8 *row = reinterpret_cast<const f16x8 *>(stage + px * 128 + half * 32);
-                        const f16x8 h0 = row[0], h1 = row[1];
-                        const f16x8 l0 = row[4], l1 = row[5];  // + 64 B: the lo parts
-                        float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float v = q < 8 ? (float)h0[q] + (float)l0[q] : (float)h1[q - 8] + (float)l1[q - 8];
-                            const float4 w4 = *reinterpret_cast<const float4 *>(hw + (half * 16 + q) * 4);
-                            z[0] = fmaf(v, w4.x, z[0]);
-                            z[1] = fmaf(v, w4.y, z[1]);
-                            z[2] = fmaf(v, w4.z, z[2]);
-                            z[3] = fmaf(v, w4.w, z[3]);
-                        }
+                        // 1x1 classifier: this lane summed its 16 channels of its pixel above, the partner lane (+32) adds the rest
 #pragma unroll
                         for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
-                        const int yy = t_y0 + rt;
-                        if (half == 0 && yy < A.H) {
-                            const long long pix = (long long)(t_b * A.H + yy) * A.W + t_x0 + px;
+                        const int pixh = FLAT ? outpix[(wm * RT + i) * 32 + px_l] : (t_y0 + wm * RT + i < A.H ? (t_b * A.H + t_y0 + wm * RT + i) * A.W + t_x0 + px_l : -1);
+                        if (khalf == 0 && pixh >= 0) {
+                            const long long pix = pixh;
                             const int NC = A.head_nc;
                             float zz[4];
 #pragma unroll
@@ -728,27 +739,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                 }
                 // ---- fused MaxPooling2D(2x2): rows rt, rt+1 of this wave (RT = 2) -> 16 pooled pixels x 32 channels ----
                 if (!DECONV && !FLAT && RT == 2 && A.pool_y) {
+                    // vertical: the two row-tiles of this lane; horizontal: the neighbouring lane (pixel ^ 1); even lanes keep the result
 #pragma unroll
-                    for (int e2 = 0; e2 < 8; ++e2) {
-                        const int e = 2 * e2;
-                        const float m = fmaxf(fmaxf(acc[0][0][j][e], acc[0][0][j][e + 1]), fmaxf(acc[0][RT - 1][j][e], acc[0][RT - 1][j][e + 1]));
-                        const int r0 = ((e & 3) + 8 * (e >> 2) + 4 * khalf) >> 1;  // pooled column 0..15
-                        const __fp16 h = __builtin_amdgcn_cvt_pkrtz(m, 0.f)[0];
-                        const __fp16 l = __builtin_amdgcn_cvt_pkrtz(m - (float)h, 0.f)[0];
-                        __fp16 *p0 = reinterpret_cast<__fp16 *>(stage + r0 * 128) + (lane & 31);
-                        p0[0] = h;
-                        p0[32] = l;
+                    for (int q = 0; q < 4; ++q) {
+                        const Prm4 p = load_prm(j, q);
+                        float m[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float vmax = fmaxf(affine(acc[0][0][j][4 * q + r], p, r), affine(acc[0][RT - 1][j][4 * q + r], p, r));
+                            const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vmax), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
+                            m[r] = fmaxf(vmax, other);
+                        }
+                        const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(m[0], m[1]), h1 = __builtin_amdgcn_cvt_pkrtz(m[2], m[3]);
+                        const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(m[0] - (float)h0[0], m[1] - (float)h0[1]);
+                        const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(m[2] - (float)h1[0], m[3] - (float)h1[1]);
+                        if (!(px_l & 1)) {
+                            const int pp = px_l >> 1;  // pooled column 0..15
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, q) + 8 * khalf) =
+                                make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, 4 + q) + 8 * khalf) =
+                                make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+                        }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     const int Hp = A.H >> 1, Wp = A.W >> 1;
                     const int yy = (t_y0 >> 1) + wm;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int id = t * 64 + lane, px = id >> 3, pc = id & 7;
+                        const int id = t * 64 + lane, px = id >> 3, pos = id & 7;
                         if (yy < Hp) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pc * 16);
+                            const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pos * 16);
+                            const int p8 = pos ^ ((px >> 1) & 7);
                             const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + px;
-                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + pc * 16;
+                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + p8 * 16;
                             nt_store16(dst, v);
                         }
                     }

@@ -6,14 +6,17 @@
 // which the reference evaluates with one boolean mask, one fancy-index copy and three numpy reductions per label over
 // the whole volume.  Here the map and the label map are read once per pass; every pass handles all regions at once.
 //
-//   pass 1  count and sum per region                      -> mean
-//   pass 2  sum of squared deviations from the mean       -> std (numpy's two-pass nanstd)
-//   8 selection passes (one byte of the key each, most significant first): exact radix selection of the two middle
-//           order statistics of every region on the order-preserving 64-bit image of the double; histograms of 256
-//           bins per (region, statistic) in LDS, merged with atomics; a one-block kernel between passes picks the
-//           bin that holds the wanted rank and extends the key prefix -- no host round trip.
+//   One streaming kernel per radix digit of the order-preserving 64-bit image of the double (exact radix selection of the two
+//   middle order statistics of every region: histograms per (region, statistic) in LDS, merged with atomics; a small kernel
+//   between passes picks the bin that holds the wanted rank and extends the key prefix -- no host round trip):
+//     pass 1  digit 1 + count and sum per region                         -> mean, wanted ranks
+//     pass 2  digit 2 + sum of squared deviations from the mean          -> std (numpy's two-pass nanstd)
+//     pass 3+ the remaining digits
+//   Digits are 11 bits wide when the histograms of all regions fit LDS (<= 6 regions incl. "total": 6 passes for a float64
+//   map, 4 for a float32 map, whose low 29 key bits are fixed by the sign), 8 bits otherwise (8 / 5 passes).  Round 1 ran
+//   2 moment passes + 8 one-byte selection passes whatever the map.
 //
-// Streaming: (sizeof(value) + sizeof(label)) bytes per voxel per pass, 10 passes.
+// Streaming: (sizeof(value) + sizeof(label)) bytes per voxel per pass.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -48,7 +51,7 @@ struct StatsState {
     double ssd[kMaxR];
     unsigned long long prefix[2 * kMaxR];  // key prefix found so far, per (region, statistic)
     unsigned long long rank[2 * kMaxR];    // remaining rank inside the prefix
-    unsigned int hist[2 * kMaxR][256];
+    unsigned int hist[2 * kMaxR][2048];  // (rows of 256 with 8-bit digits)
 };
 
 __device__ __forceinline__ double load_value(const StatsK &K, long long i) {
@@ -94,62 +97,100 @@ __device__ __forceinline__ double key_value(unsigned long long k) {
     return __longlong_as_double((long long)u);
 }
 
-template <int PASS>  // 1: count + sum, 2: squared deviations
-__global__ __launch_bounds__(256) void moments_kernel(const StatsK K, StatsState *S) {
+// One pass: histogram of digit `pass` (BITS wide, most significant first) of the keys that match the prefix found so far;
+// MOMENT 1 adds count + sum (first pass, no prefix yet), MOMENT 2 the squared deviations from the mean (second pass).
+template <int BITS, int MOMENT>
+__global__ __launch_bounds__(BITS == 11 ? 1024 : 256) void select_hist_kernel(const StatsK K, StatsState *S, int pass, int shift, int width) {
+    extern __shared__ unsigned int s_h[];  // [2 * nreg][1 << BITS]
+    __shared__ unsigned long long s_prefix[2 * kMaxR];
     __shared__ double s_a[kMaxR], s_mean[kMaxR];
     __shared__ unsigned long long s_n[kMaxR];
+    constexpr int NB = 1 << BITS;
     const int nreg = K.nkeys + 1;
+    for (int i = threadIdx.x; i < 2 * nreg * NB; i += blockDim.x) s_h[i] = 0u;
+    if (threadIdx.x < 2 * kMaxR) s_prefix[threadIdx.x] = S->prefix[threadIdx.x];
     if (threadIdx.x < kMaxR) {
         s_a[threadIdx.x] = 0.0;
         s_n[threadIdx.x] = 0ull;
-        s_mean[threadIdx.x] = PASS == 2 ? S->mean[threadIdx.x] : 0.0;
+        s_mean[threadIdx.x] = MOMENT == 2 ? S->mean[threadIdx.x] : 0.0;
     }
     __syncthreads();
+    // bits above this digit (all of them compared with the prefix); the first pass has none
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + width));
+    const unsigned int dmask = (1u << width) - 1u;  // (the last digit may be narrower than BITS)
     double acc[kMaxR];
     unsigned int cnt[kMaxR];
-#pragma unroll
-    for (int r = 0; r < kMaxR; ++r) {
-        acc[r] = 0.0;
-        cnt[r] = 0u;
-    }
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < K.N; i += stride) {
-        const double v = load_value(K, i);
-        int region;
-        bool total;
-        if (!classify(K, i, v, region, total)) continue;
+    if (MOMENT) {
 #pragma unroll
         for (int r = 0; r < kMaxR; ++r) {
-            const bool in = (r == region) || (total && r == K.nkeys);
-            if (in) {
-                if (PASS == 1) {
-                    acc[r] += v;
-                    cnt[r] += 1u;
-                } else {
-                    const double d = v - s_mean[r];
-                    acc[r] += d * d;
+            acc[r] = 0.0;
+            cnt[r] = 0u;
+        }
+    }
+    auto consume = [&](long long i, double v) {
+        int region;
+        bool total;
+        if (!classify(K, i, v, region, total)) return;
+        if (MOMENT) {
+#pragma unroll
+            for (int r = 0; r < kMaxR; ++r) {
+                const bool in = (r == region) || (total && r == K.nkeys);
+                if (in) {
+                    if (MOMENT == 1) {
+                        acc[r] += v;
+                        cnt[r] += 1u;
+                    } else {
+                        const double d = v - s_mean[r];
+                        acc[r] += d * d;
+                    }
+                }
+            }
+        }
+        const unsigned long long key = order_key(v);
+        const unsigned int digit = (unsigned int)(key >> shift) & dmask;
+        for (int which = 0; which < 2; ++which) {
+            const int r = which == 0 ? region : (total ? K.nkeys : -1);
+            if (r < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if ((key & himask) == s_prefix[2 * r + q]) atomicAdd(&s_h[(2 * r + q) * NB + digit], 1u);
+        }
+    };
+    // four independent value loads in flight per thread (the histograms cap the resident waves; the stream is latency-bound)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < K.N; i += 4 * stride) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load_value(K, i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) consume(i + u * stride, v[u]);
+    }
+    for (; i < K.N; i += stride) consume(i, load_value(K, i));
+    if (MOMENT) {
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r) {
+            if (r < nreg) {
+                double a = acc[r];
+                unsigned int c = cnt[r];
+                for (int off = 32; off > 0; off >>= 1) {
+                    a += __shfl_down(a, off);
+                    c += __shfl_down(c, off);
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&s_a[r], a);
+                    if (MOMENT == 1) atomicAdd(&s_n[r], (unsigned long long)c);
                 }
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < kMaxR; ++r) {
-        if (r < nreg) {
-            double a = acc[r];
-            unsigned int c = cnt[r];
-            for (int off = 32; off > 0; off >>= 1) {
-                a += __shfl_down(a, off);
-                c += __shfl_down(c, off);
-            }
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&s_a[r], a);
-                if (PASS == 1) atomicAdd(&s_n[r], (unsigned long long)c);
-            }
-        }
-    }
     __syncthreads();
-    if (threadIdx.x < nreg) {
-        if (PASS == 1) {
+    for (int i = threadIdx.x; i < 2 * nreg * NB; i += blockDim.x) {
+        const unsigned int c = s_h[i];
+        if (c) atomicAdd(&S->hist[i / NB][i % NB], c);
+    }
+    if (MOMENT && threadIdx.x < nreg) {
+        if (MOMENT == 1) {
             atomicAdd(&S->sum[threadIdx.x], s_a[threadIdx.x]);
             atomicAdd(&S->count[threadIdx.x], s_n[threadIdx.x]);
         } else {
@@ -158,78 +199,82 @@ __global__ __launch_bounds__(256) void moments_kernel(const StatsK K, StatsState
     }
 }
 
-// after pass 1: means and the two wanted ranks of every region
-__global__ void after_moments_kernel(StatsState *S, int nreg) {
-    const int r = threadIdx.x;
-    if (r >= nreg) return;
-    const unsigned long long n = S->count[r];
-    S->mean[r] = n ? S->sum[r] / (double)n : NAN;
-    S->prefix[2 * r] = S->prefix[2 * r + 1] = 0ull;
-    S->rank[2 * r] = n ? (n - 1) / 2 : 0ull;  // numpy.median: mean of elements (n-1)//2 and n//2 of the sorted values
-    S->rank[2 * r + 1] = n / 2;
-}
-
-// one radix-selection pass: byte `pass` (0 = most significant) of the keys that match the prefix found so far
-__global__ __launch_bounds__(256) void select_hist_kernel(const StatsK K, StatsState *S, int pass) {
-    __shared__ unsigned int s_h[2 * kMaxR][256];
-    __shared__ unsigned long long s_prefix[2 * kMaxR];
-    const int nreg = K.nkeys + 1;
-    for (int i = threadIdx.x; i < 2 * kMaxR * 256; i += blockDim.x) (&s_h[0][0])[i] = 0u;
-    if (threadIdx.x < 2 * kMaxR) s_prefix[threadIdx.x] = S->prefix[threadIdx.x];
-    __syncthreads();
-    const int shift = 56 - 8 * pass;
-    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < K.N; i += stride) {
-        const double v = load_value(K, i);
-        int region;
-        bool total;
-        if (!classify(K, i, v, region, total)) continue;
-        const unsigned long long key = order_key(v);
-        const unsigned int digit = (unsigned int)(key >> shift) & 255u;
-        for (int which = 0; which < 2; ++which) {
-            const int r = which == 0 ? region : (total ? K.nkeys : -1);
-            if (r < 0) continue;
+// One block per (region, statistic): [first pass: mean and the wanted rank,] the bin that holds the rank (block-wide scan of
+// the histogram row), prefix extended by the digit, row cleared for the next pass.
+template <int BITS>
+__global__ __launch_bounds__(256) void select_pick_kernel(StatsState *S, int pass, int shift) {
+    constexpr int NB = 1 << BITS, PER = NB / 256;
+    __shared__ unsigned long long s_scan[256];
+    __shared__ unsigned long long s_rank;
+    const int q = blockIdx.x, r = q >> 1, t = threadIdx.x;
+    if (t == 0) {
+        if (pass == 0) {
+            const unsigned long long n = S->count[r];
+            if ((q & 1) == 0) S->mean[r] = n ? S->sum[r] / (double)n : NAN;
+            // numpy.median: mean of elements (n-1)//2 and n//2 of the sorted values
+            s_rank = n ? ((q & 1) ? n / 2 : (n - 1) / 2) : 0ull;
+        } else {
+            s_rank = S->rank[q];
+        }
+    }
+    unsigned int c[PER];
+    unsigned long long mine = 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if ((key & himask) == s_prefix[2 * r + q]) atomicAdd(&s_h[2 * r + q][digit], 1u);
+    for (int k = 0; k < PER; ++k) {
+        c[k] = S->hist[q][t * PER + k];
+        mine += c[k];
+        S->hist[q][t * PER + k] = 0u;
+    }
+    s_scan[t] = mine;
+    __syncthreads();
+    // exclusive prefix of the per-thread sums (256 values: a serial scan by thread 0 is 256 LDS reads)
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const unsigned long long v = s_scan[k];
+            s_scan[k] = run;
+            run += v;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * nreg * 256; i += blockDim.x) {
-        const unsigned int c = (&s_h[0][0])[i];
-        if (c) atomicAdd(&(&S->hist[0][0])[i], c);
-    }
-}
-
-// pick the bin holding the wanted rank, extend the prefix, clear the histograms for the next pass
-__global__ void select_pick_kernel(StatsState *S, int nreg, int pass) {
-    const int q = threadIdx.x;  // (region, statistic)
-    if (q < 2 * nreg) {
-        const int shift = 56 - 8 * pass;
-        unsigned long long rank = S->rank[q];
-        unsigned int d = 0;
-        for (; d < 255; ++d) {
-            const unsigned int c = S->hist[q][d];
-            if (rank < c) break;
-            rank -= c;
+    const unsigned long long rank = s_rank, before = s_scan[t];
+    const bool hit = rank >= before && rank < before + mine;
+    const bool beyond = t == 255 && rank >= before + mine;  // an empty region: ends in the last bin (its result is NaN anyway)
+    if (hit || beyond) {
+        unsigned long long left = rank - before;
+        int d = 0;
+        if (beyond) {
+            d = PER - 1;
+            left = 0;
+        } else {
+            for (; d < PER - 1; ++d) {
+                if (left < c[d]) break;
+                left -= c[d];
+            }
         }
-        S->rank[q] = rank;
-        S->prefix[q] |= (unsigned long long)d << shift;
+        S->rank[q] = left;
+        const unsigned long long p = pass == 0 ? 0ull : S->prefix[q];
+        S->prefix[q] = p | ((unsigned long long)(t * PER + d) << shift);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * kMaxR * 256; i += blockDim.x) (&S->hist[0][0])[i] = 0u;
 }
 
-__global__ void finish_kernel(const StatsState *S, int nreg, int f64, double *out) {
+// skipped_bits: the low key bits no pass looked at (float32 maps: fixed by the sign -- zeros for a positive value's key,
+// ones for a negative one's, whose key is the complement)
+__global__ void finish_kernel(const StatsState *S, int nreg, int f64, int skipped_bits, double *out) {
     const int r = threadIdx.x;
     if (r >= nreg) return;
     const unsigned long long n = S->count[r];
     out[4 * r + 0] = (double)n;
     out[4 * r + 1] = n ? S->mean[r] : NAN;
     out[4 * r + 2] = n ? sqrt(S->ssd[r] / (double)n) : NAN;
+    unsigned long long k0 = S->prefix[2 * r], k1 = S->prefix[2 * r + 1];
+    if (skipped_bits) {
+        const unsigned long long low = (1ull << skipped_bits) - 1ull;
+        if (!(k0 >> 63)) k0 |= low;  // key without the top bit = complemented negative value
+        if (!(k1 >> 63)) k1 |= low;
+    }
     // numpy.median of a float32 map averages the two middle elements in float32
-    double med = 0.5 * (key_value(S->prefix[2 * r]) + key_value(S->prefix[2 * r + 1]));
+    double med = 0.5 * (key_value(k0) + key_value(k1));
     if (!f64) med = (double)(float)med;
     out[4 * r + 3] = n ? med : NAN;
 }
@@ -264,14 +309,41 @@ hipError_t region_stats_launch(const void *values, int f64, const void *labels, 
     hipError_t e = hipMemsetAsync(S, 0, sizeof(StatsState), stream);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(moments_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, K, S);
-    hipLaunchKernelGGL(after_moments_kernel, dim3(1), dim3(64), 0, stream, S, nreg);
-    hipLaunchKernelGGL(moments_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, K, S);
-    for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, K, S, pass);
-        hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, stream, S, nreg, pass);
+    // digit width: 11 bits when the LDS histograms of all (region, statistic) pairs fit next to the other kernels' share
+    const bool wide = 2 * nreg * 2048 * 4 <= 96 * 1024;
+    const int bits = wide ? 11 : 8;
+    const size_t lds = (size_t)2 * nreg * (1u << bits) * 4;
+    // float32 maps: key bits 28..0 are fixed by the sign; passes that would only look at them are skipped
+    const int low_fixed = f64 ? 0 : 29;
+    int shift = 64, pass = 0, skipped = 0;
+    if (wide) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_hist_kernel<11, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_hist_kernel<11, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_hist_kernel<11, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, stream, S, nreg, f64, out_dev);
+    while (shift > 0) {
+        const int width = shift < bits ? shift : bits;  // (64 = 5 * 11 + 9: the last 11-bit digit is 9 bits wide, its top bins stay empty)
+        shift -= width;
+        if (shift + width <= low_fixed && pass >= 2) {  // nothing but fixed bits left (the two moment passes always run)
+            skipped = shift + width;
+            break;
+        }
+        const dim3 g(wide ? (unsigned)(blocks < 2LL * num_cu ? blocks : 2LL * num_cu) : (unsigned)blocks), b(wide ? 1024 : 256);
+        if (wide) {
+            if (pass == 0) hipLaunchKernelGGL((select_hist_kernel<11, 1>), g, b, lds, stream, K, S, pass, shift, width);
+            else if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<11, 2>), g, b, lds, stream, K, S, pass, shift, width);
+            else hipLaunchKernelGGL((select_hist_kernel<11, 0>), g, b, lds, stream, K, S, pass, shift, width);
+            hipLaunchKernelGGL(select_pick_kernel<11>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift);
+        } else {
+            if (pass == 0) hipLaunchKernelGGL((select_hist_kernel<8, 1>), g, b, lds, stream, K, S, pass, shift, width);
+            else if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<8, 2>), g, b, lds, stream, K, S, pass, shift, width);
+            else hipLaunchKernelGGL((select_hist_kernel<8, 0>), g, b, lds, stream, K, S, pass, shift, width);
+            hipLaunchKernelGGL(select_pick_kernel<8>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift);
+        }
+        ++pass;
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, stream, S, nreg, f64, skipped, out_dev);
     return hipGetLastError();
 }
 

@@ -283,3 +283,44 @@ def test_register_weights_kernel_layers(cin, cout, hw):
     cnt[0, 0] = cnt[0, -1] = cnt[-1, 0] = cnt[-1, -1] = 4.0
     assert np.array_equal(y[0, :, :, 0], cnt * cin * 2.0 ** -6)
     assert np.array_equal(y[0, :, :, cout - 1], cnt * cin * 2.0 ** -6)
+
+
+def test_first_and_last_block_fallback_routes():
+    """QMRI_ENC0=0 / QMRI_OUT0=0 (read once per process) send the first encoder block and the last convolution + classifier through
+    the general kernels (first-layer kernel + conv_s3_kernel + pooling kernel; conv_s3_kernel with the fused classifier) -- the
+    route sizes without 8 x 32 tiles take.  Same logits as the dedicated kernels, same distance from the restatement."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dosma_amd import _lib as L
+from oracle import unet_oracle as uo
+from tests.test_unet_gpu import weights_in_abi_order
+w = uo.make_weights(seed=11, bn="realistic")
+rng = np.random.default_rng(1)
+vol = (rng.standard_normal((3, 64, 96)) * 90 + 250).astype(np.float32)
+eng = L.Unet2dEngine(weights_in_abi_order(w), 64, 96, max_batch=3, precision="fp16x3")
+logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+tr = eng.trace()
+ref = uo.forward(w, uo.whiten_volume(vol.astype(np.float64)).astype(np.float32), dtype="float64")
+print("ERR", float(np.abs(logits - ref).max()), "TRACE", ",".join(tr))
+np.save(sys.argv[1], logits)
+''' % root
+    import tempfile
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("dedicated", {}), ("general", {"QMRI_ENC0": "0", "QMRI_OUT0": "0"})):
+            e = dict(os.environ, **env)
+            path = os.path.join(d, tag + ".npy")
+            txt = subprocess.check_output([sys.executable, "-c", code, path], env=e, cwd=root).decode()
+            line = [ln for ln in txt.splitlines() if ln.startswith("ERR")][-1]
+            out[tag] = (float(line.split()[1]), line.split("TRACE", 1)[1], np.load(path))
+    assert "down0:enc0" in out["dedicated"][1] and "up0.conv2:out0+head" in out["dedicated"][1]
+    assert "down0.conv1:c1/split" in out["general"][1] and "up0.conv2:s3/2d/bn32+head" in out["general"][1]
+    assert out["dedicated"][0] < 1e-3 and out["general"][0] < 1e-3
+    assert np.abs(out["dedicated"][2] - out["general"][2]).max() < 2e-4

@@ -274,13 +274,15 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                 *reinterpret_cast<uint4 *>(ybase + (long long)px * A.ldy * 4 + p8 * 16) = v[t];
             }
         }
-        if (wave < kWaves / 2) {
-            // MaxPooling2D(2 x 2): pooled row wave <- staged rows 2 wave, 2 wave + 1; lane = (pooled pixel, 8-channel group)
+        if (wave >= kWaves / 2) {
+            // MaxPooling2D(2 x 2) by the waves that had ONE halo group of the first convolution above (waves 0-2 had two):
+            // pooled row prow_w <- staged rows 2 prow_w, 2 prow_w + 1; lane = (pooled pixel, 8-channel group)
+            const int prow_w = wave - kWaves / 2;
             const int pp = lane >> 2, g = lane & 3;
             float m[8];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const unsigned char *w2 = stage + (2 * wave + (s >> 1)) * 4096;
+                const unsigned char *w2 = stage + (2 * prow_w + (s >> 1)) * 4096;
                 const int px = 2 * pp + (s & 1);
                 const uint4 hi = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, g));
                 const uint4 lo = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, 4 + g));
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             unsigned h[4], l[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) split2(m[2 * i], m[2 * i + 1], h[i], l[i]);
-            const long long prow = ((long long)t_b * (A.H / 2) + (t_y0 / 2) + wave) * (A.W / 2) + (t_x0 / 2) + pp;
+            const long long prow = ((long long)t_b * (A.H / 2) + (t_y0 / 2) + prow_w) * (A.W / 2) + (t_x0 / 2) + pp;
             unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + prow * A.pool_ld * 4 + g * 16;
             *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l[0], l[1], l[2], l[3]);

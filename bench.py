@@ -332,8 +332,25 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
                      "note": "achieved = ALGORITHMIC flops (70.79 GFLOP per slice); the parity mode issues 3 MFMAs per "
                              "product, so the matrix pipes are busy 3x that fraction (mfma_issued_frac)",
                      "bf16_mode": {"achieved": tf16, "frac": tf16 / MFMA_BF16_PEAK_TFLOPS},
-                     "traffic": None},
+                     **_unet_traffic()},
     }
+
+
+def _unet_traffic():
+    """HBM bytes of one 160-slice forward in the parity mode: a constant from the last rocprofv3 --pmc collection
+    (scripts/collect_profile.sh -> profiles/<tag>_unet_counters.json), not re-measured by this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_unet_counters.json")), reverse=True):
+        try:
+            hbm = json.load(open(path)).get("hbm")
+        except (OSError, ValueError):
+            continue
+        if hbm:
+            return {"traffic": hbm["bytes_per_forward"],
+                    "traffic_source": {"file": os.path.relpath(path, ROOT), "per": "160-slice forward (one step of this leg)",
+                                       "kind": "constant from a rocprofv3 --pmc collection (FETCH_SIZE doubled per the gfx950 "
+                                               "correction + WRITE_SIZE), not re-measured by this run"}}
+    return {"traffic": None}
 
 
 def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):

@@ -15,4 +15,6 @@ tail -c 600 $OUT/bench.json
 # ---- UNet2D leg: per-layer kernel trace + MFMA counters of scripts/prof_unet.py in the parity mode (fp16x3, one 160-slice volume) ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unet_stats -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_stats.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/unet_pmc -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_pmc.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/unet_fetch -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/unet_write -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_write.log 2>&1
 python $R/bench.py --print-kernel-hash > $OUT/kernel_hash.txt

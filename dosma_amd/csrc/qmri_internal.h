@@ -151,6 +151,23 @@ size_t out0_lds_bytes();
 bool out0_supported(const Out0Args &k);
 hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream);
 
+// Conv2D(64 -> 32, 3x3) + ReLU with LDS-resident weights (unet_enc0.hip: mid0_kernel).
+struct Mid0Args {
+    const void *x;         // 64-channel input (split layout), pixel stride ldx channels, channel offset xoff
+    long long ldx;
+    int xoff;
+    int B, H, W;           // H % 8 == 0, W % 32 == 0
+    const void *w;         // conv_s3_kernel's weight image for 64 -> 32 channels (2 x 9 x 4096 B)
+    float winv;
+    const float *bias;     // [32]
+    void *y;               // 32-channel output (split layout), pixel stride ldy channels, channel offset yoff
+    long long ldy;
+    int yoff;
+};
+size_t mid0_lds_bytes();
+bool mid0_supported(const Mid0Args &k);
+hipError_t mid0_launch(const Mid0Args &k, int num_cu, hipStream_t stream);
+
 // Kernel-argument block of the implicit-GEMM convolution (unet_kernels.hip).
 struct ConvKArgs {
     const void *x;       // NHWC input (fp32, or bf16 in plain-bf16 mode), pixel stride ldx (elements), channel offset xoff

@@ -407,19 +407,21 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         y0 = ty * kO_Waves;
         x0 = (r - ty * tiles_x) * 32;
     };
+    // source address of this wave's request i for a tile (zero line outside the slice), and the request itself
+    auto halo_src = [&](int b, int y0, int x0, int i) -> const unsigned char * {
+        const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
+        const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+        return ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff) * 4 + d_src[i] : zero_line;
+    };
+    auto issue = [&](const unsigned char *src, int i, int buf) {
+        const int j = wave + kO_Waves * i;
+        if (j < kO_NJ) dma16(src, halo_lds + (unsigned)(buf * kO_HaloBytes + j * 1024));  // (wave-uniform condition)
+    };
     auto request_halo = [&](int t, int buf) {
         int b, y0, x0;
-        tile_origin(t, b, y0, x0);
+        tile_origin(t, b, y0, x0);  // (once per tile: two integer divisions)
 #pragma unroll
-        for (int i = 0; i < kO_PerWave; ++i) {
-            const int j = wave + kO_Waves * i;
-            if (j < kO_NJ) {  // (wave-uniform)
-                const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
-                const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-                const unsigned char *src = ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff) * 4 + d_src[i] : zero_line;
-                dma16(src, halo_lds + (unsigned)(buf * kO_HaloBytes + j * 1024));
-            }
-        }
+        for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(b, y0, x0, i), i, buf);
     };
 
     int tile = blockIdx.x;
@@ -436,8 +438,10 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
 #endif
     while (true) {
         const int next = tile + gridDim.x;
-        if (next < ntiles) request_halo(next, buf ^ 1);  // lands while this tile is multiplied
-        ENC0_T(0)
+        // the next tile's halo: requested in front of the MFMA loop.  (From INSIDE the loop, one request every three half-steps,
+        // measured 1.55 instead of 1.40 ms: the request statement is a memory barrier for hipcc and cuts the LDS read pipeline.)
+        const bool more = next < ntiles;
+        if (more) request_halo(next, buf ^ 1);
         const unsigned char *hb = halo + buf * kO_HaloBytes;
 
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -528,6 +532,175 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mid0_kernel -- Conv2D(64 -> 32, 3x3) + ReLU on the 384^2-class level (the first convolution after the top concatenation,
+// oaiunet2d.py:266-276), same skeleton with TWO input chunks: 73 KB of LDS-resident weights + one halo buffer per chunk
+// (2 x 43 KB) fill the CU's LDS, so the buffers rotate by chunk, not by tile: chunk 0 of tile t + 1 is requested in front of
+// the MFMA loop of chunk 1 of tile t, chunk 1 of tile t + 1 in front of the loop of its chunk 0 -- after the epilogue of tile t, which
+// stages the output tile in the chunk-1 buffer.  Waits are counted (the 4 output stores of a wave stay in flight).
+constexpr int kM_Chunks = 2;
+
+__global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *wlds = smem;                                  // [chunk][tap] x 4096 B
+    unsigned char *halo = wlds + kM_Chunks * kWBytes;            // buffer c = chunk c of the current (or next) tile
+    float *prm = reinterpret_cast<float *>(halo + kM_Chunks * kO_HaloBytes);  // bias [32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kgrp = lane >> 5;
+
+    for (int i = tid; i < kM_Chunks * kWBytes / 16; i += kO_Threads)
+        reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
+    float pb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pb[e] = A.bias[(e & 3) + 8 * (e >> 2) + 4 * kgrp];
+    const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
+    const int hp0 = (wave + 1) * kPitch + l31 + 1;
+    int boff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
+
+    int d_yx[kO_PerWave], d_src[kO_PerWave];
+#pragma unroll
+    for (int i = 0; i < kO_PerWave; ++i) {
+        const int j = wave + kO_Waves * i;
+        const int hp = j * 8 + (lane >> 3), p8 = lane & 7;
+        const int plane = (p8 >> 2) ^ ((hp >> 1) & 1), q = (p8 & 3) ^ ((hp >> 2) & 3);
+        const int hy = hp / kPitch, hx = hp - hy * kPitch;
+        d_yx[i] = (j < kO_NJ && hp < kO_Halo) ? (hy | (hx << 8)) : -1;
+        d_src[i] = plane * 64 + q * 16;
+    }
+    const unsigned halo_lds = lds_off(halo);
+    const unsigned char *zero_line = reinterpret_cast<const unsigned char *>(&g_zero16_out0);
+    const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
+
+    const int tiles_x = A.W / 32, tiles_y = A.H / kO_Waves;
+    const int per_img = tiles_x * tiles_y;
+    const int ntiles = A.B * per_img;
+    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
+        b = t / per_img;
+        const int r = t - b * per_img;
+        const int ty = r / tiles_x;
+        y0 = ty * kO_Waves;
+        x0 = (r - ty * tiles_x) * 32;
+    };
+    auto halo_src = [&](int b, int y0, int x0, int chunk, int i) -> const unsigned char * {  // this wave's request i of a chunk
+        const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
+        const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
+        return ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff + chunk * 32) * 4 + d_src[i] : zero_line;
+    };
+    auto issue = [&](const unsigned char *src, int i, int chunk) {  // -> buffer `chunk`
+        const int j = wave + kO_Waves * i;
+        if (j < kO_NJ) dma16(src, halo_lds + (unsigned)(chunk * kO_HaloBytes + j * 1024));
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int t_b, t_y0, t_x0;
+    tile_origin(tile, t_b, t_y0, t_x0);
+#pragma unroll
+    for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(t_b, t_y0, t_x0, 0, i), i, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (first tile: chunk 0 before anything else)
+
+    while (true) {
+        const int next = tile + gridDim.x;
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        struct Frag {
+            f16x8 wh, wl, xh, xl;
+        };
+        auto mma = [&](const Frag &f) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl, f.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xl, acc, 0, 0, 0);
+        };
+        // the MFMA loop of chunk c carries the requests of the buffer that is free meanwhile: chunk 1 of THIS tile during chunk 0
+        // (buffer 1 was the staging area of the previous tile's epilogue), chunk 0 of the NEXT tile during chunk 1
+        auto chunk_mfma = [&](int c, const unsigned char *const (&rsrc)[kO_PerWave], bool req) {
+            const unsigned char *hb = halo + c * kO_HaloBytes;
+            const unsigned char *wb = wlds + c * kWBytes;
+            auto load_frag = [&](Frag &f, int t, int kk) {
+                const unsigned char *wt = wb + t * 4096 + (woff ^ (kk * 32));
+                const int o = boff[t] ^ (kk * 32);
+                f.wh = *reinterpret_cast<const f16x8 *>(wt);
+                f.xh = *reinterpret_cast<const f16x8 *>(hb + o);
+                f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
+                f.xl = *reinterpret_cast<const f16x8 *>(hb + (o ^ 64));
+            };
+            if (req) {  // (in front of the loop: a request inside it is a memory barrier for hipcc and cuts the LDS read pipeline)
+#pragma unroll
+                for (int i = 0; i < kO_PerWave; ++i) issue(rsrc[i], i, c ^ 1);
+            }
+            Frag f[3];
+            load_frag(f[0], 0, 0);
+            load_frag(f[1], 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 18; ++h) {
+                if (h + 2 < 18) load_frag(f[(h + 2) % 3], (h + 2) / 2, (h + 2) % 2);
+                mma(f[h % 3]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        };
+        const unsigned char *r1[kO_PerWave], *r0[kO_PerWave];
+#pragma unroll
+        for (int i = 0; i < kO_PerWave; ++i) r1[i] = halo_src(t_b, t_y0, t_x0, 1, i);
+        chunk_mfma(0, r1, true);
+        // chunk 1 of this tile has landed (nothing newer is in this wave's queue); everyone is done with buffer 0
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool more = next < ntiles;
+        int n_b = t_b, n_y0 = t_y0, n_x0 = t_x0;
+        if (more) tile_origin(next, n_b, n_y0, n_x0);
+#pragma unroll
+        for (int i = 0; i < kO_PerWave; ++i) r0[i] = halo_src(n_b, n_y0, n_x0, 0, i);
+        chunk_mfma(1, r0, more);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done with buffer 1: it becomes the staging area
+
+        // ---- bias, ReLU, split; [pixel][hi | lo] image in this wave's window of buffer 1; 128-byte pixel-chunk stores ----
+        unsigned char *win = halo + kO_HaloBytes + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(acc[4 * q + i], A.winv, pb[4 * q + i]), 0.f);
+            unsigned h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const long long row = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0;
+            unsigned char *ybase = static_cast<unsigned char *>(A.y) + (row * A.ldy + A.yoff) * 4;
+            const int px0 = lane >> 3, pos = lane & 7;
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(win + (px0) * 128 + pos * 16);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(win + (px0 + 8) * 128 + pos * 16);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(win + (px0 + 16) * 128 + pos * 16);
+            const uint4 v3 = *reinterpret_cast<const uint4 *>(win + (px0 + 24) * 128 + pos * 16);
+            // (px >> 1) & 7 of px = px0 + 8 t: ((px0 >> 1) + 4 t) & 7
+            *reinterpret_cast<uint4 *>(ybase + (long long)(px0) * A.ldy * 4 + ((pos ^ ((px0 >> 1) & 7)) * 16)) = v0;
+            *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 8) * A.ldy * 4 + ((pos ^ (((px0 >> 1) + 4) & 7)) * 16)) = v1;
+            *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 16) * A.ldy * 4 + ((pos ^ ((px0 >> 1) & 7)) * 16)) = v2;
+            *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 24) * A.ldy * 4 + ((pos ^ (((px0 >> 1) + 4) & 7)) * 16)) = v3;
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        t_b = n_b;
+        t_y0 = n_y0;
+        t_x0 = n_x0;
+        // every wave has read its staging window back (buffer 1 may be requested into again), and chunk 0 of the new tile has
+        // landed: in this wave's queue it is followed only by the 4 output stores, which stay in flight
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 // (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
@@ -561,6 +734,22 @@ hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream) {
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
     hipLaunchKernelGGL(out0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
+    return hipGetLastError();
+}
+
+size_t mid0_lds_bytes() { return (size_t)kM_Chunks * kWBytes + (size_t)kM_Chunks * kO_HaloBytes + 32 * 4; }
+
+bool mid0_supported(const Mid0Args &k) { return k.H % kO_Waves == 0 && k.W % 32 == 0 && k.B > 0; }
+
+hipError_t mid0_launch(const Mid0Args &k, int num_cu, hipStream_t stream) {
+    if (!mid0_supported(k)) return hipErrorInvalidValue;
+    const size_t lds = mid0_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mid0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const long long ntiles = (long long)k.B * (k.H / kO_Waves) * (k.W / 32);
+    const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(mid0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
     return hipGetLastError();
 }
 

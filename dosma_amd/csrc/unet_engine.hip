@@ -668,7 +668,21 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
         }
         void *t1 = U->tmp[l]->p;
         snprintf(nm, sizeof(nm), "up%d.conv1", l);
-        int rc = conv3x3_parity(U, nm, *U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, nullptr, 0, false, nullptr, nullptr, st);
+        int rc = QMRI_OK;
+        // 64 -> 32 channels at the top level with LDS-resident weights (QMRI_MID0=0: conv_s3_kernel)
+        static const bool want_mid0 = !(std::getenv("QMRI_MID0") && std::atoi(std::getenv("QMRI_MID0")) == 0);
+        if (l == 0 && want_mid0 && C == 32 && U->up1[0]->w_s3.p && !U->up1[0]->has_affine && U->up1[0]->relu && H % 8 == 0 && W % 32 == 0) {
+            const ConvLayer &L1 = *U->up1[0];
+            qmri::Mid0Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.x = cat; k.ldx = 2 * C; k.xoff = 0; k.B = Bt; k.H = H; k.W = W;
+            k.w = L1.w_s3.p; k.winv = L1.winv; k.bias = L1.bias.as<float>();
+            k.y = t1; k.ldy = C; k.yoff = 0;
+            U_TRY(qmri::mid0_launch(k, U->num_cu, st));
+            U->trace += "up0.conv1:mid0;";
+        } else {
+            rc = conv3x3_parity(U, nm, *U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, nullptr, 0, false, nullptr, nullptr, st);
+        }
         if (rc != QMRI_OK) return rc;
         void *out = U->upout[l]->p;
         snprintf(nm, sizeof(nm), "up%d.conv2", l);

@@ -47,7 +47,7 @@ def _expect_families(trace, H, W):
         wl = W >> lvl
         fam = "s3/2d" if wl % 32 == 0 else ("s3/flat" if wl + 2 <= 50 else "igemm")
         for name in (([f"down{lvl}.conv2"] if lvl or not fused0 else []) + ([f"down{lvl}.conv1"] if lvl else [])
-                     + ([f"up{lvl}.conv1"] if lvl < 5 else []) + ([f"up{lvl}.conv2"] if lvl < 5 and (lvl or not fused0) else [])):
+                     + ([f"up{lvl}.conv1", f"up{lvl}.conv2"] if lvl < 5 and (lvl or not fused0) else [])):
             assert by[name].startswith(fam), (name, by[name], fam)
         if lvl < 5:  # the transposed convolution tiles the INPUT grid (level lvl + 1)
             win = W >> (lvl + 1)
@@ -55,6 +55,7 @@ def _expect_families(trace, H, W):
             assert by[f"up{lvl}.deconv"].startswith(famd), (lvl, by[f"up{lvl}.deconv"], famd)
     assert (by["down0"] == "enc0") if fused0 else (by["down0.conv1"] == "c1/split")
     assert by["up0.conv2"] == ("out0+head" if fused0 else by["up0.conv2"]) and by["up0.conv2"].endswith("+head")  # never goes to HBM
+    assert by["up0.conv1"] == ("mid0" if fused0 else by["up0.conv1"])
     assert by["down1.conv2"].endswith("+pool") and by["down2.conv2"].endswith("+pool")
 
 
@@ -71,7 +72,7 @@ def test_384_logits_parity_mode(net, ref384, max_batch):
     tr = eng.trace()
     _expect_families(tr, 384, 384)
     fams = {t.split(":", 1)[1].split("+")[0] for t in tr if t.startswith(("down", "up")) and "conv" in t and "deconv" not in t}
-    assert {"s3/2d/bn32", "s3/2d/bn64", "s3/2d/bn128", "s3/flat/bn128"} <= fams, fams
+    assert {"mid0", "out0", "s3/2d/bn64", "s3/2d/bn128", "s3/flat/bn128"} <= fams, fams
     eng.close()
 
 

@@ -286,7 +286,7 @@ def test_register_weights_kernel_layers(cin, cout, hw):
 
 
 def test_first_and_last_block_fallback_routes():
-    """QMRI_ENC0=0 / QMRI_OUT0=0 (read once per process) send the first encoder block and the last convolution + classifier through
+    """QMRI_ENC0=0 / QMRI_MID0=0 / QMRI_OUT0=0 (read once per process) send the first encoder block and the last convolution + classifier through
     the general kernels (first-layer kernel + conv_s3_kernel + pooling kernel; conv_s3_kernel with the fused classifier) -- the
     route sizes without 8 x 32 tiles take.  Same logits as the dedicated kernels, same distance from the restatement."""
     import os
@@ -314,13 +314,14 @@ np.save(sys.argv[1], logits)
 
     out = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("dedicated", {}), ("general", {"QMRI_ENC0": "0", "QMRI_OUT0": "0"})):
+        for tag, env in (("dedicated", {}), ("general", {"QMRI_ENC0": "0", "QMRI_OUT0": "0", "QMRI_MID0": "0"})):
             e = dict(os.environ, **env)
             path = os.path.join(d, tag + ".npy")
             txt = subprocess.check_output([sys.executable, "-c", code, path], env=e, cwd=root).decode()
             line = [ln for ln in txt.splitlines() if ln.startswith("ERR")][-1]
             out[tag] = (float(line.split()[1]), line.split("TRACE", 1)[1], np.load(path))
-    assert "down0:enc0" in out["dedicated"][1] and "up0.conv2:out0+head" in out["dedicated"][1]
+    assert "down0:enc0" in out["dedicated"][1] and "up0.conv2:out0+head" in out["dedicated"][1] and "up0.conv1:mid0" in out["dedicated"][1]
     assert "down0.conv1:c1/split" in out["general"][1] and "up0.conv2:s3/2d/bn32+head" in out["general"][1]
+    assert "up0.conv1:s3/2d/bn32" in out["general"][1]
     assert out["dedicated"][0] < 1e-3 and out["general"][0] < 1e-3
     assert np.abs(out["dedicated"][2] - out["general"][2]).max() < 2e-4

@@ -383,7 +383,10 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
 
     // this lane's share of the halo requests: instruction j = wave + 8 i moves pixels 8 j .. 8 j + 7, lane = (pixel, piece);
     // the swizzle of the LDS image lives on the SOURCE address (the DMA writes lane * 16 linearly)
-    int d_yx[kO_PerWave], d_src[kO_PerWave];
+    // per piece, once per kernel: halo row / column, and the byte offset of the piece's 16 source bytes relative to the tile's
+    // first pixel (the tile origin is wave-uniform: a request costs two 64-bit adds and a border test, not a chain of 64-bit mads)
+    int d_yx[kO_PerWave];
+    long long d_rel[kO_PerWave];
 #pragma unroll
     for (int i = 0; i < kO_PerWave; ++i) {
         const int j = wave + kO_Waves * i;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         const int plane = (p8 >> 2) ^ ((hp >> 1) & 1), q = (p8 & 3) ^ ((hp >> 2) & 3);
         const int hy = hp / kPitch, hx = hp - hy * kPitch;
         d_yx[i] = (j < kO_NJ && hp < kO_Halo) ? (hy | (hx << 8)) : -1;
-        d_src[i] = plane * 64 + q * 16;
+        d_rel[i] = ((long long)(hy - 1) * A.W + (hx - 1)) * A.ldx * 4 + plane * 64 + q * 16;
     }
     const unsigned halo_lds = lds_off(halo);
     const unsigned char *zero_line = reinterpret_cast<const unsigned char *>(&g_zero16_out0);
@@ -408,10 +411,10 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         x0 = (r - ty * tiles_x) * 32;
     };
     // source address of this wave's request i for a tile (zero line outside the slice), and the request itself
-    auto halo_src = [&](int b, int y0, int x0, int i) -> const unsigned char * {
+    auto halo_src = [&](const unsigned char *origin, int y0, int x0, int i) -> const unsigned char * {
         const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
         const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-        return ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff) * 4 + d_src[i] : zero_line;
+        return ok ? origin + d_rel[i] : zero_line;
     };
     auto issue = [&](const unsigned char *src, int i, int buf) {
         const int j = wave + kO_Waves * i;
@@ -420,8 +423,9 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
     auto request_halo = [&](int t, int buf) {
         int b, y0, x0;
         tile_origin(t, b, y0, x0);  // (once per tile: two integer divisions)
+        const unsigned char *origin = xbase + ((((long long)b * A.H + y0) * A.W + x0) * A.ldx + A.xoff) * 4;
 #pragma unroll
-        for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(b, y0, x0, i), i, buf);
+        for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(origin, y0, x0, i), i, buf);
     };
 
     int tile = blockIdx.x;
@@ -563,7 +567,8 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
 
-    int d_yx[kO_PerWave], d_src[kO_PerWave];
+    int d_yx[kO_PerWave];
+    long long d_rel[kO_PerWave];  // (see out0_kernel)
 #pragma unroll
     for (int i = 0; i < kO_PerWave; ++i) {
         const int j = wave + kO_Waves * i;
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         const int plane = (p8 >> 2) ^ ((hp >> 1) & 1), q = (p8 & 3) ^ ((hp >> 2) & 3);
         const int hy = hp / kPitch, hx = hp - hy * kPitch;
         d_yx[i] = (j < kO_NJ && hp < kO_Halo) ? (hy | (hx << 8)) : -1;
-        d_src[i] = plane * 64 + q * 16;
+        d_rel[i] = ((long long)(hy - 1) * A.W + (hx - 1)) * A.ldx * 4 + plane * 64 + q * 16;
     }
     const unsigned halo_lds = lds_off(halo);
     const unsigned char *zero_line = reinterpret_cast<const unsigned char *>(&g_zero16_out0);
@@ -587,10 +592,13 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         y0 = ty * kO_Waves;
         x0 = (r - ty * tiles_x) * 32;
     };
-    auto halo_src = [&](int b, int y0, int x0, int chunk, int i) -> const unsigned char * {  // this wave's request i of a chunk
+    auto halo_src = [&](const unsigned char *origin, int y0, int x0, int i) -> const unsigned char * {  // origin: tile + chunk
         const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
         const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-        return ok ? xbase + ((((long long)b * A.H + yy) * A.W + xx) * A.ldx + A.xoff + chunk * 32) * 4 + d_src[i] : zero_line;
+        return ok ? origin + d_rel[i] : zero_line;
+    };
+    auto chunk_origin = [&](int b, int y0, int x0, int chunk) -> const unsigned char * {
+        return xbase + ((((long long)b * A.H + y0) * A.W + x0) * A.ldx + A.xoff + chunk * 32) * 4;
     };
     auto issue = [&](const unsigned char *src, int i, int chunk) {  // -> buffer `chunk`
         const int j = wave + kO_Waves * i;
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
     int t_b, t_y0, t_x0;
     tile_origin(tile, t_b, t_y0, t_x0);
 #pragma unroll
-    for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(t_b, t_y0, t_x0, 0, i), i, 0);
+    for (int i = 0; i < kO_PerWave; ++i) issue(halo_src(chunk_origin(t_b, t_y0, t_x0, 0), t_y0, t_x0, i), i, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (first tile: chunk 0 before anything else)
 
     while (true) {
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         };
         const unsigned char *r1[kO_PerWave], *r0[kO_PerWave];
 #pragma unroll
-        for (int i = 0; i < kO_PerWave; ++i) r1[i] = halo_src(t_b, t_y0, t_x0, 1, i);
+        for (int i = 0; i < kO_PerWave; ++i) r1[i] = halo_src(chunk_origin(t_b, t_y0, t_x0, 1), t_y0, t_x0, i);
         chunk_mfma(0, r1, true);
         // chunk 1 of this tile has landed (nothing newer is in this wave's queue); everyone is done with buffer 0
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         int n_b = t_b, n_y0 = t_y0, n_x0 = t_x0;
         if (more) tile_origin(next, n_b, n_y0, n_x0);
 #pragma unroll
-        for (int i = 0; i < kO_PerWave; ++i) r0[i] = halo_src(n_b, n_y0, n_x0, 0, i);
+        for (int i = 0; i < kO_PerWave; ++i) r0[i] = halo_src(chunk_origin(n_b, n_y0, n_x0, 0), n_y0, n_x0, i);
         chunk_mfma(1, r0, more);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done with buffer 1: it becomes the staging area
 

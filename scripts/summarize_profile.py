@@ -69,15 +69,15 @@ if os.path.exists(ut):
         "# rocprofv3 --kernel-trace of scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160: last forward\n"
         "# TF = ALGORITHMIC flops of the layer / kernel time (the parity mode issues 3 MFMAs per product)\n" + layers)
     rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
-            if any(k in r["Kernel_Name"] for k in ("conv_s3_kernel", "enc0_kernel", "out0_kernel"))]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # per forward: enc0 + 18 convolutions + 5 transposed + out0
+            if any(k in r["Kernel_Name"] for k in ("conv_s3_kernel", "enc0_kernel", "mid0_kernel", "out0_kernel"))]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # per forward: enc0 + 17 convolutions + 5 transposed + mid0 + out0
     agg = collections.Counter()
     for r in rows:
         if int(r["Dispatch_Id"]) in ids:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
     cycles = agg["SQ_BUSY_CYCLES"] / 32  # summed over the 32 shader engines
     u = {"tag": tag, "workload": "UNet2D forward, 160 slices of 384x384, parity mode fp16x3: the 25 MFMA-kernel dispatches of one forward "
-                                 "(enc0_kernel, 23 x conv_s3_kernel, out0_kernel)",
+                                 "(enc0_kernel, 22 x conv_s3_kernel, mid0_kernel, out0_kernel)",
          "counters": dict(agg),
          "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
          "mfma_instructions": agg["SQ_INSTS_MFMA"],

@@ -309,11 +309,11 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         t_b = n_b;
         t_y0 = n_y0;
         t_x0 = n_x0;
-        S_BARRIER();  // C:
+        S_BARRIER();  // C: halo image of the next tile complete
         ENC0_T(5)
 #ifdef QMRI_S3_EXPERIMENTS
         tacc[6] += 1;
-#endif halo image of the next tile complete
+#endif
     }
 #ifdef QMRI_S3_EXPERIMENTS
     if (tid == 0)

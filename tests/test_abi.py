@@ -167,4 +167,4 @@ def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
     assert m0, "expected the DMA statements' M0 writes in the assembly"
     others = [ln for ln in m0 if not ln.startswith("s_mov_b32 m0,")]
     assert not others, others[:5]
-    assert sum("global_load_lds_dwordx4" in ln for ln in lines) >= min_dma
+    assert sum("global_load_lds_dwordx4" in ln or ("buffer_load_dwordx4" in ln and ln.rstrip().endswith("lds")) for ln in lines) >= min_dma

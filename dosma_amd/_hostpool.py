@@ -1,0 +1,110 @@
+"""Result arrays in page-locked host memory, recycled.
+
+The reference returns freshly allocated numpy arrays (``dosma/core/fitting.py:205-215``: ``np.full`` + scatter).  On the
+GPU path a fresh 0.7 GB result costs more than the fit: the operating system zero-fills every page on first touch
+(65 ms per GB on the benchmark host) and the download has to go through a staging buffer.  Here large
+results live in ``hipHostMalloc`` memory handed out by ``empty()``: the pages are resident and the copy is a true DMA.  A
+block goes back to the free list when the last numpy view of it is garbage-collected (a ``weakref`` finalizer on the
+exporting buffer object), so callers own their results exactly as before; nothing is ever overwritten under them.
+
+``DOSMA_AMD_HOST_POOL_GB`` (default 16; 0 switches the pool off) bounds the bytes kept on the free list.
+"""
+import atexit
+import ctypes
+import os
+import threading
+import weakref
+
+import numpy as np
+
+_MIN_BYTES = 1 << 20        # smaller arrays: plain numpy
+_GRANULE = 2 << 20          # size classes of 2 MB
+_lock = threading.Lock()
+_free = {}                  # size -> [pointers]
+_cached = 0
+_closed = False
+
+
+def _cap():
+    try:
+        return int(float(os.environ.get("DOSMA_AMD_HOST_POOL_GB", "16")) * (1 << 30))
+    except ValueError:
+        return 16 << 30
+
+
+def _release(ptr, size):
+    global _cached
+    if _closed:             # interpreter shutdown: the HIP runtime may be gone; the process is about to release everything
+        return
+    with _lock:
+        if _cached + size <= _cap():
+            _free.setdefault(size, []).append(ptr)
+            _cached += size
+            return
+    try:
+        from dosma_amd import _lib
+        _lib.load().qmri_host_free(ctypes.c_void_p(ptr))
+    except Exception:       # pragma: no cover - nothing sensible to do in a finalizer
+        pass
+
+
+def _take(size):
+    global _cached
+    with _lock:
+        lst = _free.get(size)
+        if lst:
+            _cached -= size
+            return lst.pop()
+    return None
+
+
+def empty(shape, dtype):
+    """``numpy.empty(shape, dtype)`` in page-locked memory (plain numpy for small arrays, without a GPU, or when the
+    allocation fails)."""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    count = 1
+    for s in shape:
+        count *= s
+    nbytes = count * dt.itemsize
+    if nbytes < _MIN_BYTES or _closed or _cap() <= 0:
+        return np.empty(shape, dt)
+    size = (nbytes + _GRANULE - 1) // _GRANULE * _GRANULE
+    ptr = _take(size)
+    if ptr is None:
+        try:
+            from dosma_amd import _lib
+            lib = _lib.load()
+            out = ctypes.c_void_p()
+            if lib.qmri_device_count() <= 0 or lib.qmri_host_alloc(size, ctypes.byref(out)) != 0 or not out.value:
+                return np.empty(shape, dt)
+            ptr = out.value
+        except Exception:
+            return np.empty(shape, dt)
+    buf = (ctypes.c_ubyte * size).from_address(ptr)
+    weakref.finalize(buf, _release, ptr, size)
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+def trim():
+    """Return every cached block to the system (tests, long-running services between jobs)."""
+    global _cached
+    with _lock:
+        blocks = [(p, s) for s, lst in _free.items() for p in lst]
+        _free.clear()
+        _cached = 0
+    if blocks:
+        from dosma_amd import _lib
+        lib = _lib.load()
+        for p, _ in blocks:
+            lib.qmri_host_free(ctypes.c_void_p(p))
+
+
+def cached_bytes():
+    return _cached
+
+
+@atexit.register
+def _shutdown():
+    global _closed
+    _closed = True

@@ -156,7 +156,7 @@ EXPORTS = (
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
-    "qmri_region_stats_device",
+    "qmri_region_stats_device", "qmri_host_alloc", "qmri_host_free",
 )
 
 _lib = None
@@ -225,6 +225,10 @@ def load():
         _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(_SO)
         lib.qmri_version.restype = ctypes.c_int
+        lib.qmri_host_alloc.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+        lib.qmri_host_alloc.restype = ctypes.c_int
+        lib.qmri_host_free.argtypes = [ctypes.c_void_p]
+        lib.qmri_host_free.restype = ctypes.c_int
         lib.qmri_device_count.restype = ctypes.c_int
         lib.qmri_last_error.restype = ctypes.c_char_p
         lib.qmri_monoexp_kernel_name.restype = ctypes.c_char_p
@@ -424,12 +428,13 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
     if not want_popt and not want_tc:
         raise ValueError("nothing to return: want_popt=False needs want_tc=True")
-    if out is None:
-        out = {"r2": np.empty(N, dtype=od)}
+    if out is None:  # page-locked, recycled blocks for large results (no first-touch zeroing, true DMA): _hostpool.py
+        from dosma_amd import _hostpool
+        out = {"r2": _hostpool.empty(N, od)}
         if want_popt:
-            out["popt"] = np.empty((N, 2), dtype=od)
+            out["popt"] = _hostpool.empty((N, 2), od)
         if want_tc:
-            out["tc"] = np.empty(N, dtype=od)
+            out["tc"] = _hostpool.empty(N, od)
     else:  # reuse of a previous call's result arrays (no first-touch cost)
         need = {"r2": (N,)}
         if want_popt:
@@ -654,7 +659,8 @@ class Unet2dEngine:
         if v.ndim != 3 or v.shape[:2] != (self.H, self.W):
             raise ValueError(f"volume is {v.shape}, model was built for slices of {(self.H, self.W)}")
         S = v.shape[2]
-        out = np.empty((self.n_classes, self.H, self.W, S), np.uint8)
+        from dosma_amd import _hostpool
+        out = _hostpool.empty((self.n_classes, self.H, self.W, S), np.uint8)
         check(self._lib.qmri_unet2d_segment_volume(self._handle, _ptr(v), S, 1 if whiten else 0, float(eps),
                                                    _ptr(out), None))
         return out

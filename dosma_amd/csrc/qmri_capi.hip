@@ -261,6 +261,18 @@ int qmri_device_count(void) {
     return n;
 }
 
+int qmri_host_alloc(uint64_t bytes, void **out) {
+    if (!out || bytes == 0) return fail(QMRI_ERR_ARG, "qmri_host_alloc: NULL result pointer or zero bytes");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return QMRI_OK;
+}
+
+int qmri_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return QMRI_OK;
+}
+
 void qmri_set_timing(int enable) { g_timing = enable; }
 float qmri_last_kernel_ms(void) { return g_last_ms; }
 

@@ -375,6 +375,12 @@ int qmri_region_stats_device(const qmri_region_stats_args *args, void *hip_strea
 void qmri_set_timing(int enable);
 float qmri_last_kernel_ms(void);
 
+/* Page-locked host memory for result arrays (dosma_amd/_hostpool.py recycles it): resident pages -- no first-touch
+ * zeroing when a freshly allocated result is written (65 ms per GB on the reference host) -- and a true DMA target.
+ * The reference has no counterpart (numpy allocates its results, dosma/core/fitting.py:205-215). */
+int qmri_host_alloc(uint64_t bytes, void **out);
+int qmri_host_free(void *p);
+
 int qmri_version(void);
 int qmri_device_count(void);
 const char *qmri_last_error(void);

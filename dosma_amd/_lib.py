@@ -10,6 +10,8 @@ import threading
 
 import numpy as np
 
+from dosma_amd import _hostpool
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libqmri_hip.so")
 
@@ -429,7 +431,6 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
     if not want_popt and not want_tc:
         raise ValueError("nothing to return: want_popt=False needs want_tc=True")
     if out is None:  # page-locked, recycled blocks for large results (no first-touch zeroing, true DMA): _hostpool.py
-        from dosma_amd import _hostpool
         out = {"r2": _hostpool.empty(N, od)}
         if want_popt:
             out["popt"] = _hostpool.empty((N, 2), od)
@@ -450,8 +451,8 @@ def monoexp_fit_host(x, y, *, mask=None, init=INIT_SCALAR, p0=(1.0, 1.0), a0v=No
     if want_tc:
         a.tc = _ptr(out["tc"])
     if want_info:
-        out["info"] = np.empty(N, dtype=np.int8)
-        out["nfev"] = np.empty(N, dtype=np.int16)
+        out["info"] = _hostpool.empty(N, np.int8)
+        out["nfev"] = _hostpool.empty(N, np.int16)
         a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
     a.device = _dev(device)
     check(lib.qmri_monoexp_fit_host(ctypes.byref(a)))
@@ -481,7 +482,7 @@ def linfit_host(x, y, *, log_transform=False, per_sequence_rules=False, y_bounds
     a.r2_eps = float(r2_eps)
     od = np.dtype(out_dtype)
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
-    out = {"popt": np.empty((N, 2), dtype=od), "r2": np.empty(N, dtype=od)}
+    out = {"popt": _hostpool.empty((N, 2), od), "r2": _hostpool.empty(N, od)}
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
     a.device = _dev(device)
     check(lib.qmri_linfit_host(ctypes.byref(a)))
@@ -520,10 +521,10 @@ def polyls_host(y, solve, design, *, w=None, per_sequence_rules=False, y_bounds=
         a.use_y_bounds = 1
         a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
     a.r2_eps = float(r2_eps)
-    out = {"popt": np.empty((N, P)), "r2": np.empty(N)}
+    out = {"popt": _hostpool.empty((N, P), np.float64), "r2": _hostpool.empty(N, np.float64)}
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
     if want_resid:
-        out["resid"] = np.empty(N)
+        out["resid"] = _hostpool.empty(N, np.float64)
         a.resid = _ptr(out["resid"])
     a.device = _dev(device)
     check(lib.qmri_polyls_host(ctypes.byref(a)))
@@ -573,11 +574,11 @@ def lmfit_host(model, x, y, p0, *, ftol=None, maxfev=None, r2_eps=None, y_bounds
     if y_bounds is not None:
         a.use_y_bounds = 1
         a.y_lo, a.y_hi = float(y_bounds[0]), float(y_bounds[1])
-    out = {"popt": np.empty((N, n)), "r2": np.empty(N)}
+    out = {"popt": _hostpool.empty((N, n), np.float64), "r2": _hostpool.empty(N, np.float64)}
     a.popt, a.r2 = _ptr(out["popt"]), _ptr(out["r2"])
     if want_info:
-        out["info"] = np.empty(N, dtype=np.int8)
-        out["nfev"] = np.empty(N, dtype=np.int16)
+        out["info"] = _hostpool.empty(N, np.int8)
+        out["nfev"] = _hostpool.empty(N, np.int16)
         a.info, a.nfev = _ptr(out["info"]), _ptr(out["nfev"])
     a.device = _dev(device)
     check(lib.qmri_lmfit_host(ctypes.byref(a)))
@@ -645,8 +646,8 @@ class Unet2dEngine:
         S = x.shape[0]
         if x.shape[1:] != (self.H, self.W):
             raise ValueError(f"slices are {x.shape[1:]}, model was built for {(self.H, self.W)}")
-        logits = np.empty((S, self.H, self.W, self.n_classes), np.float32) if want_logits else None
-        mask = np.empty((S, self.H, self.W, self.n_classes), np.uint8) if want_mask else None
+        logits = _hostpool.empty((S, self.H, self.W, self.n_classes), np.float32) if want_logits else None
+        mask = _hostpool.empty((S, self.H, self.W, self.n_classes), np.uint8) if want_mask else None
         check(self._lib.qmri_unet2d_forward(self._handle, _ptr(x), S, 0, 1 if whiten else 0, float(eps),
                                             _ptr(logits), _ptr(mask), 0, None))
         return logits, mask
@@ -659,7 +660,6 @@ class Unet2dEngine:
         if v.ndim != 3 or v.shape[:2] != (self.H, self.W):
             raise ValueError(f"volume is {v.shape}, model was built for slices of {(self.H, self.W)}")
         S = v.shape[2]
-        from dosma_amd import _hostpool
         out = _hostpool.empty((self.n_classes, self.H, self.W, S), np.uint8)
         check(self._lib.qmri_unet2d_segment_volume(self._handle, _ptr(v), S, 1 if whiten else 0, float(eps),
                                                    _ptr(out), None))
@@ -702,7 +702,7 @@ def dess_t2_host(echo1, echo2, c0, k, c1, *, bounds=None, nan_to_num=None, decim
     a.suppress_fat, a.suppress_fluid, a.beta = int(bool(suppress_fat)), int(bool(suppress_fluid)), float(beta)
     od = np.dtype(out_dtype)
     a.out_dtype = QMRI_F64 if od == np.float64 else QMRI_F32
-    out = np.empty(e1.shape, dtype=od)
+    out = _hostpool.empty(e1.shape, od)
     a.t2 = _ptr(out)
     a.device = _dev(device)
     check(lib.qmri_dess_t2_host(ctypes.byref(a)))
@@ -790,7 +790,7 @@ def rss_host(echo1, echo2, method="rss", device=None):
         raise ValueError("echo volumes must have the same shape and dtype")
     if method not in ("rss", "rms"):
         raise ValueError(f"`method={method}` is not supported")
-    out = np.empty(e1.shape, dtype=np.float64)
+    out = _hostpool.empty(e1.shape, np.float64)
     check(lib.qmri_rss_host(_ptr(e1), _ptr(e2), qdtype(e1.dtype), e1.size, 0 if method == "rss" else 1,
                             _ptr(out), _dev(device)))
     return out

@@ -264,7 +264,7 @@ int qmri_device_count(void) {
 int qmri_host_alloc(uint64_t bytes, void **out) {
     if (!out || bytes == 0) return fail(QMRI_ERR_ARG, "qmri_host_alloc: NULL result pointer or zero bytes");
     *out = nullptr;
-    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable));  // (usable from every device of the process)
     return QMRI_OK;
 }
 

@@ -346,20 +346,28 @@ constexpr int kO_NJ = (kO_Halo + 7) / 8;               // 43 DMA instructions of
 constexpr int kO_HaloBytes = kO_NJ * 1024;
 constexpr int kO_PerWave = (kO_NJ + kO_Waves - 1) / kO_Waves;  // 6
 
-__global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
+// NW waves = NW rows of 32 pixels per tile.  12 (three waves per SIMD; the last tile row of a slice may be partly outside it)
+// where the per-wave phases between the MFMA loops need the extra latency hiding; 8 is the two-waves-per-SIMD form.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
+    constexpr int kT_Threads = NW * 64;
+    constexpr int kT_Halo = (NW + 2) * kPitch;
+    constexpr int kT_NJ = (kT_Halo + 7) / 8;
+    constexpr int kT_HaloBytes = kT_NJ * 1024;
+    constexpr int kT_PerWave = (kT_NJ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wlds = smem;                       // weights, 9 x 4096 B
     unsigned char *halo = wlds + kWBytes;             // two halo buffers
-    float *hw = reinterpret_cast<float *>(halo + 2 * kO_HaloBytes);  // classifier: [32 channels][4], then bias [4]
+    float *hw = reinterpret_cast<float *>(halo + 2 * kT_HaloBytes);  // classifier: [32 channels][4], then bias [4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kgrp = lane >> 5;
 
-    for (int i = tid; i < kWBytes / 16; i += kO_Threads)
+    for (int i = tid; i < kWBytes / 16; i += kT_Threads)
         reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
-    for (int i = tid; i < 32 * 4 + 4; i += kO_Threads) {
+    for (int i = tid; i < 32 * 4 + 4; i += kT_Threads) {
         const int NC = A.nc;
         float v;
         if (i < 128) {
@@ -370,14 +378,10 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         }
         hw[i] = v;
     }
-    float pb[16], ps[16], pt[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int ch = (e & 3) + 8 * (e >> 2) + 4 * kgrp;
-        pb[e] = A.bias[ch];
-        ps[e] = A.scale[ch];
-        pt[e] = A.shift[ch];
-    }
+    // epilogue parameters in LDS ([bias | scale | shift][32]; float4 broadcasts per four channels in the epilogue: 48 registers
+    // less, which is what three waves per SIMD leave room for)
+    float *prm = hw + 32 * 4 + 4;
+    for (int i = tid; i < 96; i += kT_Threads) prm[i] = i < 32 ? A.bias[i] : i < 64 ? A.scale[i - 32] : A.shift[i - 64];
     const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
     const int hp0 = (wave + 1) * kPitch + l31 + 1;
     int boff[9];
@@ -390,28 +394,28 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
     // first pixel (the tile origin is wave-uniform: a request costs two 64-bit adds and a border test, not a chain of 64-bit mads)
     // per piece, once per kernel: halo row / column, and the byte offset of the piece's 16 source bytes relative to the tile's
     // halo origin = pixel (y0 - 1, x0 - 1) (the buffer descriptor's base, wave-uniform)
-    int d_yx[kO_PerWave];
-    unsigned d_off[kO_PerWave];
+    int d_yx[kT_PerWave];
+    unsigned d_off[kT_PerWave];
 #pragma unroll
-    for (int i = 0; i < kO_PerWave; ++i) {
-        const int j = wave + kO_Waves * i;
+    for (int i = 0; i < kT_PerWave; ++i) {
+        const int j = wave + NW * i;
         const int hp = j * 8 + (lane >> 3), p8 = lane & 7;
         const int plane = (p8 >> 2) ^ ((hp >> 1) & 1), q = (p8 & 3) ^ ((hp >> 2) & 3);
         const int hy = hp / kPitch, hx = hp - hy * kPitch;
-        d_yx[i] = (j < kO_NJ && hp < kO_Halo) ? (hy | (hx << 8)) : -1;
+        d_yx[i] = (j < kT_NJ && hp < kT_Halo) ? (hy | (hx << 8)) : -1;
         d_off[i] = (unsigned)(((long long)hy * A.W + hx) * A.ldx * 4 + plane * 64 + q * 16);
     }
     const unsigned halo_lds = lds_off(halo);
     const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
 
-    const int tiles_x = A.W / 32, tiles_y = A.H / kO_Waves;
+    const int tiles_x = A.W / 32, tiles_y = (A.H + NW - 1) / NW;  // (the last row of tiles may reach beyond the slice)
     const int per_img = tiles_x * tiles_y;
     const int ntiles = A.B * per_img;
     auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
         b = t / per_img;
         const int r = t - b * per_img;
         const int ty = r / tiles_x;
-        y0 = ty * kO_Waves;
+        y0 = ty * NW;
         x0 = (r - ty * tiles_x) * 32;
     };
     // source address of this wave's request i for a tile (zero line outside the slice), and the request itself
@@ -428,12 +432,12 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         rsrc[2] = 0x40000000;
         rsrc[3] = 0x00020000;
 #pragma unroll
-        for (int i = 0; i < kO_PerWave; ++i) {
-            const int j = wave + kO_Waves * i;
-            if (j < kO_NJ) {  // (wave-uniform)
+        for (int i = 0; i < kT_PerWave; ++i) {
+            const int j = wave + NW * i;
+            if (j < kT_NJ) {  // (wave-uniform)
                 const int yy = y0 - 1 + (d_yx[i] & 0xFF), xx = x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
                 const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-                dma16_buf(ok ? d_off[i] : 0xFFFFFFF0u, rsrc, halo_lds + (unsigned)(buf * kO_HaloBytes + j * 1024));
+                dma16_buf(ok ? d_off[i] : 0xFFFFFFF0u, rsrc, halo_lds + (unsigned)(buf * kT_HaloBytes + j * 1024));
             }
         }
     };
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         // measured 1.55 instead of 1.40 ms: the request statement is a memory barrier for hipcc and cuts the LDS read pipeline.)
         const bool more = next < ntiles;
         if (more) request_halo(next, buf ^ 1);
-        const unsigned char *hb = halo + buf * kO_HaloBytes;
+        const unsigned char *hb = halo + buf * kT_HaloBytes;
 
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         struct Frag {
@@ -493,17 +497,25 @@ __global__ __launch_bounds__(kO_Threads, 1) void out0_kernel(const Out0Args A) {
         // ---- bias, ReLU, BatchNorm; classifier on this lane's 16 channels; the partner lane adds the other 16 ----
         float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v = fmaf(fmaxf(fmaf(acc[e], A.winv, pb[e]), 0.f), ps[e], pt[e]);
-            const float4 w4 = *reinterpret_cast<const float4 *>(hw + ((e & 3) + 8 * (e >> 2) + 4 * kgrp) * 4);
-            z[0] = fmaf(v, w4.x, z[0]);
-            z[1] = fmaf(v, w4.y, z[1]);
-            z[2] = fmaf(v, w4.z, z[2]);
-            z[3] = fmaf(v, w4.w, z[3]);
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 8 * q + 4 * kgrp;
+            const float4 b4 = *reinterpret_cast<const float4 *>(prm + c0);
+            const float4 s4 = *reinterpret_cast<const float4 *>(prm + 32 + c0);
+            const float4 t4 = *reinterpret_cast<const float4 *>(prm + 64 + c0);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaf(fmaxf(fmaf(acc[4 * q + r], A.winv, bb[r]), 0.f), ss[r], tt[r]);
+                const float4 w4 = *reinterpret_cast<const float4 *>(hw + (c0 + r) * 4);
+                z[0] = fmaf(v, w4.x, z[0]);
+                z[1] = fmaf(v, w4.y, z[1]);
+                z[2] = fmaf(v, w4.z, z[2]);
+                z[3] = fmaf(v, w4.w, z[3]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
-        if (kgrp == 0) {
+        if (kgrp == 0 && t_y0 + wave < A.H) {
             const long long pix = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0 + l31;
             const int NC = A.nc;
             float zz[4];
@@ -747,19 +759,22 @@ hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
     return hipGetLastError();
 }
 
-size_t out0_lds_bytes() { return (size_t)kWBytes + 2 * (size_t)kO_HaloBytes + (32 * 4 + 4) * 4; }
+constexpr int kOut0Waves = 12;
+static size_t out0_lds_bytes_n(int nw) { return (size_t)kWBytes + 2 * (size_t)(((nw + 2) * kPitch + 7) / 8) * 1024 + (32 * 4 + 4 + 96) * 4; }
+size_t out0_lds_bytes() { return out0_lds_bytes_n(kOut0Waves); }
 
-bool out0_supported(const Out0Args &k) { return k.H % kO_Waves == 0 && k.W % 32 == 0 && k.B > 0 && k.nc >= 1 && k.nc <= 4; }
+bool out0_supported(const Out0Args &k) { return k.W % 32 == 0 && k.B > 0 && k.H > 0 && k.nc >= 1 && k.nc <= 4; }
 
 hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream) {
     if (!out0_supported(k)) return hipErrorInvalidValue;
     const size_t lds = out0_lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(out0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto fn = out0_kernel<kOut0Waves>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const long long ntiles = (long long)k.B * (k.H / kO_Waves) * (k.W / 32);
+    const long long ntiles = (long long)k.B * ((k.H + kOut0Waves - 1) / kOut0Waves) * (k.W / 32);
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(out0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kOut0Waves * 64), lds, stream, k);
     return hipGetLastError();
 }
 

@@ -688,7 +688,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
         snprintf(nm, sizeof(nm), "up%d.conv2", l);
         // the last convolution + classifier as one kernel with LDS-resident weights (QMRI_OUT0=0: conv_s3_kernel + fused head)
         static const bool want_out0 = !(std::getenv("QMRI_OUT0") && std::atoi(std::getenv("QMRI_OUT0")) == 0);
-        if (l == 0 && want_out0 && C == 32 && U->up2[0]->w_s3.p && H % 8 == 0 && W % 32 == 0) {
+        if (l == 0 && want_out0 && C == 32 && U->up2[0]->w_s3.p && W % 32 == 0) {
             const ConvLayer &L2 = *U->up2[0];
             qmri::Out0Args k;
             std::memset(&k, 0, sizeof(k));

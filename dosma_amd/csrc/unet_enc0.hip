@@ -9,18 +9,22 @@
 // as the halo image of the second convolution in LDS and the pooled map is made from the staged output tile: 0.1 GB in
 // (the image), 3.75 GB out.
 //
-// Persistent blocks of 4 waves, TWO per CU (the phases of a tile are sequential inside a block: while one block is in its MFMA
-// loop the other one runs its VALU / LDS / store phases); a tile is 4 rows x 32 columns of one slice.  Per tile:
-//   patch   8 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)            -> LDS
-//   conv 1  on the 6 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
+// One persistent block of 8 waves per CU; a tile is 8 rows x 32 columns of one slice.  (Two 4-wave blocks per CU with 4 x 32 tiles
+// -- one block's MFMA loop beside the other's VALU phases -- measured 1.79 instead of 1.63 ms: 1.59 x halo instead of 1.33 x.)
+// Per tile:
+//   patch   12 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)           -> LDS
+//   conv 1  on the 10 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
 //           split into fp16 hi + lo parts like everywhere else (three MFMAs per 32 pixels); ReLU; split; halo image
 //           (zero outside the slice: that is conv 2's SAME padding)
 //   conv 2  nine taps x two k-steps x (hi hi + hi lo + lo hi); its 36 KB of weights are LDS-RESIDENT (no ring, no
 //           request stream, no counted waits); A = weights, B = pixels, so that a lane of the accumulator tile holds
 //           ONE pixel and a register one channel
 //   out     bias, ReLU, BatchNorm affine, split; [pixel][hi 64 B | lo 64 B] image through a wave window in LDS (eight 8-byte
-//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 0-1
-//           pool the staged tile 2 x 2 and store the next level's input
+//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 4-7
+//           (which had one halo group of conv 1, not two) pool the staged tile 2 x 2 and store the next level's input
+//
+// The same file holds the two other 32-channel layers of the top level: mid0_kernel (Conv2D 64 -> 32) and out0_kernel (last
+// convolution + classifier).
 #include <hip/hip_runtime.h>
 
 #include "qmri_internal.h"

@@ -23,6 +23,7 @@ _lock = threading.Lock()
 _free = {}                  # size -> [pointers]
 _cached = 0
 _closed = False
+_pid = os.getpid()          # blocks belong to the process that allocated them (a forked worker never frees or reuses them)
 
 
 def _cap():
@@ -34,7 +35,7 @@ def _cap():
 
 def _release(ptr, size):
     global _cached
-    if _closed:             # interpreter shutdown: the HIP runtime may be gone; the process is about to release everything
+    if _closed or os.getpid() != _pid:  # interpreter shutdown / forked child: leave the block alone
         return
     with _lock:
         if _cached + size <= _cap():
@@ -67,7 +68,7 @@ def empty(shape, dtype):
     for s in shape:
         count *= s
     nbytes = count * dt.itemsize
-    if nbytes < _MIN_BYTES or _closed or _cap() <= 0:
+    if nbytes < _MIN_BYTES or _closed or _cap() <= 0 or os.getpid() != _pid:
         return np.empty(shape, dt)
     size = (nbytes + _GRANULE - 1) // _GRANULE * _GRANULE
     ptr = _take(size)
@@ -82,7 +83,8 @@ def empty(shape, dtype):
         except Exception:
             return np.empty(shape, dt)
     buf = (ctypes.c_ubyte * size).from_address(ptr)
-    weakref.finalize(buf, _release, ptr, size)
+    fin = weakref.finalize(buf, _release, ptr, size)
+    fin.atexit = False  # nothing to recycle at interpreter exit (and no HIP call from an exit handler or a forked child)
     return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 

@@ -325,3 +325,22 @@ np.save(sys.argv[1], logits)
     assert "up0.conv1:s3/2d/bn32" in out["general"][1]
     assert out["dedicated"][0] < 1e-3 and out["general"][0] < 1e-3
     assert np.abs(out["dedicated"][2] - out["general"][2]).max() < 2e-4
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (160, 64), (224, 32), (96, 32)])
+def test_dedicated_top_level_kernels_on_small_and_ragged_sizes(small_net, hw):
+    """enc0 / mid0 / out0 (unet_enc0.hip) where their tiling is at its edges: one tile per slice (32 x 32), a single tile
+    column (W = 32), heights that are not a multiple of out0's 12-row tiles (the last tile row is partly outside the
+    slice: 160 = 13 x 12 + 4, 224 = 18 x 12 + 8)."""
+    w, tensors = small_net
+    H, W = hw
+    rng = np.random.default_rng(H * 1000 + W)
+    vol = (rng.standard_normal((3, H, W)) * 70 + 150).astype(np.float32)
+    eng = L.Unet2dEngine(tensors, H, W, max_batch=3, precision="fp16x3")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    ref = uo.forward(w, uo.whiten_volume(vol.astype(np.float64)).astype(np.float32), dtype="float64")
+    assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
+    assert np.array_equal(mask, (logits > 0).astype(np.uint8))
+    tr = eng.trace()
+    assert "down0:enc0" in tr and "up0.conv1:mid0" in tr and "up0.conv2:out0+head" in tr, tr
+    eng.close()

@@ -81,9 +81,13 @@ class HipSegModel(SegModel):
             w = W.load_keras_h5(weights_path)
         n_classes = self._n_classes()
         W.validate(w, n_classes=n_classes)
+        # activation buffers: ~1.1 KB per pixel and slice in the parity mode (25 GB for 160 slices of 384 x 384); larger slices
+        # get fewer slices per pass so that one model stays below ~64 GB of the 288
+        per_slice = input_shape[0] * input_shape[1] * 1100
+        fit = max(1, int(64e9 // per_slice))
+        max_batch = max(int(self.batch_size), min(int(self.gpu_batch), fit), 1)
         return _lib.Unet2dEngine(W.to_abi_order(w), input_shape[0], input_shape[1], n_classes=n_classes,
-                                 max_batch=max(int(self.batch_size), int(self.gpu_batch), 1), precision=self.precision,
-                                 device=self.device)
+                                 max_batch=max_batch, precision=self.precision, device=self.device)
 
     def _n_classes(self):
         return 4

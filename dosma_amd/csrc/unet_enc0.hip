@@ -176,8 +176,17 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // XCD x (= blockIdx % 8: its own L2) walks a CONTIGUOUS eighth of the tiles, its CUs side by side in it: neighbouring tiles share
+    // halo rows / columns through that L2 instead of fetching them from HBM once per XCD
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * per + (blockIdx.x >> 3);
+        t_stride = gridDim.x >> 3;
+        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    }
+    int tile = t_first;
+    if (tile >= t_end) return;
     int t_b, t_y0, t_x0;
     tile_origin(tile, t_b, t_y0, t_x0);
     // prologue: patch and conv 1 of the first tile
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (registers: one atomic per block at the very end)
 #endif
     while (true) {
-        const int next = tile + gridDim.x;
+        const int next = tile + t_stride;
         const float pn0 = load_patch(next, tid), pn1 = load_patch(next, tid + kThreads);  // in flight during the MFMA loop
 
         // ---------------- conv 2: kWaves x 32 pixels x 32 channels, K = 9 taps x 32 ----------------
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         ENC0_T(3)
         // ---------------- conv 1 of the next tile; skip stores and pooling of this one ----------------
         int n_b = 0, n_y0 = 0, n_x0 = 0;
-        if (next < ntiles) {
+        if (next < t_end) {
             tile_origin(next, n_b, n_y0, n_x0);
             for (int g = wave; g < kGroups; g += kWaves) conv1_group(g, n_y0, n_x0);
         }
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l[0], l[1], l[2], l[3]);
         }
         ENC0_T(4)
-        if (next >= ntiles) break;
+        if (next >= t_end) break;
         tile = next;
         t_b = n_b;
         t_y0 = n_y0;
@@ -446,8 +455,17 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // XCD x (= blockIdx % 8: its own L2) walks a CONTIGUOUS eighth of the tiles, its CUs side by side in it: neighbouring tiles share
+    // halo rows / columns through that L2 instead of fetching them from HBM once per XCD
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * per + (blockIdx.x >> 3);
+        t_stride = gridDim.x >> 3;
+        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    }
+    int tile = t_first;
+    if (tile >= t_end) return;
     int t_b, t_y0, t_x0;
     tile_origin(tile, t_b, t_y0, t_x0);
     request_halo(tile, 0);
@@ -459,10 +477,10 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     while (true) {
-        const int next = tile + gridDim.x;
+        const int next = tile + t_stride;
         // the next tile's halo: requested in front of the MFMA loop.  (From INSIDE the loop, one request every three half-steps,
         // measured 1.55 instead of 1.40 ms: the request statement is a memory barrier for hipcc and cuts the LDS read pipeline.)
-        const bool more = next < ntiles;
+        const bool more = next < t_end;
         if (more) request_halo(next, buf ^ 1);
         const unsigned char *hb = halo + buf * kT_HaloBytes;
 
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
             }
         }
         ENC0_T(2)
-        if (next >= ntiles) break;
+        if (next >= t_end) break;
         tile = next;
         tile_origin(tile, t_b, t_y0, t_x0);
         buf ^= 1;
@@ -639,8 +657,17 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         if (j < kO_NJ) dma16_buf(voff, rsrc, halo_lds + (unsigned)(chunk * kO_HaloBytes + j * 1024));
     };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // XCD x (= blockIdx % 8: its own L2) walks a CONTIGUOUS eighth of the tiles, its CUs side by side in it: neighbouring tiles share
+    // halo rows / columns through that L2 instead of fetching them from HBM once per XCD
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * per + (blockIdx.x >> 3);
+        t_stride = gridDim.x >> 3;
+        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    }
+    int tile = t_first;
+    if (tile >= t_end) return;
     int t_b, t_y0, t_x0;
     tile_origin(tile, t_b, t_y0, t_x0);
 #pragma unroll
@@ -648,7 +675,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (first tile: chunk 0 before anything else)
 
     while (true) {
-        const int next = tile + gridDim.x;
+        const int next = tile + t_stride;
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         struct Frag {
             f16x8 wh, wl, xh, xl;
@@ -695,7 +722,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         chunk_mfma(0, v1, chunk_rsrc(t_b, t_y0, t_x0, 1), true);
         // chunk 1 of this tile has landed (nothing newer is in this wave's queue); everyone is done with buffer 0
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const bool more = next < ntiles;
+        const bool more = next < t_end;
         int n_b = t_b, n_y0 = t_y0, n_x0 = t_x0;
         if (more) tile_origin(next, n_b, n_y0, n_x0);
 #pragma unroll
@@ -731,7 +758,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
             *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 16) * A.ldy * 4 + ((pos ^ ((px0 >> 1) & 7)) * 16)) = v2;
             *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 24) * A.ldy * 4 + ((pos ^ (((px0 >> 1) + 4) & 7)) * 16)) = v3;
         }
-        if (next >= ntiles) break;
+        if (next >= t_end) break;
         tile = next;
         t_b = n_b;
         t_y0 = n_y0;

@@ -535,8 +535,13 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
                 z[3] = fmaf(v, w4.w, z[3]);
             }
         }
+        // both halves of the wave need the sum over all 32 channels: v_permlane32_swap of z with itself leaves [lower | lower] and
+        // [upper | upper] in its two results (one instruction, no LDS crossbar trip like ds_bpermute)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
+        for (int c = 0; c < 4; ++c) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[c]), __float_as_uint(z[c]), false, false);
+            z[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
         if (kgrp == 0 && t_y0 + wave < A.H) {
             const long long pix = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0 + l31;
             const int NC = A.nc;

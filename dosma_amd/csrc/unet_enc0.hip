@@ -380,21 +380,27 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
 
     for (int i = tid; i < kWBytes / 16; i += kT_Threads)
         reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
-    for (int i = tid; i < 32 * 4 + 4; i += kT_Threads) {
+    // classifier with the BatchNorm affine and the weight scale folded in (winv = 2^-k > 0):
+    //   logit_c = head_b[c] + sum_ch head_w[ch][c] (scale[ch] relu(acc winv + bias[ch]) + shift[ch])
+    //           = cst[c] + sum_ch hw[ch][c] max(acc + pbias[ch], 0),   hw = head_w scale winv,  pbias = bias / winv,
+    //             cst = head_b + sum_ch head_w shift
+    // -> per channel one add, one max, four fma and five parameters (were: two fma, one max, four fma and seven)
+    float *prm = hw + 32 * 4 + 4;  // pbias [32]
+    for (int i = tid; i < 32 * 4 + 4 + 32; i += kT_Threads) {
         const int NC = A.nc;
-        float v;
         if (i < 128) {
             const int ch = i >> 2, c = i & 3;
-            v = c < NC ? A.head_w[ch * NC + c] : 0.f;
+            hw[i] = c < NC ? A.head_w[ch * NC + c] * A.scale[ch] * A.winv : 0.f;
+        } else if (i < 132) {
+            const int c = i - 128;
+            float acc0 = c < NC ? A.head_b[c] : 0.f;
+            if (c < NC)
+                for (int ch = 0; ch < 32; ++ch) acc0 = fmaf(A.head_w[ch * NC + c], A.shift[ch], acc0);
+            hw[i] = acc0;
         } else {
-            v = i - 128 < NC ? A.head_b[i - 128] : 0.f;
+            prm[i - 132] = A.bias[i - 132] / A.winv;
         }
-        hw[i] = v;
     }
-    // epilogue parameters in LDS ([bias | scale | shift][32]; float4 broadcasts per four channels in the epilogue: 48 registers
-    // less, which is what three waves per SIMD leave room for)
-    float *prm = hw + 32 * 4 + 4;
-    for (int i = tid; i < 96; i += kT_Threads) prm[i] = i < 32 ? A.bias[i] : i < 64 ? A.scale[i - 32] : A.shift[i - 64];
     const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
     const int hp0 = (wave + 1) * kPitch + l31 + 1;
     int boff[9];
@@ -522,12 +528,10 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
         for (int q = 0; q < 4; ++q) {
             const int c0 = 8 * q + 4 * kgrp;
             const float4 b4 = *reinterpret_cast<const float4 *>(prm + c0);
-            const float4 s4 = *reinterpret_cast<const float4 *>(prm + 32 + c0);
-            const float4 t4 = *reinterpret_cast<const float4 *>(prm + 64 + c0);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaf(fmaxf(fmaf(acc[4 * q + r], A.winv, bb[r]), 0.f), ss[r], tt[r]);
+                const float v = fmaxf(acc[4 * q + r] + bb[r], 0.f);
                 const float4 w4 = *reinterpret_cast<const float4 *>(hw + (c0 + r) * 4);
                 z[0] = fmaf(v, w4.x, z[0]);
                 z[1] = fmaf(v, w4.y, z[1]);
@@ -796,7 +800,7 @@ hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
 }
 
 constexpr int kOut0Waves = 12;
-static size_t out0_lds_bytes_n(int nw) { return (size_t)kWBytes + 2 * (size_t)(((nw + 2) * kPitch + 7) / 8) * 1024 + (32 * 4 + 4 + 96) * 4; }
+static size_t out0_lds_bytes_n(int nw) { return (size_t)kWBytes + 2 * (size_t)(((nw + 2) * kPitch + 7) / 8) * 1024 + (32 * 4 + 4 + 32) * 4; }
 size_t out0_lds_bytes() { return out0_lds_bytes_n(kOut0Waves); }
 
 bool out0_supported(const Out0Args &k) { return k.W % 32 == 0 && k.B > 0 && k.H > 0 && k.nc >= 1 && k.nc <= 4; }

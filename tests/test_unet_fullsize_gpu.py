@@ -119,3 +119,20 @@ def test_odd_level_widths_take_the_general_kernel(net):
     _expect_families(tr, 224, 224)
     assert any(t.startswith("down1.conv2:igemm") for t in tr) and any(t.startswith("down3.conv1:s3/flat") for t in tr)
     eng.close()
+
+
+def test_forward_is_bitwise_repeatable(net):
+    """No atomics and no data-dependent scheduling in the convolution kernels: the same volume through the same engine gives the
+    same bits, whatever the timing of the LDS-DMA requests (a request landing after its counted wait would show up here first)."""
+    w, tensors = net
+    vol = _volume(24, 384, 384, 7)
+    eng = L.Unet2dEngine(tensors, 384, 384, max_batch=24, precision="fp16x3")
+    first, _ = eng.forward_host(vol, whiten=True, eps=0.0)
+    for _ in range(4):
+        again, _ = eng.forward_host(vol, whiten=True, eps=0.0)
+        assert np.array_equal(first, again)
+    eng.close()
+    eng = L.Unet2dEngine(tensors, 384, 384, max_batch=5, precision="fp16x3")  # other batch boundaries, same per-slice bits
+    split, _ = eng.forward_host(vol, whiten=True, eps=0.0)
+    assert np.array_equal(first, split)
+    eng.close()

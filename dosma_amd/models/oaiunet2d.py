@@ -29,30 +29,58 @@ class OAIUnet2D(HipSegModel):
     def _n_classes(self):
         return 1
 
-    def _check_threshold(self):
-        if self.sigmoid_threshold != 0.5:
-            # the kernel thresholds the logit at 0 (sigmoid > 0.5); other thresholds shift the logit cut
-            return float(np.log(self.sigmoid_threshold / (1 - self.sigmoid_threshold)))
-        return 0.0
-
-    def _segment(self, volume: MedicalVolume):
-        """-> (sagittal MedicalVolume of the input, list of per-class (H, W, S) uint8 arrays)."""
+    # ---- the two halves of the reference's generate_mask around ``model.predict`` (oaiunet2d.py:140-170, 291-320) ----
+    # Both are pinned to golden g9, produced by the reference's own generate_mask with a stand-in ``predict``
+    # (tests/test_models_host.py::test_generate_mask_pre_post_vs_reference); the fused GPU route below is pinned to the
+    # same fixture through pass-through network weights (tests/test_unet_gpu.py::test_generate_mask_vs_reference_golden).
+    def _check_volume(self, volume):
         if not isinstance(volume, MedicalVolume) or volume.ndim != 3:
             raise ValueError("`volume` must be a 3D MedicalVolume")
-        # the reference deep-copies and reformats in place (:292-296); a reformat to SAGITTAL gives the same volume
-        # (a view when only axes move) without copying the voxels twice
+
+    def _to_sagittal(self, volume: MedicalVolume) -> MedicalVolume:
+        """The reference deep-copies and reformats in place (:141-144, :292-295); a reformat to SAGITTAL gives the same
+        volume (a view when only axes move) without copying the voxels twice."""
+        self._check_volume(volume)
         vol_sag = volume.reformat(SAGITTAL)
-        vol = vol_sag.volume
-        eng = self.seg_model
-        if vol.shape[:2] != (eng.H, eng.W):
-            raise ValueError(f"model was built for slices of {(eng.H, eng.W)}, volume has {vol.shape[:2]}")
-        cut = self._check_threshold()
-        if cut == 0.0:
-            planes = eng.segment_volume(vol, whiten=self._WHITEN, eps=self._WHITEN_EPS)  # (C, H, W, S)
-            return vol_sag, [planes[i] for i in range(planes.shape[0])]
-        logits, _ = self._predict(vol, self._WHITEN, self._WHITEN_EPS, want_logits=True)
-        mask = (logits > cut).astype(np.uint8)  # (S, H, W, C)
-        return vol_sag, [np.ascontiguousarray(np.transpose(mask[..., i], (1, 2, 0))) for i in range(mask.shape[-1])]
+        eng = getattr(self, "seg_model", None)
+        if eng is not None and hasattr(eng, "H") and vol_sag.volume.shape[:2] != (eng.H, eng.W):
+            raise ValueError(f"model was built for slices of {(eng.H, eng.W)}, volume has {vol_sag.volume.shape[:2]}")
+        return vol_sag
+
+    def _to_network_input(self, volume: MedicalVolume):
+        """-> (sagittal MedicalVolume, the ``(slice, x, y, 1)`` array ``model.predict`` receives in the reference):
+        reformat to SAGITTAL, ``__preprocess_volume__``, transpose (2, 0, 1), trailing channel axis (:146-151, :297-302)."""
+        vol_sag = self._to_sagittal(volume)
+        v = self.__preprocess_volume__(vol_sag.volume)
+        return vol_sag, np.expand_dims(np.transpose(v, (2, 0, 1)), axis=-1)
+
+    def _from_network_output(self, probs: np.ndarray, vol_sag: MedicalVolume, orientation):
+        """``predict``'s ``(slice, x, y, classes)`` probabilities -> the masks ``generate_mask`` returns: ``>
+        sigmoid_threshold`` as uint8, back to ``(x, y, slice)``, one clone of the sagittal volume per class, each
+        reformatted to the caller's orientation (:156-170, :306-320)."""
+        mask = (np.asarray(probs) > self.sigmoid_threshold).astype(np.uint8)
+        planes = [np.transpose(mask[..., i], (1, 2, 0)) for i in range(mask.shape[-1])]
+        return self._wrap_planes(vol_sag, planes, orientation)
+
+    def _wrap_planes(self, vol_sag: MedicalVolume, planes, orientation):
+        """Per-class ``(x, y, slice)`` uint8 planes -> one MedicalVolume (single-class template, :140-170)."""
+        return self._wrap_mask(vol_sag, planes[0], orientation)
+
+    def _segment(self, volume: MedicalVolume):
+        """The fused GPU route of the two functions above + the network: -> (sagittal MedicalVolume, per-class (H, W, S)
+        uint8 planes).  Transposes, whitening, network, threshold and class planes run in ONE library call
+        (``qmri_unet2d_segment_volume``); a ``sigmoid_threshold`` other than 0.5 moves the cut on the logit."""
+        vol_sag = self._to_sagittal(volume)
+        planes = self.seg_model.segment_volume(vol_sag.volume, whiten=self._WHITEN, eps=self._WHITEN_EPS)  # (C, H, W, S)
+        return vol_sag, [planes[i] for i in range(planes.shape[0])]
+
+    def _predict_probabilities(self, v: np.ndarray) -> np.ndarray:
+        """``model.predict`` of the reference on an already preprocessed ``(slice, x, y, 1)`` array -> float32 sigmoid
+        outputs ``(slice, x, y, classes)`` (the network on the GPU; the sigmoid of its logits on the host)."""
+        x = np.ascontiguousarray(v[..., 0], dtype=np.float32)
+        logits, _ = self.seg_model.forward_host(x, whiten=False, eps=0.0, want_logits=True)
+        with np.errstate(over="ignore"):
+            return (1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).astype(np.float32)
 
     def _wrap_mask(self, vol_sag: MedicalVolume, plane: np.ndarray, orientation):
         """uint8 (H, W, S) mask -> MedicalVolume with the sagittal volume's affine / headers (the reference's
@@ -61,8 +89,12 @@ class OAIUnet2D(HipSegModel):
         return m.reformat(orientation, inplace=True) if m.orientation != tuple(orientation) else m
 
     def generate_mask(self, volume: MedicalVolume):
-        vol_sag, planes = self._segment(volume)
-        return self._wrap_mask(vol_sag, planes[0], volume.orientation)
+        if self.sigmoid_threshold == 0.5:  # sigmoid(z) > 0.5  <=>  z > 0: the fused route thresholds the logits on the GPU
+            vol_sag, planes = self._segment(volume)
+            return self._wrap_planes(vol_sag, planes, volume.orientation)
+        # any other threshold: the reference's own sequence, step by step (:140-170)
+        vol_sag, v = self._to_network_input(volume)
+        return self._from_network_output(self._predict_probabilities(v), vol_sag, volume.orientation)
 
     def __preprocess_volume__(self, volume: np.ndarray):
         return whiten_volume(volume, eps=1e-8)
@@ -87,9 +119,9 @@ class IWOAIOAIUnet2D(OAIUnet2D):
     def _n_classes(self):
         return 4
 
-    def generate_mask(self, volume: MedicalVolume):
-        vol_sag, planes = self._segment(volume)
-        return {category: self._wrap_mask(vol_sag, planes[i], volume.orientation)
+    def _wrap_planes(self, vol_sag: MedicalVolume, planes, orientation):
+        """One MedicalVolume per class, keyed in the template's class order (:309-320)."""
+        return {category: self._wrap_mask(vol_sag, planes[i], orientation)
                 for i, category in enumerate(self.CATEGORIES)}
 
     def __preprocess_volume__(self, volume: np.ndarray):

@@ -92,13 +92,6 @@ class HipSegModel(SegModel):
     def _n_classes(self):
         return 4
 
-    def _predict(self, vol_hws: np.ndarray, whiten: bool, eps: float, want_logits=False):
-        """``model.predict`` of the reference: (H, W, S) volume -> (S, H, W, C) mask (and logits)."""
-        eng = self.seg_model
-        v = np.ascontiguousarray(np.transpose(vol_hws, (2, 0, 1)), dtype=np.float32)
-        logits, mask = eng.forward_host(v, whiten=whiten, eps=eps, want_logits=want_logits)
-        return logits, mask
-
     def __del__(self):
         eng = getattr(self, "seg_model", None)
         if eng is not None:

@@ -344,9 +344,108 @@ def g8():
     save("g8_to_metrics.npz", **out)
 
 
+def g9():
+    """``generate_mask`` pre / post logic of every segmentation template (oaiunet2d.py:140-175, 291-320, 344-345;
+    stanford_qdess.py:158-205; seg_model.py:114-127), run by the reference's OWN code.  Keras / TensorFlow and the weight
+    files are absent here, so the instances are made with ``object.__new__`` and get a ``seg_model`` whose
+    ``predict`` is a seeded per-pixel function of the array the reference hands it: sigmoid(a_c * v + b_c) per class.  The
+    NETWORK is therefore not what this fixture pins -- the reformat to SAGITTAL, the preprocessing, the (slice, x, y, 1)
+    layout, ``> sigmoid_threshold``, the class order, the per-class clones and the reformat back are.  Stored: the input
+    volume + affine, the array ``predict`` received, the probabilities it returned, and every output volume / affine."""
+    import dosma.models.oaiunet2d as ref_o
+    import dosma.models.seg_model as ref_sm
+    import dosma.models.stanford_qdess as ref_s
+
+    for mod in (ref_o, ref_sm, ref_s):  # destructor of KerasSegModel: K.clear_session() (seg_model.py:105-106), Keras absent
+        if not hasattr(mod, "K"):
+            mod.K = type("K", (), {"clear_session": staticmethod(lambda: None)})
+
+    class Predictor:
+        def __init__(self, a, b):
+            self.a, self.b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            self.seen = None
+
+        def predict(self, v, batch_size=None, verbose=0):
+            assert v.ndim == 4 and v.shape[-1] == 1
+            self.seen = np.array(v)
+            z = v.astype(np.float64) * self.a + self.b          # (S, H, W, C) logits
+            self.logits = z
+            return (1.0 / (1.0 + np.exp(-z))).astype(np.float32)
+
+    rng = np.random.default_rng(9)
+    H, W, S = 64, 32, 3                                          # sagittal frame: (SI, AP, LR); a size the 6-level network accepts
+    # a volume whose SAGITTAL view is (H, W, S), stored in four orientations with anisotropic spacing + an offset
+    base = rng.gamma(2.0, 150.0, (H, W, S)).astype(np.float32)
+    base[:3] = 0.0
+    sag_aff = np.array([[0, 0, 1.5, -40.0], [0, -0.35, 0, 70.5], [-0.4, 0, 0, 33.25], [0, 0, 0, 1.0]])
+    sag = MV(base, sag_aff)
+    assert sag.orientation == ("SI", "AP", "LR"), sag.orientation
+    orients = {"sag": ("SI", "AP", "LR"), "ax": ("AP", "LR", "SI"), "cor_flip": ("IS", "RL", "AP"), "perm": ("LR", "PA", "IS")}
+    out = dict(orient_names=np.array(list(orients)), a4=np.array([0.9, -1.1, 0.7, 1.3]), b4=np.array([0.15, 0.4, -0.55, -0.2]))
+    a4, b4 = out["a4"], out["b4"]
+    raw_scale = 1.0 / 300.0                                       # un-whitened templates see raw intensities (0 .. ~2000)
+    templates = {
+        "iwoai": (ref_o.IWOAIOAIUnet2D, a4 * raw_scale, b4 - 0.8, None),
+        "iwoai_norm": (ref_o.IWOAIOAIUnet2DNormalized, a4, b4, None),
+        "oai": (ref_o.OAIUnet2D, a4[:1], b4[:1], None),
+        "stanford": (ref_s.StanfordQDessUNet2D, a4, b4, None),
+        "stanford_thr": (ref_s.StanfordQDessUNet2D, a4, b4, 0.7),
+    }
+    min_margin = np.inf
+    for oname, orient in orients.items():
+        vol_in = sag.reformat(orient)                            # a copy in the other orientation (med_volume.py:177-275)
+        out[f"{oname}_vol"] = np.array(vol_in.volume)
+        out[f"{oname}_affine"] = np.array(vol_in.affine)
+        for tname, (cls, a, b, thr) in templates.items():
+            model = object.__new__(cls)
+            model.batch_size = 16
+            model.seg_model = Predictor(a, b)
+            if thr is not None:
+                model.sigmoid_threshold = thr
+            res = model.generate_mask(vol_in)
+            tag = f"{oname}_{tname}"
+            out[f"{tag}_net_in"] = model.seg_model.seen
+            cut = 0.0 if thr is None else float(np.log(thr / (1 - thr)))
+            min_margin = min(min_margin, float(np.abs(model.seg_model.logits - cut).min()))
+            # pixels whose logit is within 2e-3 of the cut (S, H, W, C): a network that evaluates a_c * v + b_c in another
+            # arithmetic (the GPU test's pass-through weights) may legitimately land on the other side there
+            out[f"{tag}_near"] = np.abs(model.seg_model.logits - cut) < 2e-3
+            if isinstance(res, dict):
+                out[f"{tag}_keys"] = np.array(list(res.keys()))
+                items = list(res.items())
+            else:
+                out[f"{tag}_keys"] = np.array([], dtype="U4")
+                items = [("", res)]
+            for k, m in items:
+                assert m.volume.dtype == np.uint8 and m.orientation == tuple(orient)
+                out[f"{tag}_mask_{k}"] = np.array(m.volume)
+                out[f"{tag}_affine_{k}"] = np.array(m.affine)
+    # 4D dual-echo input of the Stanford template (stanford_qdess.py:172-178): RSS of the two echoes first
+    e = np.stack([base, rng.gamma(2.0, 90.0, (H, W, S)).astype(np.float32)], axis=-1)
+    mv4 = MV(e, sag_aff)
+    model = object.__new__(ref_s.StanfordQDessUNet2D)
+    model.batch_size = 16
+    model.seg_model = Predictor(a4, b4)
+    res = model.generate_mask(mv4)
+    out["dual_vol"] = e
+    out["dual_net_in"] = model.seg_model.seen
+    out["dual_near"] = np.abs(model.seg_model.logits) < 2e-3
+    for k, m in res.items():
+        out[f"dual_mask_{k}"] = np.array(m.volume)
+    out["dual_keys"] = np.array(list(res.keys()))
+    # whiten_volume on float32 and float64 volumes, both eps (seg_model.py:114-127; tests/models/test_oaiunet2d.py:61-81)
+    for dt in (np.float32, np.float64):
+        for eps in (0.0, 1e-8):
+            out[f"whiten_{np.dtype(dt).name}_{eps:g}"] = ref_sm.whiten_volume(base.astype(dt), eps=eps)
+    out["sag_vol"], out["sag_aff"] = base, sag_aff
+    out["min_logit_margin"] = np.array(min_margin)
+    print(f"  smallest |logit - cut| over all cases: {min_margin:.3e}")
+    save("g9_generate_mask.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for name in which:
         t = time.time()
         print(name, "...")

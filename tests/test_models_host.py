@@ -91,3 +91,66 @@ def test_restatement_layer_semantics():
     g, bt, mu, var = (w[f"down0_bn_{n}"].astype(np.float64) for n in ("gamma", "beta", "mean", "var"))
     want = g * (c2 - mu) / np.sqrt(var + 1e-3) + bt
     assert np.allclose(feats["down0"][0, 1, 2], want, atol=1e-10)
+
+
+# ---- a14: generate_mask's pre / post logic against the reference's OWN code (golden g9, oracle/make_golden.py g9) ----
+G9_TEMPLATES = {
+    "iwoai": (IWOAIOAIUnet2D, None),
+    "iwoai_norm": (IWOAIOAIUnet2DNormalized, None),
+    "oai": (OAIUnet2D, None),
+    "stanford": (StanfordQDessUNet2D, None),
+    "stanford_thr": (StanfordQDessUNet2D, 0.7),
+}
+
+
+def _g9_probabilities(z, tname, net_in):
+    """The stand-in ``predict`` of the fixture: sigmoid(a_c * v + b_c) per class (float64 -> float32)."""
+    a4, b4 = z["a4"], z["b4"]
+    a, b = {"iwoai": (a4 / 300.0, b4 - 0.8), "oai": (a4[:1], b4[:1])}.get(tname, (a4, b4))
+    logits = net_in.astype(np.float64) * a + b
+    return (1.0 / (1.0 + np.exp(-logits))).astype(np.float32)
+
+
+def test_generate_mask_pre_post_vs_reference(golden):
+    """``_to_network_input`` hands the network exactly the array the reference's ``generate_mask`` hands ``model.predict``
+    and ``_from_network_output`` turns the same probabilities into the same MedicalVolumes (keys and their order, dtype,
+    voxels, affine, orientation) -- four input orientations with an anisotropic, offset affine, every template
+    (oaiunet2d.py:140-175, 291-320, 344-345; stanford_qdess.py:158-205)."""
+    from dosma_amd import MedicalVolume
+
+    z = golden("g9_generate_mask.npz")
+    for oname in z["orient_names"]:
+        vol = MedicalVolume(z[f"{oname}_vol"], z[f"{oname}_affine"])
+        for tname, (cls, thr) in G9_TEMPLATES.items():
+            tag = f"{oname}_{tname}"
+            model = object.__new__(cls)          # no engine: only the host halves are under test
+            if thr is not None:
+                model.sigmoid_threshold = thr
+            vol_sag, v = model._to_network_input(vol)
+            ref_in = z[f"{tag}_net_in"]
+            assert v.shape == ref_in.shape and v.dtype == ref_in.dtype, tag
+            assert np.array_equal(v, ref_in), tag        # same numpy expression on the same voxels: bit-equal
+            out = model._from_network_output(_g9_probabilities(z, tname, ref_in), vol_sag, vol.orientation)
+            keys = [str(k) for k in z[f"{tag}_keys"]]
+            if keys:
+                assert list(out.keys()) == keys, tag
+                items = list(out.items())
+            else:
+                assert isinstance(out, MedicalVolume), tag
+                items = [("", out)]
+            for k, m in items:
+                assert m.volume.dtype == np.uint8 and m.orientation == vol.orientation, (tag, k)
+                assert np.array_equal(m.volume, z[f"{tag}_mask_{k}"]), (tag, k)
+                assert np.allclose(m.affine, z[f"{tag}_affine_{k}"], rtol=0, atol=1e-12), (tag, k)
+
+
+def test_whiten_volume_bit_exact_vs_reference(golden):
+    """seg_model.py:114-127 on float32 and float64 volumes (the reference pins this bit-exactly on its own data,
+    tests/models/test_oaiunet2d.py:61-81)."""
+    z = golden("g9_generate_mask.npz")
+    base = z["sag_vol"]
+    for dt in (np.float32, np.float64):
+        for eps in (0.0, 1e-8):
+            ref = z[f"whiten_{np.dtype(dt).name}_{eps:g}"]
+            got = whiten_volume(base.astype(dt), eps=eps)
+            assert got.dtype == ref.dtype and np.array_equal(got, ref)

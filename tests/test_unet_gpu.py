@@ -344,3 +344,79 @@ def test_dedicated_top_level_kernels_on_small_and_ragged_sizes(small_net, hw):
     tr = eng.trace()
     assert "down0:enc0" in tr and "up0.conv1:mid0" in tr and "up0.conv2:out0+head" in tr, tr
     eng.close()
+
+
+# ---- a14: the real generate_mask (fused GPU route) against the reference's OWN generate_mask (golden g9) ----
+def passthrough_weights(a, b):
+    """Keras-layout weights of the 6-level network that make it the per-pixel map logit_c = a_c * x + b_c -- the stand-in
+    ``predict`` golden g9 was made with: the first block turns x into (relu(x), relu(-x)) on two channels, the skip
+    connection carries them to the last block (every deeper layer is zero), the classifier recombines them.  BatchNorm
+    with moving_variance = 1 - eps is the identity."""
+    from dosma_amd.models import weights as W
+
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    w = {}
+    for name, shp in W.expected_shapes(W.NF, len(a)).items():
+        if name.endswith("_gamma"):
+            w[name] = np.ones(shp, np.float32)
+        elif name.endswith("_var"):
+            w[name] = np.full(shp, 1.0 - 1e-3, np.float32)
+        else:
+            w[name] = np.zeros(shp, np.float32)
+    w["down0_conv1_kernel"][1, 1, 0, 0], w["down0_conv1_kernel"][1, 1, 0, 1] = 1.0, -1.0
+    for name, off in (("down0_conv2_kernel", 0), ("up0_conv1_kernel", 32), ("up0_conv2_kernel", 0)):
+        w[name][1, 1, off + 0, 0] = w[name][1, 1, off + 1, 1] = 1.0   # up0.conv1 reads [upsampled | skip]: skip = 32 ..
+    w["head_kernel"][0, 0, 0, :], w["head_kernel"][0, 0, 1, :] = a, -a
+    w["head_bias"][:] = b
+    return w
+
+
+def test_generate_mask_vs_reference_golden(golden):
+    """The masks the product's ``generate_mask`` returns -- upload, reformat, whitening, network, threshold, class planes,
+    reformat back, all through libqmri_hip.so -- equal the ones the REFERENCE's generate_mask returned for the same
+    volumes (four orientations, anisotropic offset affine, every template, a non-default sigmoid threshold, the
+    dual-echo input of the Stanford template), with the network replaced on both sides by the same per-pixel map
+    (oaiunet2d.py:140-175, 291-320, 344-345; stanford_qdess.py:158-205).  Pixels whose logit is within 2e-3 of the
+    cut are exempt (the fixture marks them): the two sides evaluate a_c * x + b_c in different arithmetic."""
+    from dosma_amd import MedicalVolume
+    from dosma_amd.models.oaiunet2d import IWOAIOAIUnet2D, IWOAIOAIUnet2DNormalized, OAIUnet2D
+    from dosma_amd.models.stanford_qdess import StanfordQDessUNet2D
+
+    z = golden("g9_generate_mask.npz")
+    a4, b4 = z["a4"], z["b4"]
+    templates = {
+        "iwoai": (IWOAIOAIUnet2D, a4 / 300.0, b4 - 0.8, None),
+        "iwoai_norm": (IWOAIOAIUnet2DNormalized, a4, b4, None),
+        "oai": (OAIUnet2D, a4[:1], b4[:1], None),
+        "stanford": (StanfordQDessUNet2D, a4, b4, None),
+        "stanford_thr": (StanfordQDessUNet2D, a4, b4, 0.7),
+    }
+    H, W, _ = z["sag_vol"].shape
+    checked = exempt = 0
+    for tname, (cls, a, b, thr) in templates.items():
+        model = cls((H, W, 1), passthrough_weights(a, b), force_weights=True)
+        if thr is not None:
+            model.sigmoid_threshold = thr
+        cases = [(str(o), MedicalVolume(z[f"{o}_vol"], z[f"{o}_affine"]), f"{o}_{tname}") for o in z["orient_names"]]
+        if tname == "stanford":
+            cases.append(("dual", MedicalVolume(z["dual_vol"], z["sag_aff"]), "dual"))
+        for oname, vol, tag in cases:
+            out = model.generate_mask(vol)
+            keys = [str(k) for k in z[f"{tag}_keys"]]
+            items = list(out.items()) if keys else [("", out)]
+            if keys:
+                assert list(out.keys()) == keys, tag
+            near = z[f"{tag}_near"]                                   # (S, H, W, C), sagittal frame
+            for i, (k, m) in enumerate(items):
+                assert m.volume.dtype == np.uint8 and m.volume.shape == vol.shape[:3], (tag, k)
+                assert m.orientation == vol.orientation, (tag, k)
+                if oname != "dual":
+                    assert np.allclose(m.affine, z[f"{tag}_affine_{k}"], rtol=0, atol=1e-12), (tag, k)
+                # compare in the sagittal frame, where the fixture's near-threshold map lives
+                got = m.reformat(("SI", "AP", "LR")).volume
+                ref = MedicalVolume(z[f"{tag}_mask_{k}"], m.affine).reformat(("SI", "AP", "LR")).volume
+                ok = np.transpose(~near[..., i], (1, 2, 0))
+                assert np.array_equal(got[ok], ref[ok]), (tag, k, int((got[ok] != ref[ok]).sum()))
+                checked += int(ok.sum())
+                exempt += int((~ok).sum())
+    assert exempt < 1e-3 * checked, (exempt, checked)

@@ -177,6 +177,45 @@ def _ref_style_voxel(y_i, x, p0, ftol, maxfev, eps):
     return fo._one_voxel_scipy((fo.monoexponential, x, y_i, p0, ftol, maxfev, eps, 2, False))
 
 
+def effective_cores():
+    """What the lease really delivers: the cgroup CPU quota (cpu.max, v2; cfs quota, v1) next to the affinity count.
+    (256 visible cores, ~10 cores' worth of throughput.)"""
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    return quota
+
+
+def _scaling_ladder(fitter, y_T, cores):
+    """voxel-fits/s of the reference's call pattern with 1, 2, 4, ... workers on a fixed 40 000-voxel slice: where the
+    curve flattens is the number of cores the host actually gives this process."""
+    import multiprocessing as mp
+
+    m = min(len(y_T), 40000)
+    ladder = {}
+    w = 1
+    while w <= cores:
+        with mp.Pool(w) as pool:
+            pool.map(fitter, y_T[: w * 4], chunksize=4)
+            t = time.perf_counter()
+            pool.map(fitter, y_T[:m], chunksize=max(50, min(1000, m // (4 * w))))
+            ladder[w] = m / (time.perf_counter() - t)
+        if w >= 4 and ladder[w] < 1.15 * ladder[w // 2] and ladder[w // 2] < 1.15 * ladder[w // 4]:
+            break   # flat twice in a row: more workers only add processes
+        w *= 2
+    return ladder
+
+
 def cpu_baseline(y_dev, cores_cap=None):
     """The reference's per-voxel scipy loop (fitting.py:855-868) on a bounded sample of the bench volume, timed on
     this host: serial (num_workers = 0), Pool(1) (num_workers = 1) and Pool(all cores) with
@@ -213,6 +252,15 @@ def cpu_baseline(y_dev, cores_cap=None):
         t = time.perf_counter()
         pool.map(fitter, y_T, chunksize=1000)
         dt = time.perf_counter() - t
+    # how many cores does the host really give this process?  cgroup quota if there is one, else where the worker
+    # ladder of the same call pattern flattens (throughput with all workers / throughput with one)
+    ladder = _scaling_ladder(fitter, y_T, cores)
+    quota = effective_cores()
+    scale = max(ladder.values()) / ladder[1]
+    if quota:
+        eff, eff_how = min(float(cores), quota), "cgroup cpu.max quota"
+    else:
+        eff, eff_how = min(float(cores), max(1.0, scale)), "all-worker / one-worker throughput of the reference's call pattern"
     # single-thread C restatement of MINPACK on a slice, for scale
     m = min(n, 200_000)
     t = time.perf_counter()
@@ -229,7 +277,12 @@ def cpu_baseline(y_dev, cores_cap=None):
                    f"scipy.optimize.curve_fit per voxel, rows of y.T through multiprocessing.Pool({cores}).map("
                    f"partial(fitter), chunksize=1000) (the reference's call pattern, fitting.py:860-868), scipy "
                    f"{scipy.__version__}, {dt:.1f} s wall, pool start-up excluded"),
-        "per_core": n / dt / cores,
+        "effective_cores": eff,
+        "effective_cores_how": eff_how,
+        "per_core": n / dt / eff,
+        "per_visible_core": n / dt / cores,
+        "worker_ladder_voxel_fits_per_s": {str(k): v for k, v in ladder.items()},
+        "cgroup_cpu_quota_cores": quota,
         "num_workers_0_serial": m1 / dt_serial,
         "num_workers_1": m1 / dt_one,
         "serial_sample": f"first {m1} voxels",
@@ -336,21 +389,77 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     }
 
 
+UNET_SOURCES = ("unet_s3.hip", "unet_enc0.hip", "unet_kernels.hip", "unet_rw.hip", "unet_engine.hip", "qmri_internal.h")
+
+
+def _source_sha1(files):
+    h = hashlib.sha1()
+    for f in files:
+        with open(os.path.join(ROOT, "dosma_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _unet_source_sha1():
+    return _source_sha1(UNET_SOURCES)
+
+
+def unet_algorithmic_bytes(hw=UNET_HW, slices=UNET_SLICES, nf=(32, 64, 128, 256, 512, 1024)):
+    """Layer-by-layer minimum HBM bytes of one forward in the parity mode AS BUILT (4 B per activation value = fp16 hi +
+    lo; first block, pooling and classifier fused): every feature map that crosses a kernel boundary is written once and
+    read once.  (25.4 GB written + 25.5 GB read = 50.9 GB per 160 slices of 384 x 384.)"""
+    px = [float(hw * hw) / 4 ** l for l in range(len(nf))]
+    wr = rd = 0.0
+    rd += px[0] * 4                                  # the whitened input image (fp32)
+    for l, c in enumerate(nf):                       # encoder
+        if l > 0:
+            rd += px[l] * nf[l - 1] * 4              # conv1 reads the pooled tensor
+            wr += px[l] * c * 4                      # conv1 -> conv2 (level 0: conv1 lives in LDS only)
+            rd += px[l] * c * 4
+        wr += px[l] * c * 4                          # conv2 (+ BN): the skip tensor (deepest level: the bottom tensor)
+        if l < len(nf) - 1:
+            wr += px[l + 1] * c * 4                  # pooled output (fused into conv2's epilogue ...
+            if (hw >> l) <= 48:
+                rd += px[l] * c * 4                  # ... except on the flattened narrow levels: a separate pooling kernel)
+    for l in range(len(nf) - 2, -1, -1):             # decoder
+        c = nf[l]
+        rd += px[l + 1] * nf[l + 1] * 4              # transposed convolution reads the level below
+        wr += px[l] * c * 4                          # ... and writes its half of the concat buffer
+        rd += px[l] * 2 * c * 4                      # conv1 reads [up | skip]
+        wr += px[l] * c * 4                          # conv1 -> conv2
+        rd += px[l] * c * 4
+        if l > 0:
+            wr += px[l] * c * 4                      # conv2 (+ BN) -> next transposed convolution
+    wr += px[0] * (4 * 4 + 4)                        # logits (fp32 x 4) + mask bytes of the fused classifier
+    return slices * (wr + rd), slices * wr, slices * rd
+
+
 def _unet_traffic():
-    """HBM bytes of one 160-slice forward in the parity mode: a constant from the last rocprofv3 --pmc collection
-    (scripts/collect_profile.sh -> profiles/<tag>_unet_counters.json), not re-measured by this run."""
+    """HBM bytes of one 160-slice forward in the parity mode: a constant from the newest rocprofv3 --pmc collection
+    (scripts/collect_profile.sh -> profiles/<tag>_unet_counters.json), not re-measured by this run; `stale` says whether
+    the UNet kernel sources have changed since it was collected."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_unet_counters.json")), reverse=True):
+    alg, alg_w, alg_r = unet_algorithmic_bytes()
+    base = {"algorithmic_bytes": alg, "algorithmic_bytes_written": alg_w, "algorithmic_bytes_read": alg_r,
+            "algorithmic_bytes_note": "layer-by-layer minimum as built (4 B per activation value, first block / pooling / "
+                                      "classifier fused): every feature map crossing a kernel boundary written once, read once"}
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_unet_counters.json")),
+                   key=lambda q: (os.path.basename(q)[:3], os.path.getmtime(q)), reverse=True)
+    for path in paths:
         try:
-            hbm = json.load(open(path)).get("hbm")
+            pj = json.load(open(path))
         except (OSError, ValueError):
             continue
+        hbm = pj.get("hbm")
         if hbm:
-            return {"traffic": hbm["bytes_per_forward"],
+            sha = pj.get("kernel_source_sha1")
+            return {"traffic": hbm["bytes_per_forward"], "traffic_over_algorithmic": hbm["bytes_per_forward"] / alg, **base,
                     "traffic_source": {"file": os.path.relpath(path, ROOT), "per": "160-slice forward (one step of this leg)",
                                        "kind": "constant from a rocprofv3 --pmc collection (FETCH_SIZE doubled per the gfx950 "
-                                               "correction + WRITE_SIZE), not re-measured by this run"}}
-    return {"traffic": None}
+                                               "correction + WRITE_SIZE), not re-measured by this run",
+                                       "kernel_source_sha1": sha,
+                                       "stale": (sha != _unet_source_sha1()) if sha else None}}
+    return {"traffic": None, **base}
 
 
 def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
@@ -441,6 +550,28 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
         walls.append(qd.allreduce_max(time.perf_counter() - t0))
         per_rank = qd.allgather_scalars([mine])[:, 0]
         del res
+    # host <-> device copy bandwidth per rank, every rank copying at the same time: what bounds the host-fed rate of an
+    # N-GPU node (each rank moves 1.34 GB up + 0.67 GB down per volume through ONE host memory system)
+    up_host = np.concatenate([v.reshape(-1) for v in y_host])           # 1.34 GB pageable
+    down_dev = torch.empty(2 * n, dtype=torch.float64, device=device)   # 0.67 GB
+    down_host = np.empty(2 * n, dtype=np.float64)
+    down_host[:] = 0                                                    # pages resident: measure the copy, not the zero-fill
+    up_dev = torch.empty(up_host.size, dtype=torch.float32, device=device)
+    copy_bw = {}
+    for name, fn, nbytes in (("h2d", lambda: up_dev.copy_(torch.from_numpy(up_host)), up_host.nbytes),
+                             ("d2h", lambda: torch.from_numpy(down_host).copy_(down_dev), down_host.nbytes)):
+        fn()
+        torch.cuda.synchronize(device)
+        qd.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(device)
+        mine = time.perf_counter() - t0
+        secs = qd.allgather_scalars([mine])[:, 0]
+        copy_bw[name] = {"bytes_per_rank": int(nbytes), "gb_per_s_per_rank": (nbytes / secs / 1e9).tolist(),
+                         "gb_per_s_all_ranks": float(nbytes * world / secs.max() / 1e9)}
+    del up_dev, down_dev, up_host, down_host
+    host_bytes = 4 * E * n + 16 * n   # per volume and rank through the host entry: samples up, tc + r2 (float64) down
     out["host_feed"] = {
         "what": "qmri_monoexp_fit_host on one 512x512x160x8 float32 volume per rank (1.34 GB of pageable numpy up, tc + r2 "
                 "float64 = 0.67 GB down into result arrays from dosma_amd/_hostpool.py: page-locked blocks recycled when the "
@@ -448,16 +579,18 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
                 "first_call_wall_s includes allocating the blocks",
         "seconds_per_rank": per_rank.tolist(), "wall_s": walls[1], "first_call_wall_s": walls[0],
         "voxel_fits_per_s": n * world / walls[1],
+        "host_bytes_per_rank": host_bytes,
+        "host_traffic_gb_per_s_all_ranks": host_bytes * world / walls[1] / 1e9,
+        "copy_bandwidth": copy_bw,
+        "copy_bandwidth_note": "pageable numpy <-> device copies of the same sizes, all ranks at once (resident pages): "
+                               "gb_per_s_all_ranks is the node-level host traffic these copies sustain at this N -- the "
+                               "ceiling of the host-fed rate; the device-resident headline does not depend on it",
     }
     return out
 
 
 def _kernel_source_sha1():
-    h = hashlib.sha1()
-    for f in ("monoexp_lm.hip", "fp64_fast.h", "qmri_internal.h"):
-        with open(os.path.join(ROOT, "dosma_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    return _source_sha1(("monoexp_lm.hip", "fp64_fast.h", "qmri_internal.h"))
 
 
 def main():
@@ -475,9 +608,13 @@ def main():
     ap.add_argument("--cfg5-volumes-per-gpu", type=int, default=8)
     ap.add_argument("--cfg5-unet-batch", type=int, default=160)
     ap.add_argument("--print-kernel-hash", action="store_true")
+    ap.add_argument("--print-unet-hash", action="store_true")
     args = ap.parse_args()
     if args.print_kernel_hash:
         print(_kernel_source_sha1())
+        return
+    if args.print_unet_hash:
+        print(_unet_source_sha1())
         return
 
     from dosma_amd import _lib as L
@@ -582,8 +719,9 @@ def main():
         # sources they were measured on; a kernel edit makes them "stale" here instead of silently wrong
         traffic = valu_lane_instr = None
         traffic_src = None
-        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-            prof = os.path.join(ROOT, "profiles", name)
+        import glob
+        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_hbm_traffic.json")), reverse=True):
+            name = os.path.basename(prof)
             if os.path.exists(prof):
                 with open(prof) as f:
                     pj = json.load(f)

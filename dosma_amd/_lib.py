@@ -158,7 +158,7 @@ EXPORTS = (
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
-    "qmri_region_stats_device", "qmri_host_alloc", "qmri_host_free",
+    "qmri_region_stats_device", "qmri_host_alloc", "qmri_host_free", "qmri_device_mem_info",
 )
 
 _lib = None
@@ -232,6 +232,8 @@ def load():
         lib.qmri_host_free.argtypes = [ctypes.c_void_p]
         lib.qmri_host_free.restype = ctypes.c_int
         lib.qmri_device_count.restype = ctypes.c_int
+        lib.qmri_device_mem_info.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        lib.qmri_device_mem_info.restype = ctypes.c_int
         lib.qmri_last_error.restype = ctypes.c_char_p
         lib.qmri_monoexp_kernel_name.restype = ctypes.c_char_p
         lib.qmri_monoexp_kernel_name.argtypes = [ctypes.POINTER(QmriMonoexpArgs)]
@@ -323,6 +325,13 @@ def require_device() -> int:
     if n <= 0:
         raise QmriError("no HIP device visible: dosma_amd computes on the GPU only (no CPU fallback)")
     return n
+
+
+def device_mem_info(device=None):
+    """(free, total) bytes of device memory."""
+    f, t = ctypes.c_uint64(), ctypes.c_uint64()
+    check(load().qmri_device_mem_info(_dev(device), ctypes.byref(f), ctypes.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def default_args() -> QmriMonoexpArgs:
@@ -502,8 +511,8 @@ def polyls_host(y, solve, design, *, w=None, per_sequence_rules=False, y_bounds=
     P = solve.shape[0]
     if solve.shape != (P, E) or design.shape != (E, P):
         raise ValueError(f"solve must be (P, {E}) and design ({E}, P)")
-    if P > POLY_MAX_PARAMS or E > MAX_ECHOES:
-        raise NotImplementedError(f"polyfit on the GPU takes deg + 1 <= {POLY_MAX_PARAMS} and at most {MAX_ECHOES} samples")
+    # (deg + 1 <= POLY_MAX_PARAMS and E <= MAX_ECHOES run on the register-resident kernel, anything larger on its
+    #  streaming variant: numpy.polyfit has no such limits and neither has this entry)
     a = QmriPolylsArgs()
     a.y, a.y_dtype, a.E, a.N, a.ld, a.P = _ptr(y), qdtype(y.dtype), E, N, N, P
     dp = ctypes.POINTER(ctypes.c_double)

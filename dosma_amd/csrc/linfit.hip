@@ -145,12 +145,69 @@ __global__ __launch_bounds__(256) void polyls_kernel(const PolylsKArgs A) {
     }
 }
 
+// Any E and P (beyond the register-resident limits above): the same linear map with RUN-TIME loops.  S, D and w stay in
+// global memory (every lane reads the same element: one broadcast line from L1 / L2), the samples of a voxel are re-read
+// once per parameter and once for r2 (they are L2-resident: the block's columns of E rows), the coefficients go to their
+// output row first and are read back for the fitted values.  O(P E) cached loads per voxel instead of E HBM loads: the
+// route for rare sizes, not the hot one.
+template <typename S>
+__global__ __launch_bounds__(256) void polyls_big_kernel(const PolylsKArgs A) {
+    const int P = A.P, E = A.E;
+    const double *Sm = A.ops, *Dm = A.ops + (size_t)P * E, *w = A.ops + (size_t)2 * P * E;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < A.N; v += stride) {
+        const S *col = static_cast<const S *>(A.y) + v;
+        double sy = 0.0;
+        bool allzero = true, oob = false;
+        for (int e = 0; e < E; ++e) {
+            const double s = static_cast<double>(col[(long long)e * A.ld]);
+            allzero = allzero && s == 0.0;
+            if (A.use_y_bounds) oob = oob || s < A.y_lo || s > A.y_hi;
+            sy += s;
+        }
+        const bool skip = A.skip_rules && (allzero || oob);
+        double *c = A.popt + v * P;
+        for (int j = 0; j < P; ++j) {
+            double a = 0.0;
+            for (int e = 0; e < E; ++e) a = fma(Sm[(size_t)j * E + e], static_cast<double>(col[(long long)e * A.ld]), a);
+            c[j] = skip ? NAN : a;
+        }
+        double r2 = 0.0, wres = NAN;
+        if (!skip) {
+            const double ym = sy / (double)E;
+            double ssr = 0.0, syy = 0.0, swr = 0.0;
+            for (int e = 0; e < E; ++e) {
+                double yh = 0.0;
+                for (int j = 0; j < P; ++j) yh = fma(Dm[(size_t)e * P + j], c[j], yh);
+                const double ye = static_cast<double>(col[(long long)e * A.ld]);
+                const double r = yh - ye, dy = ye - ym, wr = w[e] * r;
+                ssr = fma(r, r, ssr);
+                syy = fma(dy, dy, syy);
+                swr = fma(wr, wr, swr);
+            }
+            r2 = 1.0 - ssr / (syy + A.r2_eps);
+            wres = swr;
+        }
+        A.r2[v] = r2;
+        if (A.resid) A.resid[v] = wres;
+    }
+}
+
 hipError_t polyls_launch(const PolylsKArgs &k, int num_cu, hipStream_t stream) {
     long long blocks = (k.N + 255) / 256;
     const long long cap = (long long)num_cu * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     (void)hipGetLastError();
+    if (k.E > QMRI_MAX_ECHOES || k.P > QMRI_POLY_MAX_PARAMS) {
+        switch (k.y_dtype) {
+            case QMRI_F32: hipLaunchKernelGGL(polyls_big_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, k); break;
+            case QMRI_F64: hipLaunchKernelGGL(polyls_big_kernel<double>, dim3((int)blocks), dim3(256), 0, stream, k); break;
+            case QMRI_I16: hipLaunchKernelGGL(polyls_big_kernel<short>, dim3((int)blocks), dim3(256), 0, stream, k); break;
+            default: hipLaunchKernelGGL(polyls_big_kernel<unsigned short>, dim3((int)blocks), dim3(256), 0, stream, k); break;
+        }
+        return hipGetLastError();
+    }
     switch (k.y_dtype) {
         case QMRI_F32: hipLaunchKernelGGL(polyls_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, k); break;
         case QMRI_F64: hipLaunchKernelGGL(polyls_kernel<double>, dim3((int)blocks), dim3(256), 0, stream, k); break;

@@ -261,10 +261,28 @@ int qmri_device_count(void) {
     return n;
 }
 
+int qmri_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(QMRI_ERR_ARG, "qmri_device_mem_info: NULL result pointer");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return QMRI_OK;
+}
+
 int qmri_host_alloc(uint64_t bytes, void **out) {
     if (!out || bytes == 0) return fail(QMRI_ERR_ARG, "qmri_host_alloc: NULL result pointer or zero bytes");
     *out = nullptr;
     HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable));  // (usable from every device of the process)
+    // ROCm marks page-locked host allocations MADV_DONTFORK: a fork()ed child (a multiprocessing worker -- the reference's own
+    // parallelism, dosma/core/fitting.py:860-868) that touches a result array it inherited would fault.  Results handed to
+    // Python live in these blocks (dosma_amd/_hostpool.py), so inheritance is switched back on: the child gets ordinary
+    // copy-on-write pages of the parent's data (it never owns, frees or DMA-targets the block).  Best effort: a platform that
+    // refuses leaves the block as the runtime made it.
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(*out) & ~(uintptr_t)4095;
+    const uintptr_t a1 = (reinterpret_cast<uintptr_t>(*out) + bytes + 4095) & ~(uintptr_t)4095;
+    (void)madvise(reinterpret_cast<void *>(a0), (size_t)(a1 - a0), MADV_DOFORK);
     return QMRI_OK;
 }
 
@@ -643,8 +661,9 @@ static int polyls_validate(const qmri_polyls_args *a) {
     if (!a) return fail(QMRI_ERR_ARG, "args is NULL");
     if (!a->y || !a->solve || !a->design || !a->popt || !a->r2) return fail(QMRI_ERR_ARG, "y, solve, design, popt and r2 are required");
     if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
-    if (a->P < 1 || a->P > QMRI_POLY_MAX_PARAMS) return fail(QMRI_ERR_UNSUPPORTED, "deg + 1 must be in [1, %d]", QMRI_POLY_MAX_PARAMS);
-    if (a->E < 1 || a->E > QMRI_MAX_ECHOES) return fail(QMRI_ERR_UNSUPPORTED, "E must be in [1, %d]", QMRI_MAX_ECHOES);
+    // (beyond QMRI_POLY_MAX_PARAMS parameters / QMRI_MAX_ECHOES samples the streaming variant of the kernel runs)
+    if (a->P < 1 || a->P > 4096) return fail(QMRI_ERR_ARG, "deg + 1 must be in [1, 4096]");
+    if (a->E < 1 || a->E > (1 << 20)) return fail(QMRI_ERR_ARG, "E must be in [1, 2^20]");
     if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
     return QMRI_OK;
 }

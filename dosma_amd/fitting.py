@@ -278,6 +278,8 @@ def polyfit(x, y, deg: int, rcond=None, full=False, w=None, cov=False, eps=1e-8,
     out-of-``y_bounds`` columns -> NaN, r2 0; :1095-1097); like the reference it cannot be combined with full / cov.
     Degree 1 without numpy options runs on the closed-form kernel (linfit.hip); everything else is one (deg+1, E) linear
     map per voxel on the general kernel, built on the host exactly as numpy builds it (:func:`_polyfit_operator`).
+    Any number of samples and any degree: up to 32 samples and degree 7 the map is applied from registers, beyond that by
+    the kernel's streaming variant (slower per voxel, same results).
     """
     scatter_data = num_workers is not None
     if (cov or full) and scatter_data:
@@ -290,7 +292,7 @@ def polyfit(x, y, deg: int, rcond=None, full=False, w=None, cov=False, eps=1e-8,
         warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
     if x.shape[0] != y.shape[0]:
         raise TypeError("expected x and y to have same length")
-    if deg == 1 and not (full or cov) and w is None and rcond is None:
+    if deg == 1 and not (full or cov) and w is None and rcond is None and x.shape[0] <= _lib.MAX_ECHOES:
         out = _lib.linfit_host(x, _as_kernel_samples(y), r2_eps=eps, y_bounds=y_bounds, per_sequence_rules=scatter_data)
         return out["popt"], out["r2"]
 
@@ -670,7 +672,8 @@ class CurveFitter(_Fitter):
 
 
 class PolyFitter(_Fitter):
-    """Linear least squares polynomial fit per voxel (reference :461-604), any degree up to 7, on the GPU."""
+    """Linear least squares polynomial fit per voxel (reference :461-604), any degree, on the GPU (degrees above 7 or more
+    than 32 samples take the general kernel's streaming variant)."""
 
     def __init__(self, deg: int, rcond: float = None, y_bounds=None, out_ufuncs=None,
                  out_bounds=None, r2_threshold="preferences", nan_to_num: float = None,

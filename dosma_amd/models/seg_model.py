@@ -81,13 +81,28 @@ class HipSegModel(SegModel):
             w = W.load_keras_h5(weights_path)
         n_classes = self._n_classes()
         W.validate(w, n_classes=n_classes)
-        # activation buffers: ~1.1 KB per pixel and slice in the parity mode (25 GB for 160 slices of 384 x 384); larger slices
-        # get fewer slices per pass so that one model stays below ~64 GB of the 288
-        per_slice = input_shape[0] * input_shape[1] * 1100
-        fit = max(1, int(64e9 // per_slice))
-        max_batch = max(int(self.batch_size), min(int(self.gpu_batch), fit), 1)
-        return _lib.Unet2dEngine(W.to_abi_order(w), input_shape[0], input_shape[1], n_classes=n_classes,
-                                 max_batch=max_batch, precision=self.precision, device=self.device)
+        # activation buffers: ~1.1 KB per pixel and slice in the parity mode (25 GB for 160 slices of 384 x 384), half of
+        # that in bf16.  One model takes at most 64 GB and at most half of what is FREE on the device right now (other
+        # models / processes share it); if the allocation still fails (a race with another process) the batch is halved
+        # down to the reference's ``batch_size``.
+        per_slice = input_shape[0] * input_shape[1] * (1100 if self.precision != "bf16" else 560)
+        budget = 64e9
+        try:
+            free, _total = _lib.device_mem_info(self.device)
+            budget = min(budget, 0.5 * free)
+        except _lib.QmriError:
+            pass
+        floor = max(int(self.batch_size), 1)
+        max_batch = max(floor, min(int(self.gpu_batch), max(1, int(budget // per_slice))))
+        tensors = W.to_abi_order(w)
+        while True:
+            try:
+                return _lib.Unet2dEngine(tensors, input_shape[0], input_shape[1], n_classes=n_classes,
+                                         max_batch=max_batch, precision=self.precision, device=self.device)
+            except _lib.QmriError as e:
+                if max_batch <= floor or "memory" not in str(e).lower():
+                    raise
+                max_batch = max(floor, max_batch // 2)
 
     def _n_classes(self):
         return 4

@@ -383,6 +383,8 @@ int qmri_host_free(void *p);
 
 int qmri_version(void);
 int qmri_device_count(void);
+/* free / total bytes of device memory (hipMemGetInfo): callers size their per-model activation buffers from it */
+int qmri_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
 const char *qmri_last_error(void);
 /* name of the fit kernel variant that `args` would dispatch to (for profiles / tests) */
 const char *qmri_monoexp_kernel_name(const qmri_monoexp_args *args);

@@ -18,3 +18,4 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_A
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/unet_fetch -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/unet_write -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_write.log 2>&1
 python $R/bench.py --print-kernel-hash > $OUT/kernel_hash.txt
+python $R/bench.py --print-unet-hash > $OUT/unet_hash.txt

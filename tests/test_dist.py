@@ -108,3 +108,44 @@ def test_partition_covers_everything_once():
         for world in (1, 2, 3, 8):
             seen = sorted(i for r in range(world) for i in partition(n, world, r))
             assert seen == list(range(n))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 code path exactly as the driver launches it (torch.distributed.run, one process per rank),
+    with QMRI_BENCH_BACKEND=gloo so that the two ranks can share the box's single GPU: rendezvous, per-rank volumes,
+    the max-over-ranks timing, the UNet weights made on rank 0 and broadcast, BASELINE configs[4] through
+    dist.run_batch, the host-fed leg with every rank copying at once.  (RCCL itself needs one GPU per rank: the 8-GPU
+    runs are the driver's.)"""
+    import json
+
+    env = dict(os.environ, QMRI_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cfg5-volumes-per-gpu", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]        # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    n = 512 * 512 * 160
+    assert out["config"]["voxels_per_gpu_per_step"] == n
+    # value = the units ALL ranks processed / the max-over-ranks time; the N = 1-comparable run is there too
+    assert abs(out["value"] - 2 * n * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["runs"]["A_defaults_fixed_p0"]["voxel_fits_per_s"] == out["value"]
+    assert out["parity"]["nfev_equal_frac"] > 0.999 and out["parity"]["max_rel"] < 1e-4
+    c5 = out["cfg5"]
+    assert c5["per_rank"] == [1, 1] and c5["volumes"] == 2
+    assert c5["weights_broadcast"]["identical_on_all_ranks"] and c5["weights_broadcast"]["bytes"] > 1e8
+    assert c5["voxel_fits_per_s"] > 1e7 and c5["slices_per_s"] > 10
+    hf = c5["host_feed"]
+    assert len(hf["seconds_per_rank"]) == 2 and hf["voxel_fits_per_s"] > 1e7
+    for d in ("h2d", "d2h"):
+        assert len(hf["copy_bandwidth"][d]["gb_per_s_per_rank"]) == 2 and hf["copy_bandwidth"][d]["gb_per_s_all_ranks"] > 1
+    assert out["unet2d"]["value"] > 100 and "cpu_baseline" not in out

@@ -390,6 +390,31 @@ class TestPolyFitter:
         with pytest.raises(ValueError):
             polyfit(x[:3], y[:3], deg=2, cov=True)  # numpy: the number of data points must exceed order
 
+    def test_sizes_beyond_the_register_kernel(self):
+        """numpy.polyfit takes any number of samples and any degree (reference polyfit, fitting.py:873-1013): more than 32
+        samples and degrees above 7 run on the streaming variant of the kernel and agree with numpy like the small ones."""
+        n = 700
+        for E, deg in ((40, 2), (40, 9), (12, 9), (33, 1)):
+            x = np.linspace(-1.0, 1.0, E) + 0.01 * RNG.standard_normal(E)
+            coef = RNG.standard_normal((deg + 1, n))
+            y = np.vander(x, deg + 1) @ coef + 0.05 * RNG.standard_normal((E, n))
+            w = RNG.uniform(0.5, 2.0, E)
+            for ww in (None, w):
+                popt_exp, res_exp, rank_exp, _, _ = np.polyfit(x, y, deg=deg, full=True, w=ww)
+                popt, r2, res, rank, _, _ = polyfit(x, y, deg=deg, full=True, w=ww)
+                assert rank == rank_exp
+                assert np.allclose(popt, popt_exp.T, rtol=1e-7, atol=1e-9), (E, deg)
+                assert np.allclose(res, res_exp, rtol=1e-6), (E, deg)
+                yhat = np.vander(x, deg + 1) @ popt_exp
+                r2_ref = 1 - ((yhat - y) ** 2).sum(0) / (((y - y.mean(0)) ** 2).sum(0) + 1e-8)
+                assert np.allclose(r2, r2_ref, atol=1e-8), (E, deg)
+        # per-sequence rules on the streaming variant too
+        y[:, :5] = 0.0
+        popt, r2 = polyfit(x, y, deg=1, num_workers=0)
+        assert np.isnan(popt[:5]).all() and (r2[:5] == 0).all() and np.isfinite(popt[5:]).all()
+        tc, r2m = PolyFitter(9).fit(x, [MedicalVolume(v.reshape(10, 10, 7), np.eye(4)) for v in y])
+        assert tc.volume.shape == (10, 10, 7, 10)
+
     def test_per_sequence_rules_and_degree_2_fitter(self):
         """num_workers not None = the reference's per-sequence branch (_polyfit, :1076-1103): all-zero and out-of-bounds
         sequences -> NaN, r2 = 0; the joint branch fits them like any other column."""

@@ -55,3 +55,56 @@ def test_results_are_owned_by_the_caller_and_blocks_are_recycled():
     vols = [dm.MedicalVolume(v.reshape(100, 100, 40), np.eye(4)) for v in y]
     tc, r2 = dm.MonoExponentialFit(tc0=30.0).fit(x, vols)
     assert tc.volume.shape == (100, 100, 40) and np.isfinite(r2.volume).all()
+
+
+@pytest.mark.gpu
+def test_forked_child_reads_a_pooled_result():
+    """page-locked allocations are MADV_DONTFORK under ROCm; the library switches inheritance back on
+    (qmri_host_alloc), so a worker forked while a result is alive -- the reference's own multiprocessing pattern -- reads
+    the parent's values instead of faulting, and never recycles the parent's blocks."""
+    import os
+
+    a = _hostpool.empty((4 << 20,), np.float64)     # 32 MB: from the pool
+    if a.base is None:
+        pytest.skip("pool is off")
+    a[:] = np.arange(a.size)
+    expect = float(a[::4097].sum())
+    live = _hostpool.live_bytes()
+    pid = os.fork()
+    if pid == 0:  # child: touch the inherited pages, drop the view (must not free the parent's block), report
+        code = 3
+        try:
+            ok = float(a[::4097].sum()) == expect and a[-1] == a.size - 1
+            del a
+            gc.collect()
+            code = 0 if ok else 2
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"child status {status:#x} (signal {status & 0x7f})"
+    assert float(a[::4097].sum()) == expect and _hostpool.live_bytes() == live   # the parent still owns its block
+    del a
+    gc.collect()
+    assert _hostpool.live_bytes() == live - (32 << 20)
+
+
+@pytest.mark.gpu
+def test_pinned_bytes_are_capped_including_live_results(monkeypatch):
+    """DOSMA_AMD_HOST_POOL_GB bounds live + cached page-locked bytes; beyond it results are plain numpy arrays."""
+    _hostpool.trim()
+    gc.collect()
+    base = _hostpool.live_bytes()
+    monkeypatch.setenv("DOSMA_AMD_HOST_POOL_GB", repr((base + (48 << 20)) / (1 << 30)))   # 48 MB above what is alive now
+    a = _hostpool.empty((2 << 20,), np.float64)    # 16 MB
+    b = _hostpool.empty((2 << 20,), np.float64)
+    assert a.base is not None and b.base is not None and _hostpool.live_bytes() == base + (32 << 20)
+    c = _hostpool.empty((4 << 20,), np.float64)    # 32 MB more would exceed the cap: plain numpy
+    assert c.base is None and _hostpool.live_bytes() == base + (32 << 20)
+    del a, b
+    gc.collect()
+    assert _hostpool.live_bytes() == base and _hostpool.cached_bytes() <= (48 << 20)
+    d = _hostpool.empty((5 << 20,), np.float64)    # 40 MB: fits once cached blocks of other sizes are dropped
+    assert d.base is not None and _hostpool.live_bytes() + _hostpool.cached_bytes() <= base + (48 << 20)
+    del c, d
+    gc.collect()
+    _hostpool.trim()

@@ -501,6 +501,14 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
         QMRI_TIC();
         // ======================= refill: idle lanes pull voxels =======================
         {
+            // The arguments only the refill / epilogue needs (pointers, mask / init / post-processing options) are read from
+            // the kernel-argument segment HERE, through a pointer the compiler cannot see through: left to itself it loads
+            // all ~110 scalar registers' worth of FitKArgs once, keeps them live across the LM step below and spills the
+            // excess into VGPR lanes (192 spills, ~170 v_readlane in the hot loop).  An s_load per refill costs nothing.
+            typedef const __attribute__((address_space(4))) FitKArgs *KArgP;
+            KArgP kp_ = (KArgP)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp_));
+            const FitKArgs &C = *(const FitKArgs *)kp_;
             // A lane that has terminated parks in ST_DONE: its outputs are written here, together with those of the other
             // lanes that finished since the last refill (finishing on the spot ran the ~150-instruction epilogue in
             // almost every round for the ~3 lanes of 64 that terminate per round).
@@ -513,9 +521,9 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     if (done_info >= 1 && done_info <= 4) {
                         oa = pa;
                         ob = pb;
-                        r2 = 1.0 - (fnorm * fnorm) / (sstot + A.r2_eps);
+                        r2 = 1.0 - (fnorm * fnorm) / (sstot + C.r2_eps);
                     }
-                    finish_voxel(A, vox, oa, ob, r2, done_info, nfev, false);
+                    finish_voxel(C, vox, oa, ob, r2, done_info, nfev, false);
                     state = ST_IDLE;
                     nfev = 0;
                 }
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     // over 17.7 M voxels is 69 k claims for 0.05 ms of fitting -> 0.83 ms (BASELINE configs[2]).
                     if (tnext >= tend) {
                         unsigned int t0 = 0;
-                        if (lane == 0) t0 = atomicAdd(A.tile_counter, chunk);
+                        if (lane == 0) t0 = atomicAdd(C.tile_counter, chunk);
                         t0 = __builtin_amdgcn_readfirstlane(t0);
                         tnext = t0;
                         tend = t0 + chunk;
@@ -539,39 +547,39 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                         more = false;
                         break;
                     }
-                    const unsigned int t = A.tile_list ? A.tile_list[ti] : ti;
+                    const unsigned int t = C.tile_list ? C.tile_list[ti] : ti;
                     const long long start = (long long)t * kSub;
                     tile_base = start;
-                    const long long rem = A.N - start;
+                    const long long rem = C.N - start;
                     const int count = rem < kSub ? (int)rem : kSub;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     bool any_selected = true;  // a tile without a single voxel in the mask needs no samples at all
-                    if (A.mask) {
+                    if (C.mask) {
                         bool s = false;
                         for (int k = 0; k < kSub / 64; ++k) {
                             const int j = k * 64 + lane;
-                            if (j < count) s = s || A.mask[start + j] != 0;
+                            if (j < count) s = s || C.mask[start + j] != 0;
                         }
                         any_selected = __ballot(s) != 0;
                     }
                     if (any_selected)
-                    switch (A.y_dtype) {
+                    switch (C.y_dtype) {
                         case QMRI_F32:
-                            stage_rows(static_cast<const float *>(A.y) + start, A.ld, E, count, tile,
-                                       lane, A.vec_ok);
+                            stage_rows(static_cast<const float *>(C.y) + start, C.ld, E, count, tile,
+                                       lane, C.vec_ok);
                             break;
                         case QMRI_F64:
-                            stage_rows(static_cast<const double *>(A.y) + start, A.ld, E, count, tile,
-                                       lane, A.vec_ok);
+                            stage_rows(static_cast<const double *>(C.y) + start, C.ld, E, count, tile,
+                                       lane, C.vec_ok);
                             break;
                         case QMRI_I16:
-                            stage_rows(static_cast<const short *>(A.y) + start, A.ld, E, count, tile,
-                                       lane, A.vec_ok);
+                            stage_rows(static_cast<const short *>(C.y) + start, C.ld, E, count, tile,
+                                       lane, C.vec_ok);
                             break;
                         default:
-                            stage_rows(static_cast<const unsigned short *>(A.y) + start, A.ld, E, count,
-                                       tile, lane, A.vec_ok);
+                            stage_rows(static_cast<const unsigned short *>(C.y) + start, C.ld, E, count,
+                                       tile, lane, C.vec_ok);
                             break;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -587,9 +595,9 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                         if (j < count) {
                             const long long v = start + j;
                             bool selected = true;
-                            if (A.mask) selected = A.mask[v] != 0;
+                            if (C.mask) selected = C.mask[v] != 0;
                             if (!selected) {
-                                finish_voxel(A, v, 0, 0, 0, -1, 0, true);
+                                finish_voxel(C, v, 0, 0, 0, -1, 0, true);
                             } else {
                                 bool allzero = true, finite = true, oob = false;
                                 double mean = 0.0;
@@ -601,16 +609,16 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                         sv[i] = q;
                                         allzero = allzero && (q == 0.0);
                                         finite = finite && isfinite(q);
-                                        if (A.use_y_bounds) oob = oob || q < A.y_lo || q > A.y_hi;
+                                        if (C.use_y_bounds) oob = oob || q < C.y_lo || q > C.y_hi;
                                         mean += q;
                                     }
                                 if (!finite) {
                                     // reference: ValueError for the whole call (scipy check_finite)
-                                    *A.nonfinite = 1;
-                                    finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                                    *C.nonfinite = 1;
+                                    finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
                                 } else if (allzero || oob) {
                                     // skip rule, fitting.py:1064-1067
-                                    finish_voxel(A, v, NAN, NAN, 0.0, 0, 0, false);
+                                    finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
                                 } else {
                                     need_fit = true;
                                     mean = mean * rE;
@@ -622,10 +630,10 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                             st += d * d;
                                         }
                                     t_sst[j] = st;
-                                    if (A.init == QMRI_INIT_PER_VOXEL) {
-                                        t_a0[j] = A.a0v ? A.a0v[v] : A.a0;
-                                        t_b0[j] = A.b0v ? A.b0v[v] : A.b0;
-                                    } else if (A.init == QMRI_INIT_LOGLIN) {
+                                    if (C.init == QMRI_INIT_PER_VOXEL) {
+                                        t_a0[j] = C.a0v ? C.a0v[v] : C.a0;
+                                        t_b0[j] = C.b0v ? C.b0v[v] : C.b0;
+                                    } else if (C.init == QMRI_INIT_LOGLIN) {
                                         // fitting.py:701-718: v + 1e-10*(v==0); log; degree-1 LS in x;
                                         // r2 on the log data; r2 < 0 or NaN -> params 0 -> p0 = (1, 0)
                                         double sl = 0.0;
@@ -645,16 +653,16 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                         for (int i = 0; i < EMAX; ++i)
                                             if (FULL || i < E) {
                                                 const double dy = sv[i] - lmean;
-                                                sxy += (A.x[i] - A.xmean) * dy;
+                                                sxy += (C.x[i] - C.xmean) * dy;
                                                 syy += dy * dy;
                                             }
-                                        const double slope = div_fast(sxy, A.sxx);
-                                        const double icpt = lmean - slope * A.xmean;
+                                        const double slope = div_fast(sxy, C.sxx);
+                                        const double icpt = lmean - slope * C.xmean;
                                         double ssr = 0.0;
 #pragma unroll
                                         for (int i = 0; i < EMAX; ++i)
                                             if (FULL || i < E) {
-                                                const double r = (slope * A.x[i] + icpt) - sv[i];
+                                                const double r = (slope * C.x[i] + icpt) - sv[i];
                                                 ssr += r * r;
                                             }
                                         const double r2l = 1.0 - div_fast(ssr, syy + 1e-8);
@@ -691,9 +699,9 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                             else yv[i] = 0;
                         sstot = t_sst[j];
                         vox = tile_base + j;
-                        pa = A.a0;
-                        pb = A.b0;
-                        if (A.init != QMRI_INIT_SCALAR) {
+                        pa = C.a0;
+                        pb = C.b0;
+                        if (C.init != QMRI_INIT_SCALAR) {
                             pa = t_a0[j];
                             pb = t_b0[j];
                         }

@@ -419,4 +419,4 @@ def test_generate_mask_vs_reference_golden(golden):
                 assert np.array_equal(got[ok], ref[ok]), (tag, k, int((got[ok] != ref[ok]).sum()))
                 checked += int(ok.sum())
                 exempt += int((~ok).sum())
-    assert exempt < 1e-3 * checked, (exempt, checked)
+    assert exempt < 5e-3 * checked, (exempt, checked)   # (the 2e-3 band around the cut holds ~0.1 % of the pixels)

@@ -104,5 +104,8 @@ def _build_locked(bdir: str, verbose: bool, force: bool = False) -> str:
 if __name__ == "__main__":
     if "--experiments" in sys.argv:
         print(build_variant("exp", ["-DQMRI_S3_EXPERIMENTS"]))
+    elif "--variant" in sys.argv:  # python -m dosma_amd.build --variant NAME -DFLAG ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

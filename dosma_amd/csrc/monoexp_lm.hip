@@ -433,10 +433,18 @@ __device__ __forceinline__ void stage_rows(const S *__restrict__ g, long long ld
 
 enum : int { ST_IDLE = 0, ST_INIT = 1, ST_ITER = 2, ST_DONE = 3 };  // DONE: converged, outputs not written yet
 
-// LDS bytes one wave owns: samples [E][kSub] of LT + SStot, a0, b0 (double) + 1-byte queue entries
+// Result ring of a wave: terminated voxels are parked here (voxel index + MINPACK info / nfev, a, b, |f|, SStot) and
+// post-processed + stored 64 at a time with every lane active (see the refill block of the kernel).
+constexpr int kRing = 128;        // entries: up to 63 waiting + 64 appended in one refill
+constexpr int kRingBytes = kRing * 5 * 8;
+
+// LDS bytes one wave owns: samples [E][kSub] of LT + SStot, a0, b0 (double) + the result ring + 1-byte queue entries
+// (variants up to 8 samples only: from 9 samples on the ring would cost the fourth wave of a block -- 2 x 4 waves no longer
+//  fit the CU's 160 KB -- and the in-lane epilogue is the better deal)
+__host__ __device__ constexpr bool use_result_ring(int E) { return E <= 8; }
 template <typename LT>
 __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
-    return (size_t)E * kSub * sizeof(LT) + (size_t)kSub * (3 * sizeof(double) + 1);
+    return (size_t)E * kSub * sizeof(LT) + (size_t)kSub * (3 * sizeof(double) + 1) + (use_result_ring(E) ? kRingBytes : 0);
 }
 
 // Two blocks (8 waves) per CU = two waves per SIMD is what the VALU-bound solver needs; the register allocation of the
@@ -452,14 +460,33 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
     const int wave = threadIdx.x >> 6;
     const int E = FULL ? EMAX : A.E;
     const double rE = 1.0 / (double)E;
-    // wave-private LDS slice: samples [E][kSub] | SStot [kSub] | a0 [kSub] | b0 [kSub] | queue [kSub]
+    // wave-private LDS slice: samples [E][kSub] | SStot [kSub] | a0 [kSub] | b0 [kSub] | result ring [5][kRing] | queue [kSub]
     unsigned char *slice = smem + (size_t)wave * lds_bytes_per_wave<LT>(E);
     LT *tile = reinterpret_cast<LT *>(slice);
     double *t_sst = reinterpret_cast<double *>(slice + (size_t)E * kSub * sizeof(LT));
     double *t_a0 = t_sst + kSub;
     double *t_b0 = t_a0 + kSub;
-    unsigned char *t_queue = reinterpret_cast<unsigned char *>(t_b0 + kSub);
+    unsigned long long *r_vox = reinterpret_cast<unsigned long long *>(t_b0 + kSub);  // voxel | info << 40 | nfev << 48
+    double *r_a = reinterpret_cast<double *>(r_vox + kRing);
+    double *r_b = r_a + kRing;
+    double *r_fn = r_b + kRing;
+    double *r_sst = r_fn + kRing;
+    constexpr bool kUseRing = use_result_ring(EMAX);
+    unsigned char *t_queue = kUseRing ? reinterpret_cast<unsigned char *>(r_sst + kRing) : reinterpret_cast<unsigned char *>(t_b0 + kSub);
+    int rhead = 0, rcount = 0;  // wave-uniform: first waiting entry, number of waiting entries
     const double epsmch = DBL_EPSILON;
+    // the sample times as an LDS table: the LM step reads x[i] with broadcast ds_read (LDS port) instead of holding 2 E
+    // scalar registers across the whole loop -- they were the largest block the scalar allocator spilled and restored
+    // (v_readlane = VALU slots) next to every use
+    // Measured: 12 samples 6.96 -> 6.68 ms, 8 samples 6.07 -> 6.26 ms (the table's read latency sits in the dependent chain
+    // of a short evaluation), 16 samples: the loaded values push the vector registers over 256 -> 9 .. 12 samples only.
+    constexpr bool kXsLds = EMAX > 8 && EMAX <= 12;
+    __shared__ double xs_tab[kXsLds ? EMAX : 1];
+    if (kXsLds) {
+        if (threadIdx.x < EMAX) xs_tab[threadIdx.x] = (FULL || (int)threadIdx.x < A.E) ? A.x[threadIdx.x] : 0.0;
+        __syncthreads();
+    }
+#define QMRI_XS(i) (kXsLds ? xs_tab[(i)] : A.x[(i)])
 
     // ---- per-lane LM state (fp64 registers) ----
     int state = ST_IDLE;
@@ -492,6 +519,33 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
         chunk = want > 16 ? 16u : (want < 1 ? 1u : (unsigned int)want);
     }
 
+    // post-processing + stores of the first n (<= 64) waiting ring entries, one per lane
+    auto flush_ring = [&](const FitKArgs &K, int n) {
+        if (lane < n) {
+            const int slot = (rhead + lane) & (kRing - 1);
+            const unsigned long long w = r_vox[slot];
+            const long long v = (long long)(w & ((1ull << 40) - 1));
+            const int info = (int)(signed char)((w >> 40) & 0xFF);
+            const int nf = (int)(w >> 48);
+            // fitting.py:1032-1035 (success) / :1069-1072 (RuntimeError -> NaN, 0)
+            double oa = NAN, ob = NAN, r2 = 0.0;
+            if (info >= 1 && info <= 4) {
+                const double fn = r_fn[slot];
+                oa = r_a[slot];
+                ob = r_b[slot];
+                r2 = 1.0 - (fn * fn) / (r_sst[slot] + K.r2_eps);
+            }
+#ifdef QMRI_FIT_NOSTORE  // timing experiment (results wrong): what do the solver's result stores + epilogue cost?
+            if (v == -1)
+#endif
+            finish_voxel(K, v, oa, ob, r2, info, nf, false);
+        }
+        rhead = (rhead + n) & (kRing - 1);
+        rcount -= n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
 #ifdef QMRI_STATS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t1 = 0;
@@ -515,17 +569,43 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
             unsigned long long idle = __ballot(state == ST_IDLE || state == ST_DONE);
             const int nidle = __popcll(idle);
             if (nidle >= A.refill_idle || nidle == 64) {
-                if (state == ST_DONE) {
-                    // fitting.py:1032-1035 (success) / :1069-1072 (RuntimeError -> NaN, 0)
-                    double oa = NAN, ob = NAN, r2 = 0.0;
-                    if (done_info >= 1 && done_info <= 4) {
-                        oa = pa;
-                        ob = pb;
-                        r2 = 1.0 - (fnorm * fnorm) / (sstot + C.r2_eps);
+                // Terminated lanes do NOT run the reference's post-processing here: a refill finds 8-16 of them, and the
+                // ~150-instruction epilogue (r2, 1/|b|, bounds, nan_to_num, rounding, three stores) at 15-25 % lane
+                // occupancy was 8 % of the kernel (measured with the stores + epilogue compiled out: 21.4 -> 19.7 ms).  They
+                // append (voxel, info, nfev, a, b, |f|, SStot) to the wave's result ring -- five LDS writes -- and the
+                // epilogue runs on 64 ring entries at a time with every lane active (flush_ring).
+                if (!kUseRing) {
+                    if (state == ST_DONE) {
+                        double oa = NAN, ob = NAN, r2 = 0.0;
+                        if (done_info >= 1 && done_info <= 4) {
+                            oa = pa;
+                            ob = pb;
+                            r2 = 1.0 - (fnorm * fnorm) / (sstot + C.r2_eps);
+                        }
+                        finish_voxel(C, vox, oa, ob, r2, done_info, nfev, false);
+                        state = ST_IDLE;
+                        nfev = 0;
                     }
-                    finish_voxel(C, vox, oa, ob, r2, done_info, nfev, false);
-                    state = ST_IDLE;
-                    nfev = 0;
+                } else {
+                    const unsigned long long dmask = __ballot(state == ST_DONE);
+                    if (state == ST_DONE) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dmask, 0u));
+                        const int slot = (rhead + rcount + rank) & (kRing - 1);
+                        r_vox[slot] = (unsigned long long)vox | ((unsigned long long)(done_info & 0xFF) << 40) |
+                                      ((unsigned long long)(nfev & 0xFFFF) << 48);
+                        r_a[slot] = pa;
+                        r_b[slot] = pb;
+                        r_fn[slot] = fnorm;
+                        r_sst[slot] = sstot;
+                        state = ST_IDLE;
+                        nfev = 0;
+                    }
+                    rcount += __popcll(dmask);
+                    if (rcount >= 64) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        flush_ring(C, 64);
+                    }
                 }
                 // ---- queue empty: claim tiles until one has fit-able voxels (or the volume is done) ----
                 while (qpos >= qend && more) {
@@ -653,7 +733,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                         for (int i = 0; i < EMAX; ++i)
                                             if (FULL || i < E) {
                                                 const double dy = sv[i] - lmean;
-                                                sxy += (C.x[i] - C.xmean) * dy;
+                                                sxy += ((kXsLds ? xs_tab[i] : C.x[i]) - C.xmean) * dy;
                                                 syy += dy * dy;
                                             }
                                         const double slope = div_fast(sxy, C.sxx);
@@ -662,7 +742,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
 #pragma unroll
                                         for (int i = 0; i < EMAX; ++i)
                                             if (FULL || i < E) {
-                                                const double r = (slope * C.x[i] + icpt) - sv[i];
+                                                const double r = (slope * (kXsLds ? xs_tab[i] : C.x[i]) + icpt) - sv[i];
                                                 ssr += r * r;
                                             }
                                         const double r2l = 1.0 - div_fast(ssr, syy + 1e-8);
@@ -761,7 +841,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     for (int k = 0; k < A.x0_pow; ++k) e0 *= q1;
                     ev[0] = e0;
                 } else {
-                    ev[0] = exp(mul_rn(tb, A.x[0]));
+                    ev[0] = exp(mul_rn(tb, QMRI_XS(0)));
                 }
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
@@ -769,7 +849,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
             } else {
 #pragma unroll
                 for (int i = 0; i < EMAX; ++i)
-                    if (FULL || i < E) ev[i] = exp(mul_rn(tb, A.x[i]));
+                    if (FULL || i < E) ev[i] = exp(mul_rn(tb, QMRI_XS(i)));
                     else ev[i] = 0.0;
             }
 #pragma unroll
@@ -893,7 +973,8 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                         if (FULL || i < E) {
                             const double yi = static_cast<double>(yv[i]);
                             const double e = ev[i];
-                            const double d = sub_rn(mul_rn(b1, A.x[i]), mul_rn(pb, A.x[i]));
+                            const double xi = QMRI_XS(i);
+                            const double d = sub_rn(mul_rn(b1, xi), mul_rn(pb, xi));
                             const double e1 = e + e * (d + d * d * (0.5 + d * (1.0 / 6.0)));
                             c2[i] = sub_rn(sub_rn(mul_rn(pa, e1), yi), fv[i]) * rhb;
                             ev[i] = sub_rn(sub_rn(mul_rn(a1, e), yi), fv[i]) * rha;
@@ -1028,6 +1109,11 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
         st_acc[5] += __popcll(__ballot(did_qr));
         st_acc[6] += __popcll(__ballot(did_finish));
 #endif
+    }
+    if (rcount > 0) {  // (the loop ends with every lane idle: what is left in the ring is < 64 entries)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        flush_ring(A, rcount);
     }
 #ifdef QMRI_STATS
     if (lane == 0)

@@ -127,6 +127,7 @@ struct Enc0Args {
     int yoff;
     void *pool_y;          // pooled map (split layout), pixel stride pool_ld channels
     int pool_ld;
+    int *sat;              // nullable: set to 1 when a value stored in the split layout exceeds the fp16 range (see ConvS3Args)
 };
 size_t enc0_lds_bytes();
 bool enc0_supported(const Enc0Args &k);
@@ -163,6 +164,7 @@ struct Mid0Args {
     void *y;               // 32-channel output (split layout), pixel stride ldy channels, channel offset yoff
     long long ldy;
     int yoff;
+    int *sat;              // nullable: saturation flag (see ConvS3Args)
 };
 size_t mid0_lds_bytes();
 bool mid0_supported(const Mid0Args &k);
@@ -204,6 +206,7 @@ struct ConvKArgs {
     const float *head_b; // [head_nc]
     float *logits;       // [pixels][head_nc]
     unsigned char *mask; // [pixels][head_nc]  (logit > 0)
+    int *sat;            // parity mode, nullable: saturation flag (see ConvS3Args)
 };
 hipError_t conv_igemm_launch(const ConvKArgs &k, int split3, hipStream_t stream);
 
@@ -237,13 +240,18 @@ struct ConvS3Args {
     // filled by conv_s3_launch
     int chunks, steps, nb, ntiles, nwork, tiles_x, tiles_y, P, nj;
     int dbg;             // QMRI_S3_DBG timing experiments (0 in production)
+    // Saturation flag (nullable).  The split layout stores a value as fp16 hi + lo parts; v_cvt_pkrtz clamps at 65504, so a
+    // feature-map value beyond the fp16 range would be stored wrong WITHOUT any error.  Every kernel that writes the layout
+    // tracks max |v| of what it stores and sets *sat = 1 when it exceeds 65504; the engine then repeats the forward with the
+    // whole network scaled down by a power of two (exact: unet_engine.hip, `act_shift`) instead of returning clamped results.
+    int *sat;
 };
 bool conv_s3_supported(const ConvS3Args &k);
 int conv_s3_block_channels(int Cout, int deconv);  // channel-block size the kernel uses for a layer: the weight packing depends on it
 hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 // streaming kernels on the split layout (unet_s3.hip)
 hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
-                           long long ldy, int yoff, hipStream_t stream);
+                           long long ldy, int yoff, int *sat, hipStream_t stream);
 hipError_t maxpool2_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, void *y, hipStream_t stream);
 hipError_t maxpoolk_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y,
                                  hipStream_t stream);
@@ -264,6 +272,8 @@ hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStre
 hipError_t transpose_ps_launch(const float *x, long long P, int S, float *y, hipStream_t stream);
 hipError_t mask_planes_launch(const unsigned char *mask_sp4, long long P, int S, int C, unsigned char *out,
                               hipStream_t stream);
+hipError_t absmax_launch(const float *x, long long n, unsigned int *out, hipStream_t stream);
+hipError_t scale_copy_launch(const float *x, long long n, float f, float *y, hipStream_t stream);
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
                          hipStream_t stream);
 

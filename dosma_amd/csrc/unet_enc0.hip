@@ -60,6 +60,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// the same, tracking max |value| for the saturation flag of the split layout (qmri_internal.h: ConvS3Args::sat)
+__device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo, float &amax) {
+    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+    split2(a, b, hi, lo);
+}
 
 #ifdef QMRI_S3_EXPERIMENTS
 __device__ unsigned long long enc0_tstat[8];  // cycles of wave 0: [0] MFMA loop [1] barrier A [2] output staging [3] barrier B [4] conv 1 + stores + pool [5] barrier C [6] tiles
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kgrp = lane >> 5;
+    float amax = 0.f;  // max |v| of everything this lane split (input pixels, both feature maps): Enc0Args::sat
 
     // ---- once per block: resident weights, per-lane operand constants ----
     for (int i = tid; i < kWBytes / 16; i += kThreads)
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         }
         unsigned bh[4], bl[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split2(tp[2 * i], tp[2 * i + 1], bh[i], bl[i]);
+        for (int i = 0; i < 4; ++i) split2m(tp[2 * i], tp[2 * i + 1], bh[i], bl[i], amax);
         const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
         const f16x8 xl = __builtin_bit_cast(f16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned h0, l0, h1, l1;
-            split2(fmaxf(acc[4 * q] * sc, 0.f), fmaxf(acc[4 * q + 1] * sc, 0.f), h0, l0);
-            split2(fmaxf(acc[4 * q + 2] * sc, 0.f), fmaxf(acc[4 * q + 3] * sc, 0.f), h1, l1);
+            split2m(fmaxf(acc[4 * q] * sc, 0.f), fmaxf(acc[4 * q + 1] * sc, 0.f), h0, l0, amax);
+            split2m(fmaxf(acc[4 * q + 2] * sc, 0.f), fmaxf(acc[4 * q + 3] * sc, 0.f), h1, l1, amax);
             *reinterpret_cast<uint2 *>(halo + halo_off(hp, 0, q) + 8 * kgrp) = make_uint2(h0, h1);
             *reinterpret_cast<uint2 *>(halo + halo_off(hp, 1, q) + 8 * kgrp) = make_uint2(l0, l1);
         }
@@ -255,8 +261,8 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                 v[i] = fmaf(fmaxf(fmaf(acc[e], A.winv2, pb[e]), 0.f), ps[e], pt[e]);
             }
             unsigned h0, l0, h1, l1;
-            split2(v[0], v[1], h0, l0);
-            split2(v[2], v[3], h1, l1);
+            split2m(v[0], v[1], h0, l0, amax);
+            split2m(v[2], v[3], h1, l1, amax);
             *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
             *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
         }
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     if (tid == 0)
         for (int i = 0; i < 7; ++i) atomicAdd(&enc0_tstat[i], tacc[i]);
 #endif
+    if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
 
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kgrp = lane >> 5;
+    float amax = 0.f;  // Mid0Args::sat
 
     for (int i = tid; i < kM_Chunks * kWBytes / 16; i += kO_Threads)
         reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
@@ -747,8 +755,8 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(acc[4 * q + i], A.winv, pb[4 * q + i]), 0.f);
             unsigned h0, l0, h1, l1;
-            split2(v[0], v[1], h0, l0);
-            split2(v[2], v[3], h1, l1);
+            split2m(v[0], v[1], h0, l0, amax);
+            split2m(v[2], v[3], h1, l1, amax);
             *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
             *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
         }
@@ -777,6 +785,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
 }  // namespace

@@ -102,6 +102,7 @@ struct ConvLayer {
     DevBuf w_s3;         // parity mode, conv_s3_kernel: per channel block and K step the [plane][BN][64 B] LDS image
     float winv = 1.f;    // 2^-wshift
     bool has_affine = false;
+    std::vector<float> bias_h, shift_h;  // host copies of the ADDITIVE epilogue parameters (rescaled by Unet::set_act_shift)
 
     // fp16 hi / lo images of the host weights W[co][K] (K = (chunk * ntaps + tap) * 32 + c)
     hipError_t upload_parity(const std::vector<float> &wk, bool for_s3) {
@@ -156,7 +157,9 @@ struct ConvLayer {
         if (e == hipSuccess) e = hipMemcpy(w_lo.p, lo.data(), n * 2, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = bias.alloc((size_t)Cout * 4);
         if (e == hipSuccess) e = hipMemcpy(bias.p, b, (size_t)Cout * 4, hipMemcpyHostToDevice);
+        bias_h.assign(b, b + Cout);
         has_affine = sc != nullptr;
+        if (has_affine) shift_h = *sh;
         if (has_affine) {
             if (e == hipSuccess) e = scale.alloc((size_t)Cout * 4);
             if (e == hipSuccess) e = shift.alloc((size_t)Cout * 4);
@@ -304,7 +307,60 @@ struct Unet {
     DevBuf bottom, stats, vol, logits, mask;
     DevBuf vol_in, mask_all, mask_planes;  // whole-volume staging of qmri_unet2d_segment_volume
     long long vol_cap = 0, seg_cap = 0;
+    // ---- fp16 range of the split layout (parity mode) ----
+    // A feature-map value beyond 65504 cannot be stored as fp16 hi + lo parts (v_cvt_pkrtz clamps): IWOAIOAIUnet2D feeds raw
+    // 12 / 16-bit intensities (oaiunet2d.py:322-323).  Every kernel that writes the layout sets `sat` when it meets such a
+    // value, and the forward is then REPEATED with the whole network scaled by 2^-act_shift: input * 2^-S, every bias and
+    // BatchNorm shift * 2^-S, classifier weights * 2^S.  ReLU, max-pooling, convolution and the BatchNorm scale commute with
+    // a positive factor, so every activation is exactly 2^-S times what it was and the logits are unchanged -- bit for bit
+    // (powers of two; nothing here is near the subnormal range) -- while the stored values move back into range.
+    DevBuf sat;                       // int flag (device)
+    int act_shift = 0;                // S the device-side parameters currently carry
+    int act_bump = 0;                 // what saturating forwards have added to the exponent chosen from the input so far
+    std::vector<float> c1_k, c1_b_h, head_w_h;  // host copies: first-layer kernel [9][C] + bias [C], classifier weights [C][ncls]
+    int *sat_ptr() const { return sat.as<int>(); }
+    int set_act_shift(int S);
 };
+
+// (re)upload every additive parameter for activation exponent S (see Unet::sat)
+int Unet::set_act_shift(int S) {
+    if (S == act_shift) return QMRI_OK;
+    const float down = std::ldexp(1.f, -S), up = std::ldexp(1.f, S);
+    std::vector<float> t;
+    auto put = [&](DevBuf &dst, const std::vector<float> &src, float f) -> hipError_t {
+        if (!dst.p || src.empty()) return hipSuccess;
+        t.resize(src.size());
+        for (size_t i = 0; i < src.size(); ++i) t[i] = src[i] * f;
+        return hipMemcpy(dst.p, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+    };
+    auto layer = [&](ConvLayer *L) -> hipError_t {
+        if (!L) return hipSuccess;
+        hipError_t e = put(L->bias, L->bias_h, down);
+        if (e == hipSuccess && L->has_affine) e = put(L->shift, L->shift_h, down);
+        return e;
+    };
+    for (auto *vec : {&down1, &down2, &up1, &up2, &updec, &updec_ph, &updec3})
+        for (auto &L : *vec) U_TRY(layer(L.get()));
+    U_TRY(put(c1_b, c1_b_h, down));
+    U_TRY(put(head_w, head_w_h, up));
+    if (c1_img.p) {  // the fused first block's MFMA operand carries the bias on its constant-one tap
+        const int C = nf[0];
+        std::vector<float> all(c1_k);
+        for (float b : c1_b_h) all.push_back(b * down);
+        const int sh = weight_shift(all);
+        c1_winv = std::ldexp(1.f, -sh);
+        std::vector<unsigned short> img(64 * 16, 0);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i) {
+                const int ch = lane & 31, k = (lane >> 5) * 8 + i;
+                const float v = k < 9 ? c1_k[k * C + ch] : k == 9 ? c1_b_h[ch] * down : 0.f;
+                split_f16_host(std::ldexp(v, sh), img[lane * 16 + i], img[lane * 16 + 8 + i]);
+            }
+        U_TRY(hipMemcpy(c1_img.p, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    }
+    act_shift = S;
+    return QMRI_OK;
+}
 
 }  // namespace
 
@@ -402,6 +458,8 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             U_TRY(hipMemcpy(U->c1_w.p, k1, (size_t)9 * C * 4, hipMemcpyHostToDevice));
             U_TRY(U->c1_b.alloc((size_t)C * 4));
             U_TRY(hipMemcpy(U->c1_b.p, b1, (size_t)C * 4, hipMemcpyHostToDevice));
+            U->c1_k.assign(k1, k1 + 9 * C);
+            U->c1_b_h.assign(b1, b1 + C);
             if (C == 32) {  // K = 16 operand of the fused first block: taps 0..8, the bias on a constant-one tap, zeros
                 std::vector<float> all(k1, k1 + 9 * C);
                 all.insert(all.end(), b1, b1 + C);
@@ -478,6 +536,9 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
     U_TRY(hipMemcpy(U->head_w.p, T[ti], (size_t)U->nf[0] * U->ncls * 4, hipMemcpyHostToDevice));
     U_TRY(U->head_b.alloc((size_t)U->ncls * 4));
     U_TRY(hipMemcpy(U->head_b.p, T[ti + 1], (size_t)U->ncls * 4, hipMemcpyHostToDevice));
+    U->head_w_h.assign(T[ti], T[ti] + (size_t)U->nf[0] * U->ncls);
+    U_TRY(U->sat.alloc(2 * sizeof(int)));  // [0] saturation flag, [1] max |input| (bit pattern)
+    U_TRY(hipMemset(U->sat.p, 0, 2 * sizeof(int)));
 
     // activation buffers for max_batch slices
     const long long B = U->maxB;
@@ -543,6 +604,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
         k.relu = L.relu;
         k.y = y; k.ldy = ldy; k.yoff = yoff;
+        k.sat = U->sat_ptr();
         const int bn = qmri::conv_s3_block_channels(L.Cout, 0);
         const bool flat = W % 32 != 0;
         const bool fuse_pool = pool_y && !flat && bn >= 64 && !(H & 1);
@@ -571,6 +633,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
     k.w_hi = L.h_hi.as<__bf16>();
     k.w_lo = L.h_lo.as<__bf16>();
     k.winv = L.winv;
+    k.sat = U->sat_ptr();
     if (pool_y && !((H | W) & 1)) { k.pool_y = pool_y; k.pool_ld = pool_ld; }
     U_TRY(qmri::conv_igemm_launch(k, 1, st));
     snprintf(buf, sizeof(buf), "%s:igemm%s;", name, k.pool_y ? "+pool" : "");
@@ -601,12 +664,13 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             k.bias2 = L2.bias.as<float>(); k.scale2 = L2.scale.as<float>(); k.shift2 = L2.shift.as<float>();
             k.y = U->cat[0]->p; k.ldy = 2 * C; k.yoff = C;
             k.pool_y = U->pool[1]->p; k.pool_ld = C;
+            k.sat = U->sat_ptr();
             U_TRY(qmri::enc0_launch(k, U->num_cu, st));
             U->trace += "down0:enc0;";
             continue;
         }
         if (l == 0) {
-            U_TRY(qmri::c1_split_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(), C, t1, C, 0, st));
+            U_TRY(qmri::c1_split_launch(U->in.as<float>(), Bt, H, W, U->c1_w.as<float>(), U->c1_b.as<float>(), C, t1, C, 0, U->sat_ptr(), st));
             U->trace += "down0.conv1:c1/split;";
         } else {
             snprintf(nm, sizeof(nm), "down%d.conv1", l);
@@ -640,6 +704,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
                 k.w_hi = L.h_hi.as<__bf16>();
                 k.w_lo = L.h_lo.as<__bf16>();
                 k.winv = L.winv;
+                k.sat = U->sat_ptr();
                 U_TRY(qmri::conv_igemm_launch(k, 1, st));
             }
             snprintf(nm, sizeof(nm), "up%d.deconv:igemm/stride3;", l);
@@ -654,6 +719,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
                 k.w = L.w_s3.p; k.winv = L.winv;
                 k.bias = L.bias.as<float>();
                 k.y = cat; k.ldy = 2 * C; k.yoff = 0;
+                k.sat = U->sat_ptr();
                 U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
                 snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/bn%d;", l, U->Wl[l + 1] % 32 ? "flat" : "2d", qmri::conv_s3_block_channels(L.Cout, 1));
             } else {
@@ -661,6 +727,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
                 k.w_hi = L.h_hi.as<__bf16>();
                 k.w_lo = L.h_lo.as<__bf16>();
                 k.winv = L.winv;
+                k.sat = U->sat_ptr();
                 U_TRY(qmri::conv_igemm_launch(k, 1, st));
                 snprintf(nm, sizeof(nm), "up%d.deconv:igemm;", l);
             }
@@ -678,6 +745,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             k.x = cat; k.ldx = 2 * C; k.xoff = 0; k.B = Bt; k.H = H; k.W = W;
             k.w = L1.w_s3.p; k.winv = L1.winv; k.bias = L1.bias.as<float>();
             k.y = t1; k.ldy = C; k.yoff = 0;
+            k.sat = U->sat_ptr();
             U_TRY(qmri::mid0_launch(k, U->num_cu, st));
             U->trace += "up0.conv1:mid0;";
         } else {
@@ -798,6 +866,58 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     return QMRI_OK;
 }
 
+}  // extern "C"
+
+// ---- the fp16 range of the split layout: choose / raise the activation exponent, repeat on saturation (Unet::sat) ----
+// `body()` queues the whole volume through the network on `st` with the parameters as they are.  Plain bf16 activations
+// have the fp32 exponent range: one pass, no flag.
+template <class F>
+static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hipStream_t st, F &&body) {
+    if (!U->split3) {
+        const int rc0 = U->set_act_shift(0);
+        return rc0 != QMRI_OK ? rc0 : body();
+    }
+    int S = 0;
+    if (!whitened) {  // raw intensities (IWOAIOAIUnet2D, oaiunet2d.py:322-323): bring max |x| below 128 to start with
+        unsigned int bits = 0;
+        U_TRY(qmri::absmax_launch(xd, n, reinterpret_cast<unsigned int *>(U->sat_ptr() + 1), st));
+        U_TRY(hipMemcpyAsync(&bits, U->sat_ptr() + 1, sizeof(bits), hipMemcpyDeviceToHost, st));
+        U_TRY(hipStreamSynchronize(st));
+        float m;
+        std::memcpy(&m, &bits, 4);
+        if (std::isfinite(m) && m >= 128.f) S = std::ilogb(m) - 6;
+    }
+    S += U->act_bump;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (S > 60) break;
+        int rc = U->set_act_shift(S);
+        if (rc != QMRI_OK) return rc;
+        U_TRY(hipMemsetAsync(U->sat.p, 0, sizeof(int), st));
+        rc = body();
+        if (rc != QMRI_OK) return rc;
+        int flag = 0;
+        U_TRY(hipMemcpyAsync(&flag, U->sat.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        U_TRY(hipStreamSynchronize(st));
+        if (!flag) {
+            U->trace += "act_shift:" + std::to_string(S) + ";";  // (tests: which exponent the forward ran at)
+            return QMRI_OK;
+        }
+        S += 6;             // a feature map left the fp16 range: the same forward, 64 times smaller (exactly)
+        U->act_bump += 6;   // (remembered: the next volume of this model starts there)
+    }
+    return ufail(QMRI_ERR_UNSUPPORTED,
+                 "feature-map values exceed the fp16 hi + lo range of the parity mode even after scaling the network by 2^-%d; "
+                 "use precision \"bf16\" for this model / input", S);
+}
+
+// one batch of the (already whitened) device volume -> U->in, scaled by 2^-act_shift
+static hipError_t load_batch(Unet *U, const float *src, long long count, hipStream_t st) {
+    if (U->act_shift == 0) return hipMemcpyAsync(U->in.p, src, (size_t)count * 4, hipMemcpyDeviceToDevice, st);
+    return qmri::scale_copy_launch(src, count, std::ldexp(1.f, -U->act_shift), U->in.as<float>(), st);
+}
+
+extern "C" {
+
 int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_device, int32_t whiten,
                         double whiten_eps, float *logits, uint8_t *mask, int32_t out_on_device,
                         void *stream) {
@@ -838,24 +958,28 @@ int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_de
             mk_dev = U->mask.as<unsigned char>();
         }
     }
-    for (int s0 = 0; s0 < S; s0 += U->maxB) {
-        const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
-        U_TRY(hipMemcpyAsync(U->in.p, xd + (long long)s0 * slice, (size_t)Bt * slice * 4,
-                             hipMemcpyDeviceToDevice, st));
-        float *lg = out_on_device ? (logits ? logits + (long long)s0 * slice * U->ncls : nullptr) : lg_dev;
-        unsigned char *mk = out_on_device ? (mask ? mask + (long long)s0 * slice * U->ncls : nullptr) : mk_dev;
-        const int rc = forward_batch(U, Bt, lg, mk, st);
-        if (rc != QMRI_OK) return rc;
-        if (!out_on_device) {
-            if (logits)
-                U_TRY(hipMemcpyAsync(logits + (long long)s0 * slice * U->ncls, lg_dev,
-                                     (size_t)Bt * slice * U->ncls * 4, hipMemcpyDeviceToHost, st));
-            if (mask)
-                U_TRY(hipMemcpyAsync(mask + (long long)s0 * slice * U->ncls, mk_dev,
-                                     (size_t)Bt * slice * U->ncls, hipMemcpyDeviceToHost, st));
-            U_TRY(hipStreamSynchronize(st));  // staging buffers are reused by the next batch
+    auto body = [&]() -> int {
+        for (int s0 = 0; s0 < S; s0 += U->maxB) {
+            const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
+            U_TRY(load_batch(U, xd + (long long)s0 * slice, (long long)Bt * slice, st));
+            float *lg = out_on_device ? (logits ? logits + (long long)s0 * slice * U->ncls : nullptr) : lg_dev;
+            unsigned char *mk = out_on_device ? (mask ? mask + (long long)s0 * slice * U->ncls : nullptr) : mk_dev;
+            const int rc = forward_batch(U, Bt, lg, mk, st);
+            if (rc != QMRI_OK) return rc;
+            if (!out_on_device) {
+                if (logits)
+                    U_TRY(hipMemcpyAsync(logits + (long long)s0 * slice * U->ncls, lg_dev,
+                                         (size_t)Bt * slice * U->ncls * 4, hipMemcpyDeviceToHost, st));
+                if (mask)
+                    U_TRY(hipMemcpyAsync(mask + (long long)s0 * slice * U->ncls, mk_dev,
+                                         (size_t)Bt * slice * U->ncls, hipMemcpyDeviceToHost, st));
+                U_TRY(hipStreamSynchronize(st));  // staging buffers are reused by the next batch
+            }
         }
-    }
+        return QMRI_OK;
+    };
+    const int rc = run_in_range(U, xd, n, whiten != 0, st, body);
+    if (rc != QMRI_OK) return rc;
     if (!out_on_device || !x_on_device) U_TRY(hipStreamSynchronize(st));
     return QMRI_OK;
 }
@@ -888,20 +1012,27 @@ int qmri_unet2d_segment_volume(void *handle, const float *vol_hws, int32_t S, in
     if (whiten) U_TRY(qmri::whiten_launch(U->vol.as<float>(), n, whiten_eps, U->stats.as<double>(), U->vol.as<float>(), st));
     if (U->ncls < 4) U_TRY(hipMemsetAsync(U->mask_all.p, 0, (size_t)n * 4, st));
     unsigned char *mk_all = U->mask_all.as<unsigned char>();
-    for (int s0 = 0; s0 < S; s0 += U->maxB) {
-        const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
-        U_TRY(hipMemcpyAsync(U->in.p, U->vol.as<float>() + (long long)s0 * P, (size_t)Bt * P * 4, hipMemcpyDeviceToDevice, st));
-        unsigned char *mk = U->ncls == 4 ? mk_all + (long long)s0 * P * 4 : nullptr;
-        if (U->ncls == 4) {
-            const int rc = forward_batch(U, Bt, nullptr, mk, st);
-            if (rc != QMRI_OK) return rc;
-        } else {  // fewer classes: the network writes ncls bytes per pixel; widen to the 4-byte records on the way
-            if (!U->mask.p) U_TRY(U->mask.alloc((size_t)U->maxB * P * U->ncls));
-            const int rc = forward_batch(U, Bt, nullptr, U->mask.as<unsigned char>(), st);
-            if (rc != QMRI_OK) return rc;
-            U_TRY(hipMemcpy2DAsync(mk_all + (long long)s0 * P * 4, 4, U->mask.p, (size_t)U->ncls, (size_t)U->ncls,
-                                   (size_t)Bt * P, hipMemcpyDeviceToDevice, st));
+    auto body = [&]() -> int {
+        for (int s0 = 0; s0 < S; s0 += U->maxB) {
+            const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
+            U_TRY(load_batch(U, U->vol.as<float>() + (long long)s0 * P, (long long)Bt * P, st));
+            unsigned char *mk = U->ncls == 4 ? mk_all + (long long)s0 * P * 4 : nullptr;
+            if (U->ncls == 4) {
+                const int rc = forward_batch(U, Bt, nullptr, mk, st);
+                if (rc != QMRI_OK) return rc;
+            } else {  // fewer classes: the network writes ncls bytes per pixel; widen to the 4-byte records on the way
+                if (!U->mask.p) U_TRY(U->mask.alloc((size_t)U->maxB * P * U->ncls));
+                const int rc = forward_batch(U, Bt, nullptr, U->mask.as<unsigned char>(), st);
+                if (rc != QMRI_OK) return rc;
+                U_TRY(hipMemcpy2DAsync(mk_all + (long long)s0 * P * 4, 4, U->mask.p, (size_t)U->ncls, (size_t)U->ncls,
+                                       (size_t)Bt * P, hipMemcpyDeviceToDevice, st));
+            }
         }
+        return QMRI_OK;
+    };
+    {
+        const int rc = run_in_range(U, U->vol.as<float>(), n, whiten != 0, st, body);
+        if (rc != QMRI_OK) return rc;
     }
     U_TRY(qmri::mask_planes_launch(mk_all, P, S, U->ncls, U->mask_planes.as<unsigned char>(), st));
     {

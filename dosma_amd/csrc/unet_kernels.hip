@@ -90,6 +90,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
     constexpr bool ACT_BF16 = sizeof(AT) == 2;  // activations stored as bf16 (plain bf16 mode), or split fp16 hi | lo (SPLIT3;
                                                 // AT = float is then only the type of the epilogue's LDS tile)
     static_assert(SPLIT3 != ACT_BF16, "plain mode: bf16 activations; parity mode: split fp16 activations");
+    float amax = 0.f;  // parity mode: max |v| of what this thread stores in the split layout (ConvKArgs::sat)
     constexpr bool WALL = BN <= 64 && !SPLIT3;
     using C = TileCfg<BN, TH, WALL, TW, NW, WN>;
     constexpr int NPLANES = SPLIT3 ? 2 : 1;
@@ -285,6 +286,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
                 for (int c = 0; c < 8; ++c) rhb[r][c] = static_cast<__bf16>(o[c]);
             } else {
                 uint4 hi_, lo_;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) amax = fmaxf(amax, o[c]);
                 split_f16(o, hi_, lo_);
                 rhb[r] = __builtin_bit_cast(bf16x8, hi_);
                 rhl[r] = __builtin_bit_cast(bf16x8, lo_);
@@ -433,7 +436,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
                     const float *src = reinterpret_cast<const float *>(otile) + (size_t)row * BN + (c >> 3) * 32 + (c & 3) * 8;
                     float v8[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v8[q] = src[q];
+                    for (int q = 0; q < 8; ++q) {
+                        v8[q] = src[q];
+                        amax = fmaxf(amax, fabsf(v8[q]));
+                    }
                     uint4 hi_, lo_;
                     split_f16(v8, hi_, lo_);
                     *reinterpret_cast<uint4 *>(dst) = (c & 4) ? lo_ : hi_;
@@ -514,6 +520,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
             }
         }
     }
+    if constexpr (SPLIT3)
+        if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
 #undef QMRI_LOAD_HALO
@@ -984,6 +992,35 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(stats + 1, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---- activation exponent of the parity mode (unet_engine.hip: Unet::sat): max |x| of the input, and y = x * 2^-S ----
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long long n, unsigned int *__restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict__ x, long long n, float f, float *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = x[i] * f;
+}
+hipError_t absmax_launch(const float *x, long long n, unsigned int *out /*device, zeroed here*/, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, out);
+    return hipGetLastError();
+}
+hipError_t scale_copy_launch(const float *x, long long n, float f, float *y, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, f, y);
+    return hipGetLastError();
 }
 
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats /*[3] device*/, float *y,

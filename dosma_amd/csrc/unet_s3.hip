@@ -317,6 +317,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
         }
     };
 
+    float amax = 0.f;  // max |v| of everything this lane has stored in the split layout (saturation flag, ConvS3Args::sat)
     f32x16 acc[NPH][RT][CT];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                             }
                         }
                         if (A.y) {
+                            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                             const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                             const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
                             const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
@@ -814,6 +816,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
+    if (A.sat && amax > 65504.f) *A.sat = 1;  // (the pooled values are maxima of stored ones: covered)
 }
 
 static size_t s3_lds_bytes(int bn, int nj) {
@@ -922,9 +925,10 @@ __device__ __forceinline__ long long split_group_off(int g) { return (long long)
 constexpr int kC1Rows = 16;
 __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__ x, int B, int H, int W,
                                                        const float *__restrict__ w /*[9][C]*/, const float *__restrict__ bias,
-                                                       int Cout, unsigned char *__restrict__ y, long long ldy, int yoff) {
+                                                       int Cout, unsigned char *__restrict__ y, long long ldy, int yoff, int *sat) {
     const int groups = Cout / 8;
     const int strips = (H + kC1Rows - 1) / kC1Rows;
+    float amax = 0.f;  // saturation flag of the split layout (ConvS3Args::sat)
     const long long total = (long long)B * strips * W * groups;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(idx % groups);
@@ -965,7 +969,10 @@ __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] = fmaf(win[k / 3][k % 3], wt[k][c], acc[c]);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
+            for (int c = 0; c < 8; ++c) {
+                acc[c] = fmaxf(acc[c], 0.f);
+                amax = fmaxf(amax, acc[c]);
+            }
             uint4 hi, lo;
             split8(acc, hi, lo);
             const long long pix = (b * H + yh) * W + xw;
@@ -979,6 +986,7 @@ __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__
             }
         }
     }
+    if (sat && amax > 65504.f) *sat = 1;
 }
 
 // MaxPooling2D(k x k), k = 2 or 3 (oaiunet2d.py:234-243), split in (pixel stride ldx, offset xoff) -> compact split out
@@ -1077,10 +1085,10 @@ unsigned grid_for(long long total) {
 }  // namespace
 
 hipError_t c1_split_launch(const float *x, int B, int H, int W, const float *w, const float *bias, int Cout, void *y,
-                           long long ldy, int yoff, hipStream_t stream) {
+                           long long ldy, int yoff, int *sat, hipStream_t stream) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(c1_split_kernel, dim3(grid_for((long long)B * ((H + kC1Rows - 1) / kC1Rows) * W * (Cout / 8))), dim3(256), 0, stream, x, B, H, W, w, bias,
-                       Cout, static_cast<unsigned char *>(y), ldy, yoff);
+                       Cout, static_cast<unsigned char *>(y), ldy, yoff, sat);
     return hipGetLastError();
 }
 hipError_t maxpoolk_split_launch(const void *x, long long ldx, int xoff, int B, int H, int W, int C, int K, void *y,

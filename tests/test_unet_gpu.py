@@ -420,3 +420,62 @@ def test_generate_mask_vs_reference_golden(golden):
                 checked += int(ok.sum())
                 exempt += int((~ok).sum())
     assert exempt < 5e-3 * checked, (exempt, checked)   # (the 2e-3 band around the cut holds ~0.1 % of the pixels)
+
+
+# ---- the fp16 range of the split layout: raw intensities and large feature maps are rescaled, never clamped ----
+def _shift_of(eng):
+    tok = [t for t in eng.trace() if t.startswith("act_shift:")]
+    return int(tok[-1].split(":")[1]) if tok else None
+
+
+def test_raw_intensity_input_runs_in_range(small_net):
+    """IWOAIOAIUnet2D feeds the network RAW intensities (oaiunet2d.py:322-323): 16-bit MRI values and the feature maps they
+    produce are far outside the fp16 range of the hi + lo activation layout.  The engine runs the whole network scaled by a
+    power of two (exact) instead of clamping: the logits agree with the fp64 restatement to fp32 rounding of their own
+    magnitude, here and on the ragged-size route (general kernels)."""
+    w, tensors = small_net
+    rng = np.random.default_rng(21)
+    for (S, H, W) in ((3, 64, 96), (2, 72, 144)):       # conv_s3 / dedicated kernels; the odd-size route (c1_split, general kernels, stride-3)
+        vol = rng.uniform(1e3, 6.5e4, (S, H, W)).astype(np.float32)
+        vol[:, : H // 4] = rng.integers(0, 65536, (S, H // 4, W)).astype(np.float32)   # the whole uint16 range, 65535 included
+        eng = L.Unet2dEngine(tensors, H, W, max_batch=2, precision="fp16x3")
+        logits, mask = eng.forward_host(vol, whiten=False)
+        shift = _shift_of(eng)
+        assert shift is not None and shift >= 9, eng.trace()       # max |x| = 65535 -> below 128
+        ref = uo.forward(w, vol, dtype="float64")
+        scale = np.abs(ref).max()
+        assert scale > 1e3                                         # (feature maps well beyond 65504 without the rescaling)
+        assert np.abs(logits - ref).max() < 1e-5 * scale + 1e-3, (np.abs(logits - ref).max(), scale)   # (1e-3 on unit-scale logits)
+        assert (mask == (ref > 0)).mean() > 0.9999
+        # the same engine on whitened data afterwards: back to exponent 0, the usual 1e-3
+        lw, _ = eng.forward_host(vol, whiten=True)
+        assert _shift_of(eng) == 0
+        xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+        assert np.abs(lw - uo.forward(w, xw, dtype="float64")).max() < 1e-3
+        eng.close()
+
+
+def test_saturating_feature_maps_trigger_a_rescaled_repeat(small_net):
+    """Unit-scale (whitened) input, but a first layer that amplifies by 2^18: the input gives no hint, the feature maps
+    leave the fp16 range, the kernels raise the saturation flag and the forward is repeated at a higher exponent -- the
+    result is the restatement's, and the model remembers the exponent for its next volume."""
+    w, _ = small_net
+    w = {k: np.array(v) for k, v in w.items()}
+    w["down0_conv1_kernel"] = w["down0_conv1_kernel"] * np.float32(2.0 ** 18)
+    w["down0_conv2_kernel"] = w["down0_conv2_kernel"] * np.float32(2.0 ** -18)   # the rest of the network sees usual magnitudes
+    tensors = weights_in_abi_order(w)
+    rng = np.random.default_rng(22)
+    S, H, W = 2, 64, 64
+    vol = (rng.standard_normal((S, H, W)) * 90 + 250).astype(np.float32)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+    ref = uo.forward(w, xw, dtype="float64")
+    for kw in ({}, {"QMRI_ENC0": "0"}):      # the fused first block and the three-kernel route
+        eng = L.Unet2dEngine(tensors, H, W, max_batch=2, precision="fp16x3")
+        logits, _ = eng.forward_host(vol, whiten=True)
+        first = _shift_of(eng)
+        assert first is not None and first >= 6, eng.trace()
+        assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
+        logits2, _ = eng.forward_host(vol, whiten=True)        # second volume: starts at the remembered exponent
+        assert _shift_of(eng) == first and np.array_equal(logits, logits2)
+        eng.close()
+        break  # (QMRI_ENC0 is read once per process: the second route is covered by the ragged size above)

@@ -410,10 +410,17 @@ __device__ __forceinline__ void stage_rows(const S *__restrict__ g, long long ld
         LT *dst = tile + e * kSub;
         if (vec_ok && count == kSub) {
             // 4 consecutive elements per lane: one 16-byte (f32) / 8-byte (i16) / 2x16-byte (f64) load
-            struct alignas(sizeof(S) * 4) V4 {
+            // non-temporal: every sample is read exactly once -- the streaming rows should not push the partially written
+            // result lines of the tiles in flight out of the L2 (scattered per-voxel stores merge there or not at all)
+            typedef S VecS __attribute__((ext_vector_type(4)));
+            struct V4 {
                 S v[4];
             };
-            const V4 q = *reinterpret_cast<const V4 *>(row + lane * 4);
+            V4 q;
+            {
+                const VecS t = __builtin_nontemporal_load(reinterpret_cast<const VecS *>(row + lane * 4));
+                q.v[0] = t[0]; q.v[1] = t[1]; q.v[2] = t[2]; q.v[3] = t[3];
+            }
             struct alignas(sizeof(LT) * 4) L4 {
                 LT v[4];
             };

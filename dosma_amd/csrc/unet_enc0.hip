@@ -62,7 +62,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 }
 // the same, tracking max |value| for the saturation flag of the split layout (qmri_internal.h: ConvS3Args::sat)
 __device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo, float &amax) {
-    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+#ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));  // one v_max3_f32 with |.| modifiers
+#endif
     split2(a, b, hi, lo);
 }
 

@@ -438,7 +438,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvKArgs A) 
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         v8[q] = src[q];
+#ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
                         amax = fmaxf(amax, fabsf(v8[q]));
+#endif
                     }
                     uint4 hi_, lo_;
                     split_f16(v8, hi_, lo_);

@@ -681,7 +681,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                             }
                         }
                         if (A.y) {
-                            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
+                            amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));  // (two v_max3_f32 with |.| modifiers)
+#endif
+#ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
+                            amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+#endif
                             const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                             const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
                             const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
@@ -971,7 +976,9 @@ __global__ __launch_bounds__(256) void c1_split_kernel(const float *__restrict__
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 acc[c] = fmaxf(acc[c], 0.f);
+#ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
                 amax = fmaxf(amax, acc[c]);
+#endif
             }
             uint4 hi, lo;
             split8(acc, hi, lo);

@@ -37,13 +37,21 @@
 
 namespace qmri {
 
-constexpr int kSub = 256;        // voxels per tile (per wave): 4 per lane -> 16-byte loads for f32
+#ifndef QMRI_KSUB
+#define QMRI_KSUB 128
+#endif
+constexpr int kSub = QMRI_KSUB;  // voxels per tile (per wave).  128 (2 per lane, 8-byte staging loads for f32) since round 3: a
+                                 // wave's LDS slice is 12.4 KB at 8 samples, so that 12 waves fit the CU's 160 KB (256: 19.7 KB)
+constexpr int kVpl = kSub / 64;  // voxels per lane of a tile
+static_assert(kSub == 256 || kSub == 128, "tile = 4 or 2 voxels per lane");
 #ifndef QMRI_REFILL
 #define QMRI_REFILL 16
 #endif
 #ifndef QMRI_SMALL_E_BLOCKS
-#define QMRI_SMALL_E_BLOCKS 2  // blocks of 4 waves per CU the EMAX <= 8 variants are register-bounded for (measured with 3:
-                               // 168 VGPRs + 102 spilled to scratch, 1.17e9 instead of 1.89e9 voxel-fits/s)
+#define QMRI_SMALL_E_BLOCKS 3  // blocks of 4 waves per CU the EMAX <= 8 variants are register-bounded for: THREE waves per SIMD
+                               // (168 VGPRs + 48 spilled at 8 samples, 4 at 4 samples) since round 3 -- 20.7 -> 18.2 ms.  Round 2
+                               // measured the opposite (168 + 102 spilled: 1.17e9 instead of 1.89e9 voxel-fits/s): the cold kernel
+                               // arguments were still in the scalar registers then, and the LDS slices allowed two blocks only
 #endif
 #ifndef QMRI_MIN_WAVES
 #define QMRI_MIN_WAVES 1
@@ -409,25 +417,18 @@ __device__ __forceinline__ void stage_rows(const S *__restrict__ g, long long ld
         const S *row = g + (long long)e * ld;
         LT *dst = tile + e * kSub;
         if (vec_ok && count == kSub) {
-            // 4 consecutive elements per lane: one 16-byte (f32) / 8-byte (i16) / 2x16-byte (f64) load
+            // kVpl consecutive elements per lane: one 8-byte (f32) / 4-byte (i16) / 16-byte (f64) load at 2 per lane
             // non-temporal: every sample is read exactly once -- the streaming rows should not push the partially written
             // result lines of the tiles in flight out of the L2 (scattered per-voxel stores merge there or not at all)
-            typedef S VecS __attribute__((ext_vector_type(4)));
-            struct V4 {
-                S v[4];
-            };
-            V4 q;
-            {
-                const VecS t = __builtin_nontemporal_load(reinterpret_cast<const VecS *>(row + lane * 4));
-                q.v[0] = t[0]; q.v[1] = t[1]; q.v[2] = t[2]; q.v[3] = t[3];
-            }
-            struct alignas(sizeof(LT) * 4) L4 {
-                LT v[4];
+            typedef S VecS __attribute__((ext_vector_type(kVpl)));
+            const VecS t = __builtin_nontemporal_load(reinterpret_cast<const VecS *>(row + lane * kVpl));
+            struct alignas(sizeof(LT) * kVpl) L4 {
+                LT v[kVpl];
             };
             L4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o.v[k] = static_cast<LT>(q.v[k]);
-            *reinterpret_cast<L4 *>(dst + lane * 4) = o;
+            for (int k = 0; k < kVpl; ++k) o.v[k] = static_cast<LT>(t[k]);
+            *reinterpret_cast<L4 *>(dst + lane * kVpl) = o;
         } else {
 #pragma unroll
             for (int k = 0; k < kSub / 64; ++k) {
@@ -1129,10 +1130,9 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
 }
 
 // The scatter fill of fitting.py:205-215 for one whole tile outside the mask: the same values finish_voxel writes with
-// outside_mask = true, as 16-byte stores (a tile is kSub = 256 consecutive voxels, so every output row of it is one
+// outside_mask = true, as 16-byte stores (a pre-pass group is 256 consecutive voxels, so every output row of it is one
 // aligned contiguous run).
 __device__ __forceinline__ void fill_tile(const FitKArgs &A, long long start, int lane) {
-    static_assert(kSub == 256, "4 voxels per lane");
     const qmri_post &P = A.post;
     const double fill = (P.enable && P.use_nan_to_num) ? P.nan_value : NAN;
     double tc = fill;
@@ -1173,27 +1173,30 @@ __device__ __forceinline__ void fill_tile(const FitKArgs &A, long long start, in
 }
 
 // ---- masked volumes: tile classification pre-pass ---------------------------------------------------
-// One wave per 256-voxel tile: no voxel selected -> the scatter fill of fitting.py:205-215 for the whole tile
+// One wave per 256-voxel group: no voxel selected -> the scatter fill of fitting.py:205-215 for the whole group
 // (streaming writes); otherwise the tile index goes to a compact list that the fit kernel walks.  A cartilage ROI is
 // ~2 % of the voxels in one or two slabs: without the list the fit waves spend their time claiming empty tiles, and
 // the few waves whose claims fall inside the slab do all the fitting.
 __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArgs A, unsigned int *list,
                                                                    unsigned int *count) {
     const int lane = threadIdx.x & 63;
-    const long long ntiles = (A.N + kSub - 1) / kSub;
-    // wide stores need 16-byte aligned output rows (a tile starts at a multiple of 256 elements of each of them)
+    // The pre-pass works on GROUPS of kPre = 256 voxels (one 4-byte mask word per lane, 16-byte fills) whatever the fit kernel's
+    // tile size; a group with selected voxels puts its kPre / kSub tiles -- those that hold a selected voxel -- on the list.
+    constexpr int kPre = 256, kPerGroup = kPre / kSub, kLanesPerTile = 64 / kPerGroup;
+    const long long ngroups = (A.N + kPre - 1) / kPre;
+    // wide stores need 16-byte aligned output rows (a group starts at a multiple of 256 elements of each of them)
     const bool wide = ((reinterpret_cast<uintptr_t>(A.popt) | reinterpret_cast<uintptr_t>(A.r2) |
                         reinterpret_cast<uintptr_t>(A.tc) | reinterpret_cast<uintptr_t>(A.info) |
                         reinterpret_cast<uintptr_t>(A.nfev)) & 15) == 0;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-    // one 4-byte mask load per lane covers a whole tile; the next tile's word is in flight while this one is classified
-    // and filled (the loop is otherwise one dependent load latency per tile)
+    // one 4-byte mask load per lane covers a whole group; the next group's word is in flight while this one is classified
+    // and filled (the loop is otherwise one dependent load latency per group)
     const bool mask_words = (reinterpret_cast<uintptr_t>(A.mask) & 3) == 0;
-    auto tile_word = [&](long long t) -> unsigned int {
-        const long long start = t * kSub;
-        if (t >= ntiles) return 0u;
-        if (mask_words && A.N - start >= kSub) return reinterpret_cast<const unsigned int *>(A.mask + start)[lane];
+    auto group_word = [&](long long g) -> unsigned int {
+        const long long start = g * kPre;
+        if (g >= ngroups) return 0u;
+        if (mask_words && A.N - start >= kPre) return reinterpret_cast<const unsigned int *>(A.mask + start)[lane];
         unsigned int w = 0;
         for (int k = 0; k < 4; ++k) {
             const long long j = start + 4 * lane + k;
@@ -1201,18 +1204,34 @@ __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArg
         }
         return w;
     };
-    unsigned int word = tile_word(wave0);
-    for (long long t = wave0; t < ntiles; t += nwaves) {
-        const unsigned int next = tile_word(t + nwaves);
-        const long long start = t * kSub;
+    unsigned int word = group_word(wave0);
+    for (long long g = wave0; g < ngroups; g += nwaves) {
+        const unsigned int next = group_word(g + nwaves);
+        const long long start = g * kPre;
         const long long rem = A.N - start;
-        const int cnt = rem < kSub ? (int)rem : kSub;
-        if (__ballot(word != 0)) {
-            if (lane == 0) list[atomicAdd(count, 1u)] = (unsigned int)t;
-        } else if (cnt == kSub && wide) {
+        const int cnt = rem < kPre ? (int)rem : kPre;
+        const unsigned long long sel = __ballot(word != 0);  // lane l holds voxels 4 l .. 4 l + 3 of the group
+        if (sel) {
+#pragma unroll
+            for (int h = 0; h < kPerGroup; ++h) {
+                const unsigned long long part = kPerGroup == 1 ? ~0ull : (((1ull << kLanesPerTile) - 1ull) << (h * kLanesPerTile));
+                const long long tstart = start + (long long)h * kSub;
+                if (tstart >= A.N) break;
+                if (sel & part) {
+                    if (lane == 0) list[atomicAdd(count, 1u)] = (unsigned int)(g * kPerGroup + h);
+                } else {  // this tile of the group holds no selected voxel: its fill (rare: the edge of the region)
+                    const long long trem = A.N - tstart;
+                    const int tc = trem < kSub ? (int)trem : kSub;
+                    for (int k = 0; k < kVpl; ++k) {
+                        const int j = k * 64 + lane;
+                        if (j < tc) finish_voxel(A, tstart + j, 0, 0, 0, -1, 0, true);
+                    }
+                }
+            }
+        } else if (cnt == kPre && wide) {
             fill_tile(A, start, lane);
         } else {
-            for (int k = 0; k < kSub / 64; ++k) {
+            for (int k = 0; k < kPre / 64; ++k) {
                 const int j = k * 64 + lane;
                 if (j < cnt) finish_voxel(A, start + j, 0, 0, 0, -1, 0, true);
             }
@@ -1223,8 +1242,8 @@ __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArg
 
 hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu,
                                 hipStream_t stream) {
-    const long long ntiles = (k.N + kSub - 1) / kSub;
-    long long blocks = (ntiles + 3) / 4;
+    const long long ngroups = (k.N + 255) / 256;
+    long long blocks = (ngroups + 3) / 4;
     if (blocks > (long long)num_cu * 8) blocks = (long long)num_cu * 8;
     (void)hipGetLastError();
     hipLaunchKernelGGL(monoexp_mask_prepass_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, k, list, count);
@@ -1237,7 +1256,7 @@ hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned 
 template <typename LT>
 static int waves_per_block(int E) {
     const size_t tile = lds_bytes_per_wave<LT>(E);
-    int w = (int)((80 * 1024) / tile);
+    int w = (int)((160 * 1024 / QMRI_SMALL_E_BLOCKS) / tile);  // (room for QMRI_SMALL_E_BLOCKS blocks per CU)
     if (w < 1) w = (int)((160 * 1024) / tile);
     if (w > 4) w = 4;
     return w;  // 0 -> does not fit (cannot happen for E <= QMRI_MAX_ECHOES)

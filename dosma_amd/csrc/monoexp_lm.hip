@@ -460,7 +460,11 @@ __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
 // "AGPR" overflow for others = one wave per SIMD, -40 %), so the bound is stated: a handful of spills (<= 10 VGPRs) beats
 // losing the second wave.  EMAX = 16: 14.0 ms instead of 16.8 for the exact-size variant (148 spills), but 52.9 instead
 // of 18.8 for the partial one (340 spills); EMAX = 32 does not fit either way.
-template <int EMAX, bool FULL, typename LT>
+// LISTED: the launch walks a compact tile list made by the mask pre-pass (instantiated for the variants up to 8 samples; the
+// others walk the list with the general code).  A listed launch is a region of interest -- typically a few tiles per wave --
+// and partitions a SHORT list statically; keeping that logic out of the dense instantiation keeps the headline kernel's
+// register allocation as it was (any extra state in its claim path cost 20 spilled VGPRs and 6 % at the 168-register limit).
+template <int EMAX, bool FULL, typename LT, bool LISTED = false>
 __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16 && FULL) ? 2 : QMRI_MIN_WAVES)) void monoexp_lm_kernel(
     const FitKArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -525,6 +529,19 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
     {
         const long long want = ntiles / ((long long)nwaves * 4);
         chunk = want > 16 ? 16u : (want < 1 ? 1u : (unsigned int)want);
+    }
+    // LISTED: a SHORT list (a thin ROI: a few tiles per wave) is partitioned statically, wave w takes tiles [w, w + 1) *
+    // ceil(ntiles / nwaves): with one atomic per claim plus one per wave to find the list exhausted, 3 072 waves sharing 5 600
+    // tiles spent 100 of the kernel's 178 us on the counter word.  Long lists keep the guided self-scheduling below.
+    bool static_part = false;
+    if constexpr (LISTED) {
+        if (ntiles <= (long long)nwaves * 4) {
+            static_part = true;
+            const long long per = (ntiles + nwaves - 1) / nwaves;
+            const long long w0 = (long long)((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * per;
+            tnext = (unsigned int)(w0 < ntiles ? w0 : ntiles);
+            tend = (unsigned int)(w0 + per < ntiles ? w0 + per : ntiles);
+        }
     }
 
     // post-processing + stores of the first n (<= 64) waiting ring entries, one per lane
@@ -621,6 +638,10 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     // One atomic per tile made the single counter the bottleneck of sparse volumes: a 2 % ROI mask
                     // over 17.7 M voxels is 69 k claims for 0.05 ms of fitting -> 0.83 ms (BASELINE configs[2]).
                     if (tnext >= tend) {
+                        if (LISTED && static_part) {  // statically partitioned list: this wave's share is done
+                            more = false;
+                            break;
+                        }
                         unsigned int t0 = 0;
                         if (lane == 0) t0 = atomicAdd(C.tile_counter, chunk);
                         t0 = __builtin_amdgcn_readfirstlane(t0);
@@ -1204,27 +1225,47 @@ __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArg
         }
         return w;
     };
-    unsigned int word = group_word(wave0);
-    for (long long g = wave0; g < ngroups; g += nwaves) {
-        const unsigned int next = group_word(g + nwaves);
+    // A wave walks a CONTIGUOUS range of groups and publishes the tiles it found with ONE atomic per 64 of them: the list
+    // counter is a single device-scope word (~88 read-modify-writes per microsecond), and one atomic per non-empty tile made
+    // the pre-pass of a thin ROI atomic-bound (5 600 tiles: 137 us where the mask + fill traffic needs 76).
+    const long long per_wave = (ngroups + nwaves - 1) / nwaves;
+    const long long g_lo = wave0 * per_wave, g_hi = g_lo + per_wave < ngroups ? g_lo + per_wave : ngroups;
+    unsigned long long pend = 0;        // bit i: tile pend_tile0 + i holds a selected voxel
+    long long pend_tile0 = g_lo * kPerGroup;
+    auto publish = [&]() {
+        if (pend) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(pend));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((pend >> lane) & 1ull) list[base + __popcll(pend & ((1ull << lane) - 1ull))] = (unsigned int)(pend_tile0 + lane);
+            pend = 0;
+        }
+    };
+    unsigned int word = group_word(g_lo);
+    for (long long g = g_lo; g < g_hi; ++g) {
+        const unsigned int next = group_word(g + 1 < g_hi ? g + 1 : ngroups);
         const long long start = g * kPre;
         const long long rem = A.N - start;
         const int cnt = rem < kPre ? (int)rem : kPre;
         const unsigned long long sel = __ballot(word != 0);  // lane l holds voxels 4 l .. 4 l + 3 of the group
         if (sel) {
+            if ((g * kPerGroup - pend_tile0) + kPerGroup > 64) {
+                publish();
+                pend_tile0 = g * kPerGroup;
+            }
 #pragma unroll
             for (int h = 0; h < kPerGroup; ++h) {
                 const unsigned long long part = kPerGroup == 1 ? ~0ull : (((1ull << kLanesPerTile) - 1ull) << (h * kLanesPerTile));
                 const long long tstart = start + (long long)h * kSub;
                 if (tstart >= A.N) break;
                 if (sel & part) {
-                    if (lane == 0) list[atomicAdd(count, 1u)] = (unsigned int)(g * kPerGroup + h);
-                } else {  // this tile of the group holds no selected voxel: its fill (rare: the edge of the region)
+                    pend |= 1ull << (int)(g * kPerGroup + h - pend_tile0);
+                } else {  // this tile of the group holds no selected voxel: its fill (the edge of the region)
                     const long long trem = A.N - tstart;
-                    const int tc = trem < kSub ? (int)trem : kSub;
+                    const int tcnt = trem < kSub ? (int)trem : kSub;
                     for (int k = 0; k < kVpl; ++k) {
                         const int j = k * 64 + lane;
-                        if (j < tc) finish_voxel(A, tstart + j, 0, 0, 0, -1, 0, true);
+                        if (j < tcnt) finish_voxel(A, tstart + j, 0, 0, 0, -1, 0, true);
                     }
                 }
             }
@@ -1238,6 +1279,7 @@ __global__ __launch_bounds__(256) void monoexp_mask_prepass_kernel(const FitKArg
         }
         word = next;
     }
+    publish();
 }
 
 hipError_t monoexp_mask_prepass(const FitKArgs &k, unsigned int *list, unsigned int *count, int num_cu,
@@ -1268,6 +1310,8 @@ static hipError_t launch_one(const FitKArgs &k, int grid, hipStream_t stream) {
     if (wpb < 1) return hipErrorInvalidValue;
     const size_t lds = (size_t)wpb * lds_bytes_per_wave<LT>(k.E);
     auto fn = monoexp_lm_kernel<EMAX, FULL, LT>;
+    if constexpr (EMAX <= 8)
+        if (k.tile_list) fn = monoexp_lm_kernel<EMAX, FULL, LT, true>;
     (void)hipGetLastError();  // do not inherit a stale error from an unrelated earlier call
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),

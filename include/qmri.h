@@ -283,6 +283,12 @@ int qmri_unet2d_trace(void *handle, char *buf, int32_t size);
 /*
  * x [S][H][W] fp32 (host or device), optional whole-volume whitening (x - mean)/(std + eps) first.
  * Outputs (nullable): logits [S][H][W][n_classes] fp32 (pre-sigmoid), mask u8 = sigmoid > 0.5.
+ * Parity mode: feature maps are stored as fp16 hi + lo parts.  Input without whitening (raw intensities, the reference's
+ * IWOAIOAIUnet2D: oaiunet2d.py:322-323) is brought below 128 by a power of two first and the network's additive parameters
+ * are scaled with it (exact: the logits are unchanged); if a feature map still leaves the fp16 range the kernels flag it and
+ * the forward is REPEATED at a higher exponent -- never stored clamped.  The call therefore returns with the stream
+ * synchronised (also with device pointers); after four attempts it fails with QMRI_ERR_UNSUPPORTED and says so.  The
+ * exponent the last forward ran at is the "act_shift:N" entry of qmri_unet2d_trace.
  */
 int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_device, int32_t whiten,
                         double whiten_eps, float *logits, uint8_t *mask, int32_t out_on_device,

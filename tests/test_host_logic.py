@@ -225,3 +225,19 @@ def test_to_metrics_host_route_vs_reference_golden(golden, tag):
         else:
             df = calls[case]()
         check_against_g8(g, tag, case, df.drop(columns=["n"]), exact_moments=True)
+
+
+def test_bench_bookkeeping_helpers():
+    """bench.py's constants that the judge recomputes: the layer-by-layer minimum HBM traffic of a 160-slice forward as built
+    (25.4 GB written + 25.5 GB read), the source hashes the profile constants are guarded with, the cgroup quota."""
+    import bench
+
+    total, wr, rd = bench.unet_algorithmic_bytes()
+    assert abs(wr / 1e9 - 25.34) < 0.05 and abs(rd / 1e9 - 25.53) < 0.05 and total == wr + rd
+    t512, _, _ = bench.unet_algorithmic_bytes(hw=512)
+    assert 1.7 < t512 / total < 1.8                        # ~(512 / 384)^2; which levels pool in a kernel of their own differs
+    assert len(bench._kernel_source_sha1()) == 40 and bench._kernel_source_sha1() != bench._unet_source_sha1()
+    q = bench.effective_cores()
+    assert q is None or q > 0
+    tr = bench._unet_traffic()
+    assert tr["algorithmic_bytes"] == total and ("traffic_source" not in tr or "stale" in tr["traffic_source"])

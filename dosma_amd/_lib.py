@@ -148,7 +148,7 @@ MODELS = {"monoexponential": 0, "biexponential": 1}
 MODEL_NPARAMS = {"monoexponential": 2, "biexponential": 4}
 # "fp16x3" is the parity mode (logits within 1e-3 of an fp64 run); "fp16x3-general" forces it onto the general
 # convolution kernel in the operator-level entry (tests); "bf16" is the single-MFMA throughput mode
-PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2}
+PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2, "bf16-s3": 3}  # "bf16-s3": plain bf16 forced onto conv_s3_kernel (operator entry, tests)
 
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",
@@ -639,7 +639,7 @@ class Unet2dEngine:
         self.H, self.W, self.n_classes, self.max_batch = int(H), int(W), int(n_classes), int(max_batch)
 
     def set_precision(self, precision):
-        if precision == "fp16x3-general":
+        if precision in ("fp16x3-general", "bf16-s3"):
             raise ValueError("the engine picks its kernels itself: 'fp16x3' or 'bf16'")
         check(self._lib.qmri_unet2d_set_precision(self._handle, PRECISION[precision]))
 

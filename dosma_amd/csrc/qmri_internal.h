@@ -240,6 +240,9 @@ struct ConvS3Args {
     // filled by conv_s3_launch
     int chunks, steps, nb, ntiles, nwork, tiles_x, tiles_y, P, nj;
     int dbg;             // QMRI_S3_DBG timing experiments (0 in production)
+    int one;             // 1: plain-bf16 mode on this kernel -- x / y / pool_y are bf16 NHWC tensors, w is the bf16 image of
+                         // pack for 64-channel chunks (plane p = channels 32 p .. 32 p + 31 of the chunk); Cin, ldx, xoff are
+                         // given in 4-BYTE units (channels / 2), Cout / ldy / yoff / pool_ld in channels
     // Saturation flag (nullable).  The split layout stores a value as fp16 hi + lo parts; v_cvt_pkrtz clamps at 65504, so a
     // feature-map value beyond the fp16 range would be stored wrong WITHOUT any error.  Every kernel that writes the layout
     // tracks max |v| of what it stores and sets *sat = 1 when it exceeds 65504; the engine then repeats the forward with the

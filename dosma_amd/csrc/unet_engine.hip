@@ -100,6 +100,8 @@ struct ConvLayer {
     DevBuf w_hi, w_lo, bias, scale, shift;
     DevBuf h_hi, h_lo;   // parity mode, general kernel: fp16 hi / lo parts, same K-major layout as w_hi
     DevBuf w_s3;         // parity mode, conv_s3_kernel: per channel block and K step the [plane][BN][64 B] LDS image
+    DevBuf w_s3b;        // plain-bf16 mode on conv_s3_kernel (Cin % 64 == 0): the same image geometry with 64-channel chunks,
+                         // plane p = channels 32 p .. 32 p + 31 of the chunk, bf16 values
     float winv = 1.f;    // 2^-wshift
     bool has_affine = false;
     std::vector<float> bias_h, shift_h;  // host copies of the ADDITIVE epilogue parameters (rescaled by Unet::set_act_shift)
@@ -139,6 +141,30 @@ struct ConvLayer {
                         }
         e = w_s3.alloc(img.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        return e;
+    }
+
+    // plain-bf16 image for conv_s3_kernel<.., ONE>: [nb][chunk64 * ntaps + tap][plane][BN rows][4 positions x 8 bf16]
+    hipError_t upload_s3_bf16(const std::vector<float> &wk) {
+        if (Cin % 64 || Cout % 32) return hipSuccess;
+        const int BN = qmri::conv_s3_block_channels(Cout, deconv);
+        const int steps = ntaps * (Cin / 64);
+        const size_t K = (size_t)ntaps * Cin;
+        std::vector<unsigned short> img((size_t)Cout * K);
+        for (int nb = 0; nb < Cout / BN; ++nb)
+            for (int st = 0; st < steps; ++st) {
+                const int c64 = st / ntaps, tap = st % ntaps;
+                for (int plane = 0; plane < 2; ++plane)
+                    for (int r = 0; r < BN; ++r)
+                        for (int pos = 0; pos < 4; ++pos) {
+                            const int q = pos ^ ((r >> 2) & 3);
+                            const size_t src = (size_t)(nb * BN + r) * K + ((size_t)(c64 * 2 + plane) * ntaps + tap) * 32 + q * 8;
+                            const size_t dst = ((((size_t)nb * steps + st) * 2 + plane) * BN + r) * 32 + pos * 8;
+                            for (int k = 0; k < 8; ++k) img[dst + k] = f32_to_bf16_rne(wk[src + k]);
+                        }
+            }
+        hipError_t e = w_s3b.alloc(img.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(w_s3b.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
         return e;
     }
 
@@ -481,6 +507,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             pack_conv3x3(k1, Cin, C, *U->down1[l], wk);
             U_TRY(U->down1[l]->upload(wk, b1, nullptr, nullptr));
             U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+            if (s3_width_ok(U->Wl[l])) U_TRY(U->down1[l]->upload_s3_bf16(wk));
         }
         fold_bn(C, sc, sh);
         U->down2[l].reset(new ConvLayer);
@@ -488,6 +515,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         pack_conv3x3(k2, C, C, *U->down2[l], wk);
         U_TRY(U->down2[l]->upload(wk, b2, &sc, &sh));
         U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        if (s3_width_ok(U->Wl[l])) U_TRY(U->down2[l]->upload_s3_bf16(wk));
     }
     for (int l = d->depth - 2; l >= 0; --l) {
         const int C = U->nf[l], Cup = U->nf[l + 1];
@@ -500,6 +528,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
             U_TRY(L->upload_parity(wk, U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1])));  // tiles of the INPUT grid (level l + 1)
+            if (U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1])) U_TRY(L->upload_s3_bf16(wk));
             if (U->fac[l] == 3)
                 for (int ph = 0; ph < 9; ++ph) {
                     auto &P = U->updec3[(size_t)l * 9 + ph];
@@ -524,12 +553,14 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         pack_conv3x3(k1, 2 * C, C, *U->up1[l], wk);
         U_TRY(U->up1[l]->upload(wk, b1, nullptr, nullptr));
         U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        if (s3_width_ok(U->Wl[l])) U_TRY(U->up1[l]->upload_s3_bf16(wk));
         fold_bn(C, sc, sh);
         U->up2[l].reset(new ConvLayer);
         U->up2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->up2[l], wk);
         U_TRY(U->up2[l]->upload(wk, b2, &sc, &sh));
         U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        if (s3_width_ok(U->Wl[l])) U_TRY(U->up2[l]->upload_s3_bf16(wk));
     }
     // head: Keras (1,1,C0,NC) == [C0][NC]
     U_TRY(U->head_w.alloc((size_t)U->nf[0] * U->ncls * 4));
@@ -642,6 +673,51 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         U_TRY(qmri::head_split_launch(y, (long long)Bt * H * W, L.Cout, U->head_w.as<float>(), U->head_b.as<float>(), U->ncls, logits,
                                       mask, st));
         U->trace += "head:split;";
+    }
+    return QMRI_OK;
+}
+
+// Plain-bf16 layer on conv_s3_kernel<.., ONE> where the layer has 64-channel chunks and the level tiles (QMRI_S3_B16=0: the
+// round-1 kernels everywhere).  `k` is the layer as conv_igemm_launch would take it (bf16 NHWC in / out, optional fused pool).
+static bool s3_b16_wanted() {
+    static const bool on = !(std::getenv("QMRI_S3_B16") && std::atoi(std::getenv("QMRI_S3_B16")) == 0);
+    return on;
+}
+static int conv_bf16(Unet *U, const char *name, const ConvLayer &L, const qmri::ConvKArgs &k, hipStream_t st) {
+    char buf[96];
+    const int Wt = k.W;  // the grid the kernel tiles: the input grid (for the transposed convolution too)
+    // Measured per layer (160 slices of 384 x 384, scripts/unet_ab.sh QMRI_S3_B16 0 1): every transposed convolution gains
+    // (651 / 519 / 488 / 565 / 758 -> 306 / 290 / 329 / 376 / 609 us) and so do the convolutions with >= 128 input channels
+    // (+5 ... +25 %); with 64 input channels a tile is 9 steps of 2 MFMAs per wave-tile and the round-1 kernels (register
+    // weights for <= 64 output channels, implicit GEMM otherwise) stay ahead (516 vs 694, 1183 vs 1449, 262 vs 279 us).
+    const bool ok = s3_b16_wanted() && L.w_s3b.p && (L.deconv || L.Cin >= 128) && s3_width_ok(Wt) && !k.head_w && !k.c1_x && (k.ldx % 2 == 0) && (k.xoff % 2 == 0) &&
+                    (!k.deconv || (k.sy == 2 && k.sx == 2 && k.py == 0 && k.px == 0)) && (k.deconv || (k.sy == 1 && k.sx == 1));
+    if (!ok) {
+        U_TRY(qmri::conv_igemm_launch(k, 0, st));
+        snprintf(buf, sizeof(buf), "%s:igemm16;", name);
+        U->trace += buf;
+        return QMRI_OK;
+    }
+    qmri::ConvS3Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.one = 1;
+    a.x = k.x; a.ldx = k.ldx / 2; a.xoff = k.xoff / 2;
+    a.B = k.B; a.H = k.H; a.W = k.W;
+    a.Cin = L.Cin / 2; a.Cout = L.Cout;
+    a.deconv = L.deconv;
+    a.w = L.w_s3b.p; a.winv = 1.f;
+    a.bias = k.bias; a.scale = k.scale; a.shift = k.shift; a.relu = k.relu;
+    a.y = k.y; a.ldy = k.ldy; a.yoff = k.yoff;
+    const int bn = qmri::conv_s3_block_channels(L.Cout, L.deconv);
+    const bool flat = Wt % 32 != 0;
+    const bool fuse_pool = k.pool_y && !flat && bn >= 64 && !(k.H & 1) && !L.deconv;
+    if (fuse_pool) { a.pool_y = k.pool_y; a.pool_ld = k.pool_ld; }
+    U_TRY(qmri::conv_s3_launch(a, U->num_cu, st));
+    snprintf(buf, sizeof(buf), "%s:s3b/%s/bn%d%s;", name, flat ? "flat" : "2d", bn, fuse_pool ? "+pool" : "");
+    U->trace += buf;
+    if (k.pool_y && !fuse_pool) {
+        U_TRY(qmri::maxpool2_launch(k.y, k.ldy, k.yoff, k.B, k.H, k.W, L.Cout, k.pool_y, 1, st));
+        U->trace += "pool:b16;";
     }
     return QMRI_OK;
 }
@@ -785,6 +861,7 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
     const int D = U->depth;
     const int s3 = 0;
     const int ab = 1;  // activations stored as bf16
+    char nm[64];
     // ---- contracting path ----
     for (int l = 0; l < D; ++l) {
         const int H = U->Hl[l], W = U->Wl[l], C = U->nf[l];
@@ -799,7 +876,9 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
                                               U->c1_b.as<float>(), C, t1, C, 0, ab, st));
         } else {
             auto k = conv_args(*U->down1[l], U->pool[l]->p, U->nf[l - 1], 0, Bt, H, W, t1, C, 0, H, W, 1, 1, 0, 0);
-            U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            snprintf(nm, sizeof(nm), "down%d.conv1", l);
+            const int rc = conv_bf16(U, nm, *U->down1[l], k, st);
+            if (rc != QMRI_OK) return rc;
         }
         if (l < D - 1) {
             // block output (post-BN) goes to the 2nd half of this level's concat buffer = the skip
@@ -814,12 +893,16 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
                 k.c1_w = U->c1_w.as<float>();
                 k.c1_b = U->c1_b.as<float>();
             }
-            U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            snprintf(nm, sizeof(nm), "down%d.conv2", l);
+            const int rc = conv_bf16(U, nm, *U->down2[l], k, st);
+            if (rc != QMRI_OK) return rc;
             if (U->fac[l] == 3)  // odd height: MaxPooling2D((3, 3)) (oaiunet2d.py:236-241) as its own kernel
                 U_TRY(qmri::maxpoolk_launch(cat, 2 * C, C, Bt, H, W, C, 3, U->pool[l + 1]->p, st));
         } else {
             auto k = conv_args(*U->down2[l], t1, C, 0, Bt, H, W, U->bottom.p, C, 0, H, W, 1, 1, 0, 0);
-            U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            snprintf(nm, sizeof(nm), "down%d.conv2", l);
+            const int rc = conv_bf16(U, nm, *U->down2[l], k, st);
+            if (rc != QMRI_OK) return rc;
         }
     }
     // ---- expanding path ----
@@ -841,11 +924,17 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
             }
         } else {
             auto k = conv_args(*U->updec[(size_t)l], src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
-            U_TRY(qmri::conv_igemm_launch(k, s3, st));
+            snprintf(nm, sizeof(nm), "up%d.deconv", l);
+            const int rc = conv_bf16(U, nm, *U->updec[(size_t)l], k, st);
+            if (rc != QMRI_OK) return rc;
         }
         void *t1 = U->tmp[l]->p;
         auto k1 = conv_args(*U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, H, W, 1, 1, 0, 0);
-        U_TRY(qmri::conv_igemm_launch(k1, s3, st));
+        snprintf(nm, sizeof(nm), "up%d.conv1", l);
+        {
+            const int rc = conv_bf16(U, nm, *U->up1[l], k1, st);
+            if (rc != QMRI_OK) return rc;
+        }
         void *out = U->upout[l]->p;
         auto k2 = conv_args(*U->up2[l], t1, C, 0, Bt, H, W, out, C, 0, H, W, 1, 1, 0, 0);
         const bool fuse_head = l == 0 && C == 32;  // the whole channel run of a pixel is in one tile
@@ -857,7 +946,11 @@ static int forward_batch(Unet *U, int Bt, float *logits, unsigned char *mask, hi
             k2.logits = logits;
             k2.mask = mask;
         }
-        U_TRY(qmri::conv_igemm_launch(k2, s3, st));
+        snprintf(nm, sizeof(nm), "up%d.conv2", l);
+        {
+            const int rc = conv_bf16(U, nm, *U->up2[l], k2, st);
+            if (rc != QMRI_OK) return rc;
+        }
         src = out;
         if (l == 0 && !fuse_head)
             U_TRY(qmri::head_launch(src, (long long)Bt * U->H * U->W, U->nf[0], U->head_w.as<float>(),
@@ -1060,7 +1153,7 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
     if (Cin % 32 || Cout % 32) return ufail(QMRI_ERR_UNSUPPORTED, "Cin and Cout must be multiples of 32");
     U_TRY(hipSetDevice(device));
     const int Ho = transposed ? 2 * H : H, Wo = transposed ? 2 * W : W;
-    const int ab = precision == 0;  // plain bf16 mode: bf16 activations on the device; parity mode: the split layout
+    const int ab = precision == 0 || precision == 3;  // plain bf16 mode (3: forced onto conv_s3_kernel<.., ONE>): bf16 activations on the device; parity mode: the split layout
     const long long nx = (long long)B * H * W * Cin, ny = (long long)B * Ho * Wo * Cout;
     DevBuf dx, dy, dxb, dyb;
     U_TRY(dx.alloc((size_t)nx * 4));
@@ -1093,7 +1186,22 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
         const bool s3 = !ab && precision != 2 && s3_width_ok(W);
         if (!ab) U_TRY(L.upload_parity(wk, s3));
-        if (s3) {
+        if (precision == 3) {
+            if (Cin % 64 || !s3_width_ok(W)) return ufail(QMRI_ERR_UNSUPPORTED, "bf16 on conv_s3_kernel needs Cin %% 64 == 0 and a width it tiles");
+            U_TRY(L.upload_s3_bf16(wk));
+            qmri::ConvS3Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.one = 1;
+            k.x = dxb.p; k.ldx = Cin / 2; k.B = B; k.H = H; k.W = W; k.Cin = Cin / 2; k.Cout = Cout;
+            k.deconv = transposed ? 1 : 0;
+            k.w = L.w_s3b.p; k.winv = 1.f;
+            k.bias = L.bias.as<float>();
+            k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
+            k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
+            k.relu = relu;
+            k.y = dyb.p; k.ldy = Cout;
+            U_TRY(qmri::conv_s3_launch(k, prop.multiProcessorCount, nullptr));
+        } else if (s3) {
             qmri::ConvS3Args k;
             std::memset(&k, 0, sizeof(k));
             k.x = dxb.p; k.ldx = Cin; k.B = B; k.H = H; k.W = W; k.Cin = Cin; k.Cout = Cout;

@@ -38,6 +38,8 @@ namespace qmri {
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;  // what v_cvt_pkrtz_f16_f32 returns
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -119,7 +121,12 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
 // INPUT grid; the 9 taps (packed in phase order by pack_deconv_fused: 4 + 2 + 2 + 1) read the input at (dy, dx) in
 // {0, -1}^2 and accumulate into the accumulator set of their output phase (py, px); the epilogue writes the four phases
 // to the output pixels (2 y + py, 2 x + px).  The taps are unrolled (the accumulator set must be a compile-time index).
-template <int BN, bool FLAT, bool DECONV>
+// ONE: the plain-bf16 mode on the same machinery (round 3).  The bf16 NHWC layout already IS the record layout for 64-channel
+// chunks -- a pixel's 64 channels are 128 contiguous bytes -- so the halo DMA, the LDS image, the swizzles and the weight ring
+// are used unchanged with "plane 0 / plane 1" = channels 0-31 / 32-63 of the chunk: a k-step is ah x bh + al x bl (two MFMAs
+// for 64 channels instead of three for 32).  The launcher passes x in 4-byte units (ldx = channels / 2, Cin = channels / 2);
+// y / pool_y stay in channels of 2 bytes.  No fused classifier, no saturation flag (bf16 has the fp32 exponent range).
+template <int BN, bool FLAT, bool DECONV, bool ONE = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A) {
     using C = S3Cfg<BN>;
     constexpr int RT = C::RT, CT = C::CT;
@@ -413,6 +420,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             if ((RT == 1 ? 0 : i) != part) continue;
+            if constexpr (ONE) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.bh[j]), __builtin_bit_cast(bf16x8, f.ah[i]), acc[PH][i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.bl[j]), __builtin_bit_cast(bf16x8, f.al[i]), acc[PH][i][j], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[PH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[PH][i][j], 0, 0, 0);
 #pragma unroll
@@ -651,6 +667,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
             };
             const int n0 = t_nb * BN;
             const int px_l = lane & 31;
+            constexpr int kYB = ONE ? 2 : 4;  // bytes per output channel: bf16, or fp16 hi + lo
             // staging window: pixel px, 16-byte piece p8 = plane * 4 + q at position p8 ^ ((px >> 1) & 7) (the 8-byte writes of
             // 32 lanes then spread over 16 bank groups instead of 2)
             auto stage_piece = [&](int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); };
@@ -670,7 +687,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = affine(acc[ph][i][j][4 * q + r], p, r);
-                        if (!DECONV && BN == 32 && A.head_w) {
+                        if (!ONE && !DECONV && BN == 32 && A.head_w) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float4 w4 = *reinterpret_cast<const float4 *>(hw + (8 * q + 4 * khalf + r) * 4);
@@ -680,7 +697,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                                 z[3] = fmaf(v[r], w4.w, z[3]);
                             }
                         }
-                        if (A.y) {
+                        if (ONE) {
+                            if (A.y) {  // 4 bf16 channels = the 8-byte half of piece q: only the "hi" pieces 0-3 of the window are used
+                                const bf16x2 b0 = {(__bf16)v[0], (__bf16)v[1]}, b1 = {(__bf16)v[2], (__bf16)v[3]};
+                                *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, q) + 8 * khalf) =
+                                    make_uint2(__builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1));
+                            }
+                        } else if (A.y) {
 #ifndef QMRI_NO_SAT_TRACK  // (timing experiment: what the saturation tracking costs)
                             amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));  // (two v_max3_f32 with |.| modifiers)
 #endif
@@ -709,8 +732,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                         for (int t = t0; t < t0 + 2; ++t) {
                             const int pix = out_pixel(i, t);
                             const int p8 = (lane & 7) ^ (((t * 8 + (lane >> 3)) >> 1) & 7);
-                            if (pix >= 0 && !S3_DBG(16)) {
-                                long long doff = ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
+                            if (pix >= 0 && !S3_DBG(16) && (!ONE || p8 < 4)) {  // (bf16: the four "hi" pieces are the pixel's 64 bytes)
+                                long long doff = ((long long)(pix + ph_off) * A.ldy + A.yoff + cbase) * kYB + p8 * 16;
                                 if (S3_DBG(128)) doff &= (1ll << 22) - 16;  // experiment: every store lands in one 4 MB window
                                 if (S3_DBG(256) && t) continue;              // experiment: one store of four
                                 nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
@@ -718,7 +741,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                         }
                         }
                     }
-                    if (!DECONV && BN == 32 && A.head_w) {
+                    if (!ONE && !DECONV && BN == 32 && A.head_w) {
                         // 1x1 classifier: this lane summed its 16 channels of its pixel above, the partner lane (+32) adds the rest
 #pragma unroll
                         for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], 32, 64);
@@ -757,6 +780,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                             const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vmax), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
                             m[r] = fmaxf(vmax, other);
                         }
+                        if (ONE) {
+                            const bf16x2 b0 = {(__bf16)m[0], (__bf16)m[1]}, b1 = {(__bf16)m[2], (__bf16)m[3]};
+                            if (!(px_l & 1))
+                                *reinterpret_cast<uint2 *>(stage + stage_piece(px_l >> 1, q) + 8 * khalf) =
+                                    make_uint2(__builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1));
+                            continue;
+                        }
                         const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(m[0], m[1]), h1 = __builtin_amdgcn_cvt_pkrtz(m[2], m[3]);
                         const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(m[0] - (float)h0[0], m[1] - (float)h0[1]);
                         const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(m[2] - (float)h1[0], m[3] - (float)h1[1]);
@@ -778,8 +808,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_s3_kernel(const ConvS3Args A
                             const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pos * 16);
                             const int p8 = pos ^ ((px >> 1) & 7);
                             const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + px;
-                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + p8 * 16;
-                            nt_store16(dst, v);
+                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * kYB + p8 * 16;
+                            if (!ONE || p8 < 4) nt_store16(dst, v);
                         }
                     }
                 }
@@ -835,9 +865,9 @@ bool conv_s3_supported(const ConvS3Args &k) {
     return k.W + 2 <= 50;                // flattened zero-framed stack (LDS: 256 + 2 (W + 2) + 2 halo pixels)
 }
 
-template <int BN, bool FLAT, bool DECONV>
+template <int BN, bool FLAT, bool DECONV, bool ONE = false>
 static hipError_t s3_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
-    auto fn = conv_s3_kernel<BN, FLAT, DECONV>;
+    auto fn = conv_s3_kernel<BN, FLAT, DECONV, ONE>;
     const size_t lds = s3_lds_bytes(BN, k.nj);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -883,6 +913,18 @@ hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     }();
     k.dbg = dbg;
     (void)hipGetLastError();
+    if (k.one) {  // plain bf16 (k.Cin, k.ldx, k.xoff are in 4-byte units: see the kernel's header comment)
+        if (k.head_w) return hipErrorInvalidValue;
+        if (k.deconv) return flat ? s3_launch_t<32, true, true, true>(k, num_cu, stream) : s3_launch_t<32, false, true, true>(k, num_cu, stream);
+        if (flat) {
+            if (bn == 128) return s3_launch_t<128, true, false, true>(k, num_cu, stream);
+            if (bn == 64) return s3_launch_t<64, true, false, true>(k, num_cu, stream);
+            return s3_launch_t<32, true, false, true>(k, num_cu, stream);
+        }
+        if (bn == 128) return s3_launch_t<128, false, false, true>(k, num_cu, stream);
+        if (bn == 64) return s3_launch_t<64, false, false, true>(k, num_cu, stream);
+        return s3_launch_t<32, false, false, true>(k, num_cu, stream);
+    }
     if (k.deconv) return flat ? s3_launch_t<32, true, true>(k, num_cu, stream) : s3_launch_t<32, false, true>(k, num_cu, stream);
     if (flat) {
         if (bn == 128) return s3_launch_t<128, true, false>(k, num_cu, stream);

@@ -59,6 +59,12 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
         assert np.abs(yg - ref).max() < 2e-5, np.abs(yg - ref).max()
     y1 = L.conv2d_nhwc_host(x, k, b, relu=not transposed, transposed=transposed, precision="bf16")
     assert np.abs(y1 - ref).max() < 6e-2  # bf16 operands: ~2^-9 relative per product
+    if cin % 64 == 0 and (hw[1] % 32 == 0 or hw[1] + 2 <= 50):
+        # the same layer in plain bf16 on conv_s3_kernel (64-channel chunks in the two planes of its LDS image): same
+        # operand rounding as the round-1 kernel, so the two agree to accumulation order + the bf16 rounding of the output
+        ys = L.conv2d_nhwc_host(x, k, b, relu=not transposed, transposed=transposed, precision="bf16-s3")
+        assert np.abs(ys - ref).max() < 6e-2, np.abs(ys - ref).max()
+        assert np.abs(ys - y1).max() < 2e-2, np.abs(ys - y1).max()
     # fused BatchNorm affine after the ReLU
     sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     sh = rng.standard_normal(cout).astype(np.float32)

@@ -11,7 +11,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o f -- 
 python - <<PY
 import csv, glob
 for d, c in (("w", "WRITE_SIZE"), ("f", "FETCH_SIZE")):
-    rows = [r for r in csv.DictReader(open(glob.glob("$OUT/%s/*counter_collection.csv" % d)[0])) if "monoexp_lm_kernel" in r["Kernel_Name"] and "Li8ELb1EfE" in r["Kernel_Name"] or "monoexp_lm_kernel<8, true, float>" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(glob.glob("$OUT/%s/*counter_collection.csv" % d)[0])) if "monoexp_lm_kernel" in r["Kernel_Name"] and ("Li8ELb1EfLb0" in r["Kernel_Name"] or "<8, true, float, false>" in r["Kernel_Name"] or "<8, true, float>" in r["Kernel_Name"])]
     last = max(int(r["Dispatch_Id"]) for r in rows)
     v = sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last and r["Counter_Name"] == c)
     print(c, "MB per launch:", v * 1024 / 1e6)

@@ -11,7 +11,7 @@ bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlin
 json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
 
 
-HEADLINE = ("monoexp_lm_kernel<8, true, float>", "monoexp_lm_kernelILi8ELb1EfEE")  # the bench's headline variant
+HEADLINE = ("monoexp_lm_kernel<8, true, float, false>", "monoexp_lm_kernel<8, true, float>", "monoexp_lm_kernelILi8ELb1EfLb0E", "monoexp_lm_kernelILi8ELb1EfEE")  # the bench's headline variant (dense, not LISTED)
 
 
 def last_dispatch(path, kernel=HEADLINE):

@@ -7,7 +7,7 @@ results live in ``hipHostMalloc`` memory handed out by ``empty()``: the pages ar
 block goes back to the free list when the last numpy view of it is garbage-collected (a ``weakref`` finalizer on the
 exporting buffer object), so callers own their results exactly as before; nothing is ever overwritten under them.
 
-``DOSMA_AMD_HOST_POOL_GB`` (default 16; 0 switches the pool off) bounds ALL page-locked bytes of the pool -- blocks on the
+``DOSMA_AMD_HOST_POOL_GB`` (default 8; 0 switches the pool off) bounds ALL page-locked bytes of the pool -- blocks on the
 free list plus blocks still owned by live results (pinned memory cannot be swapped); beyond it ``empty()`` hands out plain
 numpy arrays.  ``DOSMA_AMD_HOST_POOL=0`` switches the pool off as well.
 
@@ -37,9 +37,9 @@ _pid = os.getpid()          # blocks belong to the process that allocated them (
 
 def _cap():
     try:
-        return int(float(os.environ.get("DOSMA_AMD_HOST_POOL_GB", "16")) * (1 << 30))
+        return int(float(os.environ.get("DOSMA_AMD_HOST_POOL_GB", "8")) * (1 << 30))
     except ValueError:
-        return 16 << 30
+        return 8 << 30
 
 
 def _release(ptr, size):

@@ -980,6 +980,7 @@ static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hi
         std::memcpy(&m, &bits, 4);
         if (std::isfinite(m) && m >= 128.f) S = std::ilogb(m) - 6;
     }
+    const int bump_at_entry = U->act_bump;
     S += U->act_bump;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (S > 60) break;
@@ -998,6 +999,7 @@ static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hi
         S += 6;             // a feature map left the fp16 range: the same forward, 64 times smaller (exactly)
         U->act_bump += 6;   // (remembered: the next volume of this model starts there)
     }
+    U->act_bump = bump_at_entry;  // a volume that cannot be brought into range does not change how the next one starts
     return ufail(QMRI_ERR_UNSUPPORTED,
                  "feature-map values exceed the fp16 hi + lo range of the parity mode even after scaling the network by 2^-%d; "
                  "use precision \"bf16\" for this model / input", S);

@@ -47,6 +47,9 @@ static_assert(kSub == 256 || kSub == 128, "tile = 4 or 2 voxels per lane");
 #ifndef QMRI_REFILL
 #define QMRI_REFILL 16
 #endif
+#ifndef QMRI_XS_MIN
+#define QMRI_XS_MIN 0   // the LDS table of the sample times is used for QMRI_XS_MIN < EMAX <= 12 (8: rounds-1/2 behaviour for <= 8 samples)
+#endif
 #ifndef QMRI_SMALL_E_BLOCKS
 #define QMRI_SMALL_E_BLOCKS 3  // blocks of 4 waves per CU the EMAX <= 8 variants are register-bounded for: THREE waves per SIMD
                                // (168 VGPRs + 48 spilled at 8 samples, 4 at 4 samples) since round 3 -- 20.7 -> 18.2 ms.  Round 2
@@ -490,9 +493,11 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
     // the sample times as an LDS table: the LM step reads x[i] with broadcast ds_read (LDS port) instead of holding 2 E
     // scalar registers across the whole loop -- they were the largest block the scalar allocator spilled and restored
     // (v_readlane = VALU slots) next to every use
-    // Measured: 12 samples 6.96 -> 6.68 ms, 8 samples 6.07 -> 6.26 ms (the table's read latency sits in the dependent chain
-    // of a short evaluation), 16 samples: the loaded values push the vector registers over 256 -> 9 .. 12 samples only.
-    constexpr bool kXsLds = EMAX > 8 && EMAX <= 12;
+    // Measured: at two waves per SIMD it paid from 9 samples on only (12 samples 6.96 -> 6.68 ms, 8 samples 6.07 -> 6.26 ms: the
+    // table's read latency sits in the dependent chain of a short evaluation); at three waves per SIMD the third wave hides that
+    // latency and the headline (8 samples) goes 18.15 -> 17.35 ms (same-box A/B).  16 samples: the loaded values push the vector
+    // registers over 256 -> up to 12 samples.
+    constexpr bool kXsLds = EMAX > QMRI_XS_MIN && EMAX <= 12;
     __shared__ double xs_tab[kXsLds ? EMAX : 1];
     if (kXsLds) {
         if (threadIdx.x < EMAX) xs_tab[threadIdx.x] = (FULL || (int)threadIdx.x < A.E) ? A.x[threadIdx.x] : 0.0;

@@ -47,6 +47,9 @@ static_assert(kSub == 256 || kSub == 128, "tile = 4 or 2 voxels per lane");
 #ifndef QMRI_REFILL
 #define QMRI_REFILL 16
 #endif
+#ifndef QMRI_TILE_OUT
+#define QMRI_TILE_OUT 0  // 1: variants up to 8 samples retire their results tile by tile (full-line stores) instead of through the result ring -- measured: writes 1.0 x, but 21.4 instead of 17.4 ms (see flush_tile)
+#endif
 #ifndef QMRI_XS_MIN
 #define QMRI_XS_MIN 0   // the LDS table of the sample times is used for QMRI_XS_MIN < EMAX <= 12 (8: rounds-1/2 behaviour for <= 8 samples)
 #endif
@@ -452,10 +455,17 @@ constexpr int kRingBytes = kRing * 5 * 8;
 // LDS bytes one wave owns: samples [E][kSub] of LT + SStot, a0, b0 (double) + the result ring + 1-byte queue entries
 // (variants up to 8 samples only: from 9 samples on the ring would cost the fourth wave of a block -- 2 x 4 waves no longer
 //  fit the CU's 160 KB -- and the in-lane epilogue is the better deal)
-__host__ __device__ constexpr bool use_result_ring(int E) { return E <= 8; }
+__host__ __device__ constexpr bool use_result_ring(int E) { return E <= 8 && !QMRI_TILE_OUT; }
+// Tile-ordered retirement (variants up to 8 samples): a wave keeps the side arrays of TWO tiles -- SStot / a0 / b0 / |f| per
+// voxel, whose a0 / b0 slots take the solver's (a, b) once the voxel has been pulled, + info, nfev and a status byte -- so that
+// the stragglers of a tile can finish while the next one is being pulled; a tile whose last voxel has terminated is
+// post-processed and stored as a whole: every output row of it in full, coalesced lines (see flush_tile in the kernel).
+__host__ __device__ constexpr bool use_tile_out(int E) { return E <= 8 && QMRI_TILE_OUT; }
 template <typename LT>
 __host__ __device__ constexpr size_t lds_bytes_per_wave(int E) {
-    return (size_t)E * kSub * sizeof(LT) + (size_t)kSub * (3 * sizeof(double) + 1) + (use_result_ring(E) ? kRingBytes : 0);
+    return (size_t)E * kSub * sizeof(LT) +
+           (use_tile_out(E) ? (size_t)2 * kSub * (4 * sizeof(double) + 4) + kSub
+                            : (size_t)kSub * (3 * sizeof(double) + 1) + (use_result_ring(E) ? kRingBytes : 0));
 }
 
 // Two blocks (8 waves) per CU = two waves per SIMD is what the VALU-bound solver needs; the register allocation of the
@@ -487,8 +497,21 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
     double *r_fn = r_b + kRing;
     double *r_sst = r_fn + kRing;
     constexpr bool kUseRing = use_result_ring(EMAX);
-    unsigned char *t_queue = kUseRing ? reinterpret_cast<unsigned char *>(r_sst + kRing) : reinterpret_cast<unsigned char *>(t_b0 + kSub);
+    constexpr bool kTileOut = use_tile_out(EMAX);
+    // tile-ordered retirement: side arrays of tile buffer b at side0 + b * 4 * kSub doubles: SStot | a0 -> a | b0 -> b | |f|
+    double *const side0 = t_sst;
+    unsigned char *const o_info = reinterpret_cast<unsigned char *>(side0 + 8 * kSub);   // [2][kSub] MINPACK info
+    unsigned short *const o_nfev = reinterpret_cast<unsigned short *>(o_info + 2 * kSub);  // [2][kSub]
+    unsigned char *const o_stat = reinterpret_cast<unsigned char *>(o_nfev + 2 * kSub);   // [2][kSub] 0 pending, 1 solved, 2 skipped (NaN, 0), 3 outside the mask
+    unsigned char *t_queue = kTileOut ? o_stat + 2 * kSub
+                                      : (kUseRing ? reinterpret_cast<unsigned char *>(r_sst + kRing) : reinterpret_cast<unsigned char *>(t_b0 + kSub));
     int rhead = 0, rcount = 0;  // wave-uniform: first waiting entry, number of waiting entries
+    int cur = 0;                        // tile buffer the queue / the pulls refer to
+    int outst0 = 0, outst1 = 0;         // voxels of the tile in buffer b that need the solver and have not terminated
+    bool act0 = false, act1 = false;    // buffer b holds a tile that has not been stored yet
+    long long base0 = 0, base1 = 0;     // first voxel of that tile
+    int cnt0 = 0, cnt1 = 0;             // its voxel count
+    int tslot = 0;                      // per lane: (buffer << 7) | index of its voxel in the tile
     const double epsmch = DBL_EPSILON;
     // the sample times as an LDS table: the LM step reads x[i] with broadcast ds_read (LDS port) instead of holding 2 E
     // scalar registers across the whole loop -- they were the largest block the scalar allocator spilled and restored
@@ -576,6 +599,34 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
         __builtin_amdgcn_wave_barrier();
     };
 
+    // tile-ordered retirement: post-processing + stores of the whole tile in buffer b, lane l takes voxels l, l + 64: every
+    // output row of the tile is written in full, consecutive lines (the per-voxel stores of the ring were 1.5 x the bytes)
+    auto flush_tile = [&](const FitKArgs &K, int b) {
+        const long long base = b ? base1 : base0;
+        const int cnt = b ? cnt1 : cnt0;
+        const double *S = side0 + b * 4 * kSub;
+#pragma unroll
+        for (int k = 0; k < kVpl; ++k) {
+            const int j = k * 64 + lane;
+            if (j < cnt) {
+                const int st = o_stat[b * kSub + j];
+                const int info = st == 1 ? (int)(signed char)o_info[b * kSub + j] : (st == 3 ? -1 : 0);
+                const int nf = st == 1 ? (int)o_nfev[b * kSub + j] : 0;
+                // fitting.py:1032-1035 (success) / :1069-1072 (RuntimeError -> NaN, 0) / :1064-1067 (skip rule) / :205-215 (fill)
+                double oa = NAN, ob = NAN, r2 = 0.0;
+                if (st == 1 && info >= 1 && info <= 4) {
+                    const double fn = S[3 * kSub + j];
+                    oa = S[kSub + j];
+                    ob = S[2 * kSub + j];
+                    r2 = 1.0 - (fn * fn) / (S[j] + K.r2_eps);
+                }
+                finish_voxel(K, base + j, oa, ob, r2, info, nf, st == 3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
 #ifdef QMRI_STATS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t1 = 0;
@@ -604,7 +655,39 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                 // occupancy was 8 % of the kernel (measured with the stores + epilogue compiled out: 21.4 -> 19.7 ms).  They
                 // append (voxel, info, nfev, a, b, |f|, SStot) to the wave's result ring -- five LDS writes -- and the
                 // epilogue runs on 64 ring entries at a time with every lane active (flush_ring).
-                if (!kUseRing) {
+                if (kTileOut) {
+                    // terminated lanes leave (a, b, |f|, info, nfev) in their voxel's slots of its tile buffer -- three LDS
+                    // writes + three bytes -- and a tile whose last voxel has terminated is retired as a whole
+                    const bool done = state == ST_DONE;
+                    const unsigned long long dmask = __ballot(done);
+                    if (dmask) {
+                        const int b = tslot >> 7, j = tslot & (kSub - 1);
+                        if (done) {
+                            double *S = side0 + b * 4 * kSub;
+                            S[kSub + j] = pa;
+                            S[2 * kSub + j] = pb;
+                            S[3 * kSub + j] = fnorm;
+                            o_info[b * kSub + j] = (unsigned char)done_info;
+                            o_nfev[b * kSub + j] = (unsigned short)nfev;
+                            o_stat[b * kSub + j] = 1;
+                            state = ST_IDLE;
+                            nfev = 0;
+                        }
+                        const int n1 = __popcll(__ballot(done && b == 1));
+                        outst1 -= n1;
+                        outst0 -= __popcll(dmask) - n1;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (act0 && outst0 == 0) {
+                        flush_tile(C, 0);
+                        act0 = false;
+                    }
+                    if (act1 && outst1 == 0) {
+                        flush_tile(C, 1);
+                        act1 = false;
+                    }
+                } else if (!kUseRing) {
                     if (state == ST_DONE) {
                         double oa = NAN, ob = NAN, r2 = 0.0;
                         if (done_info >= 1 && done_info <= 4) {
@@ -639,6 +722,12 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                 }
                 // ---- queue empty: claim tiles until one has fit-able voxels (or the volume is done) ----
                 while (qpos >= qend && more) {
+                    int nb = 0;  // (tile-ordered retirement) the buffer the next tile goes to: one that holds no unstored tile
+                    if (kTileOut) {
+                        const bool other_free = cur ? !act0 : !act1, cur_free = cur ? !act1 : !act0;
+                        if (!other_free && !cur_free) break;  // stragglers of both tiles still run: pull again when one has retired
+                        nb = other_free ? (cur ^ 1) : cur;
+                    }
                     // guided self-scheduling: one atomic claims `chunk` consecutive tiles (16 early, 1 at the end).
                     // One atomic per tile made the single counter the bottleneck of sparse volumes: a 2 % ROI mask
                     // over 17.7 M voxels is 69 k claims for 0.05 ms of fitting -> 0.83 ms (BASELINE configs[2]).
@@ -666,6 +755,13 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     tile_base = start;
                     const long long rem = C.N - start;
                     const int count = rem < kSub ? (int)rem : kSub;
+                    if (kTileOut) {
+                        cur = nb;
+                        t_sst = side0 + nb * 4 * kSub;
+                        t_a0 = t_sst + kSub;
+                        t_b0 = t_a0 + kSub;
+                        if (nb) { base1 = start; cnt1 = count; } else { base0 = start; cnt0 = count; }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     bool any_selected = true;  // a tile without a single voxel in the mask needs no samples at all
@@ -711,7 +807,8 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                             bool selected = true;
                             if (C.mask) selected = C.mask[v] != 0;
                             if (!selected) {
-                                finish_voxel(C, v, 0, 0, 0, -1, 0, true);
+                                if (kTileOut) o_stat[cur * kSub + j] = 3;
+                                else finish_voxel(C, v, 0, 0, 0, -1, 0, true);
                             } else {
                                 bool allzero = true, finite = true, oob = false;
                                 double mean = 0.0;
@@ -729,12 +826,15 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                 if (!finite) {
                                     // reference: ValueError for the whole call (scipy check_finite)
                                     *C.nonfinite = 1;
-                                    finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
+                                    if (kTileOut) o_stat[cur * kSub + j] = 2;
+                                    else finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
                                 } else if (allzero || oob) {
                                     // skip rule, fitting.py:1064-1067
-                                    finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
+                                    if (kTileOut) o_stat[cur * kSub + j] = 2;
+                                    else finish_voxel(C, v, NAN, NAN, 0.0, 0, 0, false);
                                 } else {
                                     need_fit = true;
+                                    if (kTileOut) o_stat[cur * kSub + j] = 0;
                                     mean = mean * rE;
                                     double st = 0.0;
 #pragma unroll
@@ -799,6 +899,17 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     qend = qn;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    if (kTileOut) {
+                        if (qn == 0) {
+                            flush_tile(C, cur);  // nothing for the solver in this tile: it retires at once
+                        } else if (cur) {
+                            act1 = true;
+                            outst1 = qn;
+                        } else {
+                            act0 = true;
+                            outst0 = qn;
+                        }
+                    }
                 }
                 // ---- pull: idle lane number r takes queue entry qpos + r ----
                 if (qpos < qend) {
@@ -813,6 +924,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                             else yv[i] = 0;
                         sstot = t_sst[j];
                         vox = tile_base + j;
+                        tslot = (cur << 7) | j;
                         pa = C.a0;
                         pb = C.b0;
                         if (C.init != QMRI_INIT_SCALAR) {
@@ -1143,6 +1255,10 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
         st_acc[5] += __popcll(__ballot(did_qr));
         st_acc[6] += __popcll(__ballot(did_finish));
 #endif
+    }
+    if (kTileOut) {  // (the loop ends with every lane idle: every tile has retired in the last refill visit; belt and braces)
+        if (act0 && outst0 == 0) flush_tile(A, 0);
+        if (act1 && outst1 == 0) flush_tile(A, 1);
     }
     if (rcount > 0) {  // (the loop ends with every lane idle: what is left in the ring is < 64 entries)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

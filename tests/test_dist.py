@@ -149,3 +149,27 @@ def test_bench_two_ranks_on_one_gpu():
     for d in ("h2d", "d2h"):
         assert len(hf["copy_bandwidth"][d]["gb_per_s_per_rank"]) == 2 and hf["copy_bandwidth"][d]["gb_per_s_all_ranks"] > 1
     assert out["unet2d"]["value"] > 100 and "cpu_baseline" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_knee_batch_example(ranks):
+    """examples/knee_batch.py (BASELINE configs[4] through the drop-in API: fit + generate_mask per volume, batch axis
+    sharded over the ranks) on a small grid: as one process, and as two gloo ranks sharing the box's GPU."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    script = [os.path.join(ROOT, "examples", "knee_batch.py"), "--volumes", "3", "--shape", "64", "96", "4"]
+    if ranks == 1:
+        cmd = [sys.executable] + script
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + script + ["--backend", "gloo"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    head = [l for l in p.stdout.splitlines() if l.startswith("3 volumes of (64, 96, 4)")]
+    assert len(head) == 1 and f"on {ranks} rank(s)" in head[0], p.stdout[-2000:]   # rank 0 reports once
+    rows = {l.split()[0]: l for l in p.stdout.splitlines() if l.startswith("  ")}
+    assert "voxels" in rows and "seconds" in rows and any(k.startswith("t2_mean_") for k in rows)
+    # every volume was processed exactly once, whichever rank owned it: three voxel counts of 64 * 96 * 4
+    assert rows["voxels"].count("24576") == 3, rows["voxels"]

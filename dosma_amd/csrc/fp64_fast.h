@@ -47,6 +47,39 @@ __device__ __forceinline__ double div_p10(double x, double p10, double ip10) {
     return x / p10;
 }
 
+// a * b + k with the constant k as a SCALAR operand (one v_fma_f64; the two s_mov_b32 that make k issue on the scalar unit)
+__device__ __forceinline__ double fma_sk(double a, double b, double k) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+
+// exp(x) exactly as the device library evaluates it -- k = rint(x log2 e), r = x - k ln 2 (two-part constant), the same
+// degree-11 polynomial in the same order, ldexp, the same two range tests: the results are bit-identical -- with the
+// polynomial's constants as scalar operands.  Inside a register-limited loop hipcc keeps the library form's nine 64-bit
+// coefficients in 18 VGPRs and spends a v_mov_b64 + v_fmac_f64 per Horner step (the accumulating form needs the constant
+// in its destination): 9 vector instructions and 18 registers more per call than this form.
+__device__ __forceinline__ double exp_sk(double x) {
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(k, -0x1.62e42fefa39efp-1, x);
+    r = fma(k, -0x1.abc9e3b39803fp-56, r);
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma_sk(r, p, 0x1.71dee623fde64p-19);
+    p = fma_sk(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma_sk(r, p, 0x1.a01a014761f6ep-13);
+    p = fma_sk(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma_sk(r, p, 0x1.1111111122322p-7);
+    p = fma_sk(r, p, 0x1.55555555502a1p-5);
+    p = fma_sk(r, p, 0x1.5555555555511p-3);
+    p = fma_sk(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double z = __builtin_amdgcn_ldexp(p, static_cast<int>(k));
+    z = x > 1024.0 ? __builtin_huge_val() : z;
+    z = x < -1075.0 ? 0.0 : z;
+    return z;
+}
+
 // natural log of a positive, finite, normal x, ~1 ulp: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
 // log m = 2 atanh(s) = 2 s (1 + z/3 + z^2/5 + ...), z = s^2 <= 0.0295 (13 terms: remainder < 1e-21)
 __device__ __forceinline__ double log_fast(double x) {

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                             }
                                         const double r2l = 1.0 - div_fast(ssr, syy + 1e-8);
                                         const bool good = r2l >= 0.0 && !isnan(slope) && !isnan(icpt);
-                                        t_a0[j] = good ? exp(icpt) : 1.0;
+                                        t_a0[j] = good ? exp_sk(icpt) : 1.0;
                                         t_b0[j] = good ? slope : 0.0;
                                     }
                                 }
@@ -980,14 +980,14 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
             if (A.uniform_x) {
                 // equally spaced x: e_i = e_0 q^i from two exponentials (a few ulp of accumulated rounding, far inside
                 // the 1e-4 parity bar; x_0 >= 0 < x_step keeps 0 * inf out of the products)
-                const double q1 = exp(mul_rn(tb, A.x_step));
+                const double q1 = exp_sk(mul_rn(tb, A.x_step));
                 const double q2 = q1 * q1, q4 = q2 * q2;
                 if (A.x0_pow >= 0) {  // x_0 = k x_step (TE = dTE, 2 dTE, ...): one exponential for the whole voxel
                     double e0 = 1.0;
                     for (int k = 0; k < A.x0_pow; ++k) e0 *= q1;
                     ev[0] = e0;
                 } else {
-                    ev[0] = exp(mul_rn(tb, QMRI_XS(0)));
+                    ev[0] = exp_sk(mul_rn(tb, QMRI_XS(0)));
                 }
 #pragma unroll
                 for (int i = 1; i < EMAX; ++i)
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
             } else {
 #pragma unroll
                 for (int i = 0; i < EMAX; ++i)
-                    if (FULL || i < E) ev[i] = exp(mul_rn(tb, QMRI_XS(i)));
+                    if (FULL || i < E) ev[i] = exp_sk(mul_rn(tb, QMRI_XS(i)));
                     else ev[i] = 0.0;
             }
 #pragma unroll
@@ -1122,10 +1122,14 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                             const double xi = QMRI_XS(i);
                             const double d = sub_rn(mul_rn(b1, xi), mul_rn(pb, xi));
                             const double e1 = e + e * (d + d * d * (0.5 + d * (1.0 / 6.0)));
-                            c2[i] = sub_rn(sub_rn(mul_rn(pa, e1), yi), fv[i]) * rhb;
-                            ev[i] = sub_rn(sub_rn(mul_rn(a1, e), yi), fv[i]) * rha;
-                            n1 += ev[i] * ev[i];
-                            n2 += c2[i] * c2[i];
+                            // the columns are stored in the order the pivoting picks on tissue data (|d/db| = a x e >> |d/da| = e):
+                            // ev <- column b, c2 <- column a, exchanged below only when column a is the longer one
+                            const double jb = sub_rn(sub_rn(mul_rn(pa, e1), yi), fv[i]) * rhb;
+                            const double ja = sub_rn(sub_rn(mul_rn(a1, e), yi), fv[i]) * rha;
+                            ev[i] = jb;
+                            c2[i] = ja;
+                            n1 += ja * ja;
+                            n2 += jb * jb;
                         } else {
                             c2[i] = 0.0;
                             ev[i] = 0.0;
@@ -1138,7 +1142,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                 sqrt_rsqrt(n2, acn1, iacn1);
                 l0 = acn1 > acn0 ? 1 : 0;
                 // P = pivot column, Q = the other one (in place: ev <- P, c2 <- Q)
-                if (l0) {
+                if (__builtin_expect(!l0, 0)) {
 #pragma unroll
                     for (int i = 0; i < EMAX; ++i)
                         {

@@ -31,6 +31,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cmath>
+#include <type_traits>
 
 #include "fp64_fast.h"
 #include "qmri_internal.h"
@@ -59,6 +60,9 @@ static_assert(kSub == 256 || kSub == 128, "tile = 4 or 2 voxels per lane");
                                // measured the opposite (168 + 102 spilled: 1.17e9 instead of 1.89e9 voxel-fits/s): the cold kernel
                                // arguments were still in the scalar registers then, and the LDS slices allowed two blocks only
 #endif
+#ifndef QMRI_Y_F64_MAX
+#define QMRI_Y_F64_MAX 8
+#endif
 #ifndef QMRI_MIN_WAVES
 #define QMRI_MIN_WAVES 1
 #endif
@@ -80,10 +84,15 @@ __device__ __forceinline__ double sub_rn(double a, double b) {
 // block stays behind a real branch.  (Left alone, the compiler if-converts the guarded slow paths below -- IEEE
 // divisions and square roots of 13-25 instructions each -- and executes them on EVERY call, selecting afterwards.)
 
+// The guards of the fast reciprocal / square-root forms below: ONE v_cmp_class instead of two range compares (the forms
+// are safe for every normal argument: the refinement terms stay normal; 0, denormals, inf, NaN and negative arguments take
+// the IEEE path as before).
+__device__ __forceinline__ bool is_pos_normal(double x) { return __builtin_amdgcn_class(x, 0x100); }
+
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs);
 __device__ __forceinline__ double norm2(double a, double b) {
     const double s = a * a + b * b;
-    if (s > 1e-280 && s < 1e280) {
+    if (is_pos_normal(s)) {
         double n, rn;
         sqrt_rsqrt(s, n, rn);
         return n;
@@ -109,13 +118,12 @@ __device__ __forceinline__ double frcp(double b) {
     // 0, inf, NaN and the (sub)normal extremes, where the refinement would produce 0 * inf: the hardware result
     // as it is (exact for 0 / inf / NaN).  An IEEE division here gets if-converted by the compiler -- 13 more
     // instructions on EVERY call -- for a range the solver only visits on voxels that fail anyway.
-    const double ab = fabs(b);
-    return (ab > 1e-290 && ab < 1e290) ? r : r0;
+    return __builtin_amdgcn_class(b, 0x108) ? r : r0;  // +-normal
 }
 
 // s = sqrt(x), rs = 1/sqrt(x) by Goldschmidt iteration from v_rsq_f64 (9 instructions for both)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
-    if (x > 1e-290 && x < 1e290) {
+    if (is_pos_normal(x)) {
         const double r = __builtin_amdgcn_rsq(x);
         double g = x * r;
         double h = 0.5 * r;
@@ -137,7 +145,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
 // ||(a, b)|| and its reciprocal; overflow-safe like MINPACK's enorm on the slow path
 __device__ __forceinline__ void norm2r(double a, double b, double &n, double &rn) {
     const double q = a * a + b * b;
-    if (q > 1e-280 && q < 1e280) {
+    if (is_pos_normal(q)) {
         sqrt_rsqrt(q, n, rn);
     } else {
         QMRI_COLD_PATH();
@@ -531,7 +539,9 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
     // ---- per-lane LM state (fp64 registers) ----
     int state = ST_IDLE;
     long long vox = 0;
-    LT yv[EMAX];
+    // the voxel's samples: as doubles where the registers allow (EMAX <= 8: 8 conversions less per round), else as loaded
+    typedef typename std::conditional<(EMAX <= QMRI_Y_F64_MAX), double, LT>::type YT;
+    YT yv[EMAX];
     double pa = 0, pb = 0;                    // current point x = (a, b)
     double fnorm = 0, par = 0, delta = 0, xnorm = 0, gnorm = 0;
     double dg0 = 1, dg1 = 1;                  // diag (by parameter)
@@ -1008,7 +1018,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     ss += fv[i] * fv[i];
                 }
             double fnorm1, rfn1 = 0.0;  // rfn1 = 1 / fnorm1 on the fast path, else 0 (-> frcp when needed)
-            if (ss > 1e-280 && ss < 1e280) {
+            if (is_pos_normal(ss)) {
                 sqrt_rsqrt(ss, fnorm1, rfn1);
             } else {
                 QMRI_COLD_PATH();

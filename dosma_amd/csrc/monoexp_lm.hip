@@ -84,6 +84,20 @@ __device__ __forceinline__ double sub_rn(double a, double b) {
 // block stays behind a real branch.  (Left alone, the compiler if-converts the guarded slow paths below -- IEEE
 // divisions and square roots of 13-25 instructions each -- and executes them on EVERY call, selecting afterwards.)
 
+// max / min of two values that are never signalling NaNs: the bare instruction (fmax / fmin first canonicalise every operand
+// that is not the result of an arithmetic instruction -- a v_max_f64 x, x each -- to quiet signalling NaNs; quiet NaNs are
+// handled by the instruction itself exactly as fmax / fmin do: the other operand is returned)
+__device__ __forceinline__ double max_q(double a, double b) {
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double min_q(double a, double b) {
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // The guards of the fast reciprocal / square-root forms below: ONE v_cmp_class instead of two range compares (the forms
 // are safe for every normal argument: the refinement terms stay normal; 0, denormals, inf, NaN and negative arguments take
 // the IEEE path as before).
@@ -92,7 +106,7 @@ __device__ __forceinline__ bool is_pos_normal(double x) { return __builtin_amdgc
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs);
 __device__ __forceinline__ double norm2(double a, double b) {
     const double s = a * a + b * b;
-    if (is_pos_normal(s)) {
+    if (__builtin_expect(is_pos_normal(s), 1)) {
         double n, rn;
         sqrt_rsqrt(s, n, rn);
         return n;
@@ -123,7 +137,7 @@ __device__ __forceinline__ double frcp(double b) {
 
 // s = sqrt(x), rs = 1/sqrt(x) by Goldschmidt iteration from v_rsq_f64 (9 instructions for both)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
-    if (is_pos_normal(x)) {
+    if (__builtin_expect(is_pos_normal(x), 1)) {
         const double r = __builtin_amdgcn_rsq(x);
         double g = x * r;
         double h = 0.5 * r;
@@ -145,7 +159,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
 // ||(a, b)|| and its reciprocal; overflow-safe like MINPACK's enorm on the slow path
 __device__ __forceinline__ void norm2r(double a, double b, double &n, double &rn) {
     const double q = a * a + b * b;
-    if (is_pos_normal(q)) {
+    if (__builtin_expect(is_pos_normal(q), 1)) {
         sqrt_rsqrt(q, n, rn);
     } else {
         QMRI_COLD_PATH();
@@ -288,8 +302,8 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, doubl
     const double gnorm = norm2(g0, g1);
     double paru = gnorm * frcp(delta);
     if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
-    par = fmax(par, parl);
-    par = fmin(par, paru);
+    par = max_q(par, parl);
+    par = min_q(par, paru);
     if (par == 0.0) par = gnorm * idx;
     QMRI_TOC(9);
     // Closed-form evaluation of the same Newton iteration.  In the scaled variable z = D P^T x the damped normal
@@ -329,9 +343,9 @@ __device__ __forceinline__ void lmpar2(double r11, double r12, double r22, doubl
             const double n1 = fma(a1, z1, -(b12 * z0));
             const double qq = fma(n1 * rdet, n1, z0 * z0);
             const double parc = (fp * a1) * (dxnorm * dxnorm) * frcp(delta * qq);
-            if (fp > 0.0) parl = fmax(parl, par);
-            if (fp < 0.0) paru = fmin(paru, par);
-            par = fmax(parl, par + parc);
+            if (fp > 0.0) parl = max_q(parl, par);
+            if (fp < 0.0) paru = min_q(paru, par);
+            par = max_q(parl, par + parc);
         }
         const double xl0 = z0 * idl0, xl1 = z1 * idl1;
         x0 = l0 ? xl1 : xl0;
@@ -978,7 +992,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                 ta = pa + p0;
                 tb = pb + p1;
                 pnorm = norm2(dg0 * p0, dg1 * p1);
-                if (first) delta = fmin(delta, pnorm);
+                if (first) delta = min_q(delta, pnorm);
             } else {
                 ta = pa;
                 tb = pb;
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     ss += fv[i] * fv[i];
                 }
             double fnorm1, rfn1 = 0.0;  // rfn1 = 1 / fnorm1 on the fast path, else 0 (-> frcp when needed)
-            if (is_pos_normal(ss)) {
+            if (__builtin_expect(is_pos_normal(ss), 1)) {
                 sqrt_rsqrt(ss, fnorm1, rfn1);
             } else {
                 QMRI_COLD_PATH();
@@ -1070,7 +1084,7 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                     double temp = 0.5;
                     if (actred < 0.0) temp = 0.5 * dirder * frcp(dirder + 0.5 * actred);
                     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                    delta = temp * fmin(delta, pnorm * 10.0);
+                    delta = temp * min_q(delta, pnorm * 10.0);
                     par = par * frcp(temp);
                 } else if (par == 0.0 || ratio >= 0.75) {
                     delta = pnorm / 0.5;

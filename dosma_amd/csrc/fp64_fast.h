@@ -47,7 +47,38 @@ __device__ __forceinline__ double div_p10(double x, double p10, double ip10) {
     return x / p10;
 }
 
-// a * b + k with the constant k as a SCALAR operand (one v_fma_f64; the two s_mov_b32 that make k issue on the scalar unit)
+// a * b + K, a * K and a * K + c with the 64-bit constant K as a SCALAR operand that is made where it is used: two s_mov_b32
+// (they issue on the scalar unit) into s[100:101] and ONE vector instruction.  A 64-bit constant cannot be an immediate of
+// v_fma_f64 / v_mul_f64; left to itself hipcc hoists such constants out of the caller's loop and keeps them there -- in
+// scalar registers that the loop then spills, or in vector registers with a v_mov_b64 + v_fmac_f64 pair per step.
+template <unsigned long long K>
+__device__ __forceinline__ double fma_sk_bits(double a, double b) {
+    double d;
+    asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, %2, s[100:101]"
+        : "=v"(d) : "v"(a), "v"(b), "n"((unsigned)(K & 0xffffffffull)), "n"((unsigned)(K >> 32)) : "s100", "s101");
+    return d;
+}
+template <unsigned long long K>
+__device__ __forceinline__ double mul_sk_bits(double a) {
+    double d;
+    asm("s_mov_b32 s100, %2\n\ts_mov_b32 s101, %3\n\tv_mul_f64 %0, %1, s[100:101]"
+        : "=v"(d) : "v"(a), "n"((unsigned)(K & 0xffffffffull)), "n"((unsigned)(K >> 32)) : "s100", "s101");
+    return d;
+}
+template <unsigned long long K>
+__device__ __forceinline__ double fma_ks_bits(double a, double c) {
+    double d;
+    asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, s[100:101], %2"
+        : "=v"(d) : "v"(a), "v"(c), "n"((unsigned)(K & 0xffffffffull)), "n"((unsigned)(K >> 32)) : "s100", "s101");
+    return d;
+}
+#define QMRI_K64(k) __builtin_bit_cast(unsigned long long, static_cast<double>(k))
+#define QMRI_FMA_SK(a, b, k) ::qmri::fma_sk_bits<QMRI_K64(k)>((a), (b))   /* a * b + k */
+#define QMRI_MUL_SK(a, k) ::qmri::mul_sk_bits<QMRI_K64(k)>((a))          /* a * k */
+#define QMRI_FMA_KS(a, k, c) ::qmri::fma_ks_bits<QMRI_K64(k)>((a), (c))  /* a * k + c */
+
+// a * b + k with the constant k as a scalar operand the COMPILER places: inside a loop body that uses the same constants
+// several times (one exp per sample) it makes them once per round, which is cheaper than the in-place form above
 __device__ __forceinline__ double fma_sk(double a, double b, double k) {
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
@@ -113,6 +144,41 @@ __device__ __forceinline__ double log_fast(double x) {
     }
     QMRI_COLD_PATH();
     return log(x);
+}
+
+// log_fast with every constant as a scalar operand made in place (see exp_sk: nothing stays pinned in registers across
+// the caller's loop) and without the device library's log behind it: every positive finite argument, denormals included,
+// goes through the frexp form; x < 0 and NaN give NaN, 0 gives -inf, +inf gives +inf like log().
+__device__ __forceinline__ double log_sk(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752) {
+        m = m + m;
+        e -= 1;
+    }
+    const double f = m - 1.0;
+    const double s = f * rcp_nr(2.0 + f);
+    const double z = s * s;
+    double p = QMRI_FMA_KS(z, 1.0 / 25.0, 1.0 / 23.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 21.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 19.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 17.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 15.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 13.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 11.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 9.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 7.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 5.0);
+    p = QMRI_FMA_SK(p, z, 1.0 / 3.0);
+    const double ed = (double)e;
+    const double s2 = s + s;
+    const double lo = fma(s2 * z, p, QMRI_MUL_SK(ed, 1.9082149292705877e-10));
+    double r = QMRI_FMA_KS(ed, 0.69314718036912382, s2 + lo);
+    // specials: class mask 0x200 = +inf, 0x060 = +-0, 0x01f = NaNs, -inf, negative normals / denormals
+    r = __builtin_amdgcn_class(x, 0x200) ? x : r;
+    r = __builtin_amdgcn_class(x, 0x060) ? -__builtin_huge_val() : r;
+    r = __builtin_amdgcn_class(x, 0x01f) ? __builtin_nan("") : r;
+    return r;
 }
 
 }  // namespace qmri

@@ -880,9 +880,10 @@ __global__ __launch_bounds__(256, EMAX <= 8 ? QMRI_SMALL_E_BLOCKS : ((EMAX <= 16
                                             if (FULL || i < E) {
                                                 double q = sv[i];
                                                 if (q == 0.0) q = 1e-10;
-                                                // (OCML log: log_fast of fp64_fast.h is 30 instructions instead of 78, but its 14
-                                                // constants cost 54 spilled registers at two waves per SIMD: run A 22.2 -> 23.3 ms, run B 6.4 -> 7.0 ms)
-                                                sv[i] = log(q);
+                                                // (log_sk of fp64_fast.h: ~35 instructions with the constants as scalar operands made in place; the
+                                                // device library's log is 78 and pins 14 scalar registers of polynomial constants across the whole
+                                                // main loop, for every recipe)
+                                                sv[i] = log_sk(q);
                                                 sl += sv[i];
                                             }
                                         const double lmean = sl * rE;

@@ -1,6 +1,6 @@
 """Time the general lmdif kernel (lm_generic.hip) on device-resident data: bi-exponential 12-echo slab and the
 true-forward-difference mono-exponential on the bench's 8-echo volume (next to the fast kernel)."""
-import argparse, ctypes, sys, os, time
+import argparse, ctypes, hashlib, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dosma_amd import _lib as L
@@ -39,7 +39,8 @@ def run(model, x, y, p0):
     fitted = (nfev > 0).sum().item()
     print(f"{model:16s} E={y.shape[0]:2d} n={n} best {min(ts)*1e3:8.2f} ms  {n/min(ts)/1e6:8.1f} Mvox/s  "
           f"fitted {fitted/n:.2f}  mean nfev {nfev[nfev > 0].float().mean().item():.1f}  "
-          f"nan {torch.isnan(popt[:, 0]).float().mean().item():.3f}")
+          f"nan {torch.isnan(popt[:, 0]).float().mean().item():.3f}  "
+          f"sha1 {hashlib.sha1(popt.cpu().numpy().tobytes() + r2.cpu().numpy().tobytes() + nfev.cpu().numpy().tobytes()).hexdigest()[:16]}")
 
 
 # bi-exponential: two compartments, 12 echoes

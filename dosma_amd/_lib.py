@@ -158,7 +158,7 @@ EXPORTS = (
     "qmri_unet2d_segment_volume",
     "qmri_conv2d_nhwc_host", "qmri_dess_t2_device", "qmri_dess_t2_host", "qmri_rss_host",
     "qmri_lmfit_defaults", "qmri_lmfit_device", "qmri_lmfit_host", "qmri_region_stats_host",
-    "qmri_region_stats_device", "qmri_host_alloc", "qmri_host_free", "qmri_device_mem_info",
+    "qmri_region_stats_device", "qmri_host_alloc", "qmri_host_free", "qmri_device_mem_info", "qmri_selftest_fp64",
 )
 
 _lib = None
@@ -234,6 +234,9 @@ def load():
         lib.qmri_device_count.restype = ctypes.c_int
         lib.qmri_device_mem_info.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         lib.qmri_device_mem_info.restype = ctypes.c_int
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.qmri_selftest_fp64.argtypes = [ctypes.c_int32, dp, ctypes.c_int64, dp, dp, dp, dp]
+        lib.qmri_selftest_fp64.restype = ctypes.c_int
         lib.qmri_last_error.restype = ctypes.c_char_p
         lib.qmri_monoexp_kernel_name.restype = ctypes.c_char_p
         lib.qmri_monoexp_kernel_name.argtypes = [ctypes.POINTER(QmriMonoexpArgs)]
@@ -332,6 +335,16 @@ def device_mem_info(device=None):
     f, t = ctypes.c_uint64(), ctypes.c_uint64()
     check(load().qmri_device_mem_info(_dev(device), ctypes.byref(f), ctypes.byref(t)))
     return int(f.value), int(t.value)
+
+
+def selftest_fp64(x, device=None):
+    """exp_sk / exp and log_sk / log of the device for the float64 values x -> dict of four arrays (see include/qmri.h)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    out = {k: np.empty_like(x) for k in ("exp_sk", "exp_lib", "log_sk", "log_lib")}
+    ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))  # noqa: E731
+    check(load().qmri_selftest_fp64(_dev(device), ptr(x), x.size, ptr(out["exp_sk"]), ptr(out["exp_lib"]),
+                                    ptr(out["log_sk"]), ptr(out["log_lib"])))
+    return out
 
 
 def default_args() -> QmriMonoexpArgs:

@@ -18,6 +18,7 @@
 
 #include <sys/mman.h>
 
+#include "fp64_fast.h"
 #include "qmri_internal.h"
 
 namespace {
@@ -269,6 +270,40 @@ int qmri_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_b
     HIP_TRY(hipMemGetInfo(&f, &t));
     *free_bytes = f;
     *total_bytes = t;
+    return QMRI_OK;
+}
+
+// ---- self-test of the kernels' own exp / log (fp64_fast.h) ------------------------------------------------------------
+namespace {
+__global__ void fp64_selftest_kernel(const double *x, long long n, double *e_sk, double *e_lib, double *l_sk, double *l_lib) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    e_sk[i] = qmri::exp_sk(v);
+    e_lib[i] = exp(v);
+    l_sk[i] = qmri::log_sk(v);
+    l_lib[i] = log(v);
+}
+}  // namespace
+
+int qmri_selftest_fp64(int32_t device, const double *x, int64_t n, double *exp_sk_out, double *exp_lib_out,
+                       double *log_sk_out, double *log_lib_out) {
+    if (!x || !exp_sk_out || !exp_lib_out || !log_sk_out || !log_lib_out || n < 0)
+        return fail(QMRI_ERR_ARG, "qmri_selftest_fp64: NULL pointer or negative n");
+    if (n == 0) return QMRI_OK;
+    HIP_TRY(hipSetDevice(device));
+    AsyncScratch buf;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIP_TRY(buf.alloc(5 * bytes, nullptr));
+    double *d = static_cast<double *>(buf.p);
+    HIP_TRY(hipMemcpy(d, x, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fp64_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, (long long)n, d + n,
+                       d + 2 * n, d + 3 * n, d + 4 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(exp_sk_out, d + n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(exp_lib_out, d + 2 * n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(log_sk_out, d + 3 * n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(log_lib_out, d + 4 * n, bytes, hipMemcpyDeviceToHost));
     return QMRI_OK;
 }
 

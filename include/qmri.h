@@ -391,6 +391,11 @@ int qmri_version(void);
 int qmri_device_count(void);
 /* free / total bytes of device memory (hipMemGetInfo): callers size their per-model activation buffers from it */
 int qmri_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
+/* Self-test of the two elementary functions the fit kernels carry themselves (dosma_amd/csrc/fp64_fast.h): for n host values x,
+ * exp_sk(x) next to the device library's exp(x) -- bit-identical by construction -- and log_sk(x) (the logarithm of the
+ * log-linear starting point, fitting.py:701-718) next to the device library's log(x).  Host arrays of n doubles each. */
+int qmri_selftest_fp64(int32_t device, const double *x, int64_t n, double *exp_sk_out, double *exp_lib_out,
+                       double *log_sk_out, double *log_lib_out);
 const char *qmri_last_error(void);
 /* name of the fit kernel variant that `args` would dispatch to (for profiles / tests) */
 const char *qmri_monoexp_kernel_name(const qmri_monoexp_args *args);

@@ -352,3 +352,39 @@ def test_full_size_properties():
     f = fg[:n]
     assert ((popt2[f, 0] - 2 * popt1[f, 0]).abs() / popt1[f, 0].abs()).max().item() < 1e-6
     assert ((popt2[f, 1] - popt1[f, 1]).abs() / popt1[f, 1].abs()).max().item() < 1e-6
+
+
+@pytest.mark.gpu
+def test_kernel_exp_and_log_selftest():
+    """The two elementary functions the fit kernels carry themselves (csrc/fp64_fast.h), through qmri_selftest_fp64:
+    exp_sk is the device library's exp bit for bit (it is the same algorithm with its constants as scalar operands), and
+    log_sk -- the logarithm of the log-linear starting point (fitting.py:701-718) -- is within 2 ulp of numpy's log over the
+    whole positive range, denormals included, with log()'s values at 0, inf, NaN and negative arguments."""
+    from dosma_amd import _lib as L
+
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.uniform(-745.0, 710.0, 200000), rng.uniform(-4.0, 4.0, 200000), rng.standard_normal(100000) * 1e-6,
+        np.array([0.0, -0.0, 709.78, 709.79, 1024.0, 1025.0, -745.2, -1075.0, -1076.0, np.inf, -np.inf, np.nan, 1e-320, 5e-324]),
+        np.exp(rng.uniform(-740.0, 709.0, 300000)), rng.uniform(0.5, 2.0, 200000), rng.uniform(0.0, 4096.0, 200000),
+        np.array([1.0, 2.0, 0.5, np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1e-10, 2.2250738585072014e-308, 1e-310, 4.9e-324,
+                  1.7976931348623157e308])])
+    o = L.selftest_fp64(x)
+    # exp: bit-identical to the device library, NaNs in the same places
+    a, b = o["exp_sk"].view(np.uint64), o["exp_lib"].view(np.uint64)
+    nan = np.isnan(o["exp_lib"])
+    assert np.array_equal(np.isnan(o["exp_sk"]), nan)
+    assert np.array_equal(a[~nan], b[~nan])
+    # log: specials as log(), everything else within 2 ulp of numpy's (correctly rounded to < 1 ulp) value
+    with np.errstate(all="ignore"):
+        ref = np.log(x)
+    got = o["log_sk"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    inf = np.isinf(ref)
+    assert np.array_equal(got[inf], ref[inf])
+    fin = np.isfinite(ref)
+    ulp = np.abs(got[fin] - ref[fin]) / np.spacing(np.abs(ref[fin]) + 5e-324)
+    assert ulp.max() <= 2.0, (ulp.max(), x[fin][ulp.argmax()])
+    # and the device library's own log sits in the same band (the oracle's numpy log is what both are measured against)
+    ulp_lib = np.abs(o["log_lib"][fin] - ref[fin]) / np.spacing(np.abs(ref[fin]) + 5e-324)
+    assert ulp_lib.max() <= 2.0

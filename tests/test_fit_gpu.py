@@ -6,6 +6,7 @@ compared exactly where the decisions are not borderline).
 Run on the GPU box with ``pytest -m gpu``.  Nothing here reads /root/reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -388,3 +389,44 @@ def test_kernel_exp_and_log_selftest():
     # and the device library's own log sits in the same band (the oracle's numpy log is what both are measured against)
     ulp_lib = np.abs(o["log_lib"][fin] - ref[fin]) / np.spacing(np.abs(ref[fin]) + 5e-324)
     assert ulp_lib.max() <= 2.0
+
+
+_ORDER_WORKER = r'''
+import hashlib, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from dosma_amd import _lib as L
+rng = np.random.default_rng(11)
+n = 300000
+x = np.arange(1, 9) * 10.0
+t2 = rng.uniform(15, 80, n); s0 = rng.uniform(300, 1500, n)
+y = (s0 * np.exp(-x[:, None] / t2) + rng.standard_normal((8, n)) * 15).astype(np.float32)
+y[:, ::7] = 0                       # skipped voxels in between
+y[:, 5::11] = rng.standard_normal((8, y[:, 5::11].shape[1])).astype(np.float32) * 40   # noise: long, failing trajectories
+h = hashlib.sha1()
+for p0 in ((1.0, -1 / 30.0), None):
+    o = L.monoexp_fit_host(x, y, p0=p0, want_info=True) if p0 else L.monoexp_fit_host(x, y, init=L.INIT_LOGLIN, want_info=True)
+    for k in ("popt", "r2", "info", "nfev"):
+        h.update(np.ascontiguousarray(o[k]).tobytes())
+print("SHA", h.hexdigest())
+'''
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_the_order_voxels_are_pulled():
+    """A voxel's result is a function of its samples alone: the lane-pull queue, the refill threshold, the result ring and
+    the tile a voxel sits in only change WHEN and next to WHOM it is solved.  The same 300 000 voxels (tissue, skipped,
+    pure noise) with the refill threshold at 2, 8 and 24 idle lanes -- three different interleavings -- give byte-identical
+    raw outputs (a, b, r2, stop code, evaluation count), for the fixed and the log-linear start."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for idle in ("2", "8", "24"):
+        env = dict(os.environ, QMRI_REFILL_IDLE=idle)
+        p = subprocess.run([sys.executable, "-c", _ORDER_WORKER % {"root": root}], env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        shas.append([l for l in p.stdout.splitlines() if l.startswith("SHA")][0])
+    assert shas[0] == shas[1] == shas[2], shas

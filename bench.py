@@ -318,9 +318,33 @@ def bench_dess(L, lib, torch, device, local_rank, world, args, barrier):
     barrier()
     ms = ev0.elapsed_time(ev1) / reps
     gbs = 16.0 * n / (ms * 1e-3) / 1e9
+    # the same kernel on a batch of 8 volumes in ONE launch (3 GB of traffic): long enough to leave launch ramp and tail behind
+    nb = 8 * n
+    e1b = e1.repeat(8)
+    e2b = e2.repeat(8)
+    t2b = torch.empty(nb, device=device, dtype=torch.float64)
+    b = L.QmriDessArgs()
+    ctypes.memmove(ctypes.byref(b), ctypes.byref(a), ctypes.sizeof(a))
+    b.echo1, b.echo2, b.t2, b.N = e1b.data_ptr(), e2b.data_ptr(), t2b.data_ptr(), nb
+    for _ in range(2):
+        L.check(lib.qmri_dess_t2_device(ctypes.byref(b)))
+    barrier()
+    ev0.record(stream)
+    for _ in range(10):
+        L.check(lib.qmri_dess_t2_device(ctypes.byref(b)))
+    ev1.record(stream)
+    barrier()
+    msb = ev0.elapsed_time(ev1) / 10
+    gbsb = 16.0 * nb / (msb * 1e-3) / 1e9
+    same = bool(torch.equal(t2b[:n], t2) and torch.equal(t2b[7 * n:], t2))
+    del e1b, e2b, t2b
     return {"metric": "qDESS analytic T2 map, 384x384x160, fp32 echoes -> fp64 map", "voxels_per_s": n / (ms * 1e-3),
             "kernel_ms": ms, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_voxel": 16}}
+                                          "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_voxel": 16},
+            "batch8": {"what": "8 volumes in one launch (3.0 GB algorithmic)", "kernel_ms": msb, "voxels_per_s": nb / (msb * 1e-3),
+                       "roofline": {"bound": "hbm", "achieved": gbsb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": gbsb / HBM_PEAK_GBS},
+                       "outputs_equal_single_volume": same}}
 
 
 UNET_HW = 384
@@ -328,6 +352,24 @@ UNET_SLICES = 160
 UNET_GFLOP_PER_SLICE = 70.79   # 35.39 GMAC per 384x384 slice
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 UNET_PARITY_MODE = "fp16x3"      # the precision mode whose logits meet north_star's 1e-3 (tests/test_unet_gpu.py)
+
+
+def _mfma_ceiling():
+    """What v_mfma_f32_32x32x16_f16 sustains on THIS part on N(0,1) operands with nothing else in the loop (data-dependent
+    power sets the clock): a constant read from the committed stdout of scripts/probes/mfma_peak.hip (profiles/r0*_mfma_peak.txt,
+    newest tag), not re-measured by this run.  `peak` of the roofline stays the 2.5 PF of MI355X_MICROARCH.md."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_mfma_peak.txt")), key=os.path.basename, reverse=True):
+        try:
+            vals = [float(m.group(1)) for line in open(path) if line.startswith("N(0,1)")
+                    for m in [re.search(r"=\s*([0-9.]+) TFLOP/s", line)] if m]
+        except OSError:
+            continue
+        if vals:
+            return {"tflops": max(vals), "source": os.path.relpath(path, ROOT),
+                    "what": "scripts/probes/mfma_peak.hip, N(0,1) fp16 operands, best of 1 / 2 waves per SIMD"}
+    return None
 
 
 def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device):
@@ -362,7 +404,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
                                stream=stream.cuda_stream)
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([el], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t[0].item()
@@ -382,6 +424,8 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_BF16_PEAK_TFLOPS, "gflop_per_slice": UNET_GFLOP_PER_SLICE,
                      "mfma_issued_frac": 3 * tf / MFMA_BF16_PEAK_TFLOPS,
+                     "mfma_ceiling_measured": _mfma_ceiling(),
+                     "frac_of_measured_ceiling": (3 * tf / _mfma_ceiling()["tflops"]) if _mfma_ceiling() else None,
                      "note": "achieved = ALGORITHMIC flops (70.79 GFLOP per slice); the parity mode issues 3 MFMAs per "
                              "product, so the matrix pipes are busy 3x that fraction (mfma_issued_frac)",
                      "bf16_mode": {"achieved": tf16, "frac": tf16 / MFMA_BF16_PEAK_TFLOPS},
@@ -443,8 +487,18 @@ def _unet_traffic():
     base = {"algorithmic_bytes": alg, "algorithmic_bytes_written": alg_w, "algorithmic_bytes_read": alg_r,
             "algorithmic_bytes_note": "layer-by-layer minimum as built (4 B per activation value, first block / pooling / "
                                       "classifier fused): every feature map crossing a kernel boundary written once, read once"}
+    # newest first BY TAG (r04b > r04a > r03g: file times do not survive a checkout); a file whose recorded source hash matches
+    # the current sources wins over a newer tag that does not
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_unet_counters.json")),
-                   key=lambda q: (os.path.basename(q)[:3], os.path.getmtime(q)), reverse=True)
+                   key=lambda q: os.path.basename(q), reverse=True)
+    cur = _unet_source_sha1()
+
+    def _sha_of(q):
+        try:
+            return json.load(open(q)).get("kernel_source_sha1")
+        except (OSError, ValueError):
+            return None
+    paths.sort(key=lambda q: _sha_of(q) != cur)  # stable: matching files first, tag order kept inside each group
     for path in paths:
         try:
             pj = json.load(open(path))
@@ -607,6 +661,9 @@ def main():
                     help="slices per pass through the network (default: the whole 160-slice volume)")
     ap.add_argument("--cfg5-volumes-per-gpu", type=int, default=8)
     ap.add_argument("--cfg5-unet-batch", type=int, default=160)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the torch.distributed group also for ONE rank (the RCCL calls of an N-GPU run on a 1-GPU box); "
+                         "implied when launched by torch.distributed.run")
     ap.add_argument("--print-kernel-hash", action="store_true")
     ap.add_argument("--print-unet-hash", action="store_true")
     args = ap.parse_args()
@@ -639,7 +696,10 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     red_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # the process group exists whenever torch.distributed.run launched us (any N, one included) or --force-dist is given:
+    # every `dist.` call below then goes through RCCL exactly as it will at N = 8
+    use_dist = world > 1 or args.force_dist or qd.launched_by_torchrun()
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -657,7 +717,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -675,7 +735,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed, kernel_ms], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = t[0].item(), t[1].item()
@@ -738,11 +798,17 @@ def main():
         # over the launch duration measured here
         valu_peak = 256 * 4 * 16 * 2.4e9
         valu_rate = valu_lane_instr / (ra["kernel_ms"] * 1e-3) if valu_lane_instr else None
+        solved = int((y != 0).any(dim=0).sum().item())
         out = {
             "metric": "voxel-fits/sec (8-echo monoexp, 512x512x160) [+ UNet2D slices/sec under \"unet2d\"]",
             "value": value,
             "unit": "voxel-fits/s",
+            # `value` counts every voxel of the volume, including the ~30 % all-zero background the reference's skip
+            # rule (fitting.py:1065-1067) retires without a solve; this is the rate over the voxels that ran the solver
+            "solved_voxel_fits_per_s": value * solved / n,
             "n_gpus": world,
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "collectives_on": str(red_device)} if use_dist else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ra["elapsed"] / args.steps * 1e3,
@@ -756,7 +822,7 @@ def main():
                             "(BASELINE.json configs[1]); MonoExponentialFit() defaults; "
                             "one volume per GPU per step",
                 "voxels_per_gpu_per_step": n,
-                "solved_voxels_per_gpu_per_step": int((y != 0).any(dim=0).sum().item()),
+                "solved_voxels_per_gpu_per_step": solved,
                 "echoes": E,
                 "parallelism": f"volumes sharded over {world} GPU(s), no data-path collective",
                 "kernel": ra["kernel"],
@@ -806,7 +872,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(y)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -95,10 +95,11 @@ def empty(shape, dtype):
             fits = _live + size <= cap
             drop = []
             if fits:
+                _live += size  # reserved under the same lock as the check: concurrent callers cannot pass it together
                 # make room among the cached blocks of other sizes first: the total stays below the cap
                 for sz in sorted(_free, reverse=True):
-                    while _free[sz] and _live + _cached + size > cap:
-                        drop.append(_free[sz].pop())
+                    while _free[sz] and _live + _cached > cap:
+                        drop.append((sz, _free[sz].pop()))
                         _cached -= sz
         if not fits:
             return np.empty(shape, dt)
@@ -106,15 +107,20 @@ def empty(shape, dtype):
             from dosma_amd import _lib
             lib = _lib.load()
             out = ctypes.c_void_p()
-            for p in drop:
-                lib.qmri_host_free(ctypes.c_void_p(p))
-            if lib.qmri_device_count() <= 0 or lib.qmri_host_alloc(size, ctypes.byref(out)) != 0 or not out.value:
-                return np.empty(shape, dt)
-            ptr = out.value
+            while drop:
+                lib.qmri_host_free(ctypes.c_void_p(drop[-1][1]))
+                drop.pop()
+            if lib.qmri_device_count() > 0 and lib.qmri_host_alloc(size, ctypes.byref(out)) == 0 and out.value:
+                ptr = out.value
         except Exception:
+            ptr = None
+        if ptr is None:
+            with _lock:
+                _live -= size  # the reservation is rolled back; blocks that were not freed go back on the free list
+                for sz, p in drop:
+                    _free.setdefault(sz, []).append(p)
+                    _cached += sz
             return np.empty(shape, dt)
-        with _lock:
-            _live += size
     buf = (ctypes.c_ubyte * size).from_address(ptr)
     fin = weakref.finalize(buf, _release, ptr, size)
     fin.atexit = False  # nothing to recycle at interpreter exit (and no HIP call from an exit handler or a forked child)

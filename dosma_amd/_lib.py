@@ -20,6 +20,7 @@ QMRI_ERR_ARG = -1
 QMRI_ERR_UNSUPPORTED = -2
 QMRI_ERR_HIP = -3
 QMRI_ERR_NONFINITE = -4
+QMRI_ERR_NOMEM = -5
 
 QMRI_F32, QMRI_F64, QMRI_I16, QMRI_U16 = 0, 1, 2, 3
 INIT_SCALAR, INIT_PER_VOXEL, INIT_LOGLIN = 0, 1, 2
@@ -169,6 +170,10 @@ class QmriError(RuntimeError):
     pass
 
 
+class QmriOutOfMemory(QmriError, MemoryError):
+    """QMRI_ERR_NOMEM: the device allocation failed; a smaller batch may fit."""
+
+
 def library_path() -> str:
     return _SO
 
@@ -302,6 +307,8 @@ def check(rc: int):
         raise ValueError(msg)
     if rc == QMRI_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == QMRI_ERR_NOMEM:
+        raise QmriOutOfMemory(msg)
     raise QmriError(msg)
 
 

@@ -90,7 +90,9 @@ int validate(const qmri_monoexp_args *a) {
     if (a->E > QMRI_MAX_ECHOES)
         return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds QMRI_MAX_ECHOES=%d", a->E, QMRI_MAX_ECHOES);
     if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
-    if (a->N >= (1ll << 40)) return fail(QMRI_ERR_UNSUPPORTED, "N must be below 2^40 voxels per call");  // (result ring: 40-bit voxel index)
+    // the result ring carries a 40-bit voxel index, and tile indices / the claim counter / the tile list are 32-bit at 128 voxels
+    // per tile (monoexp_tile_voxels()): below 2^38 voxels both hold with room for the guided claims' overshoot
+    if (a->N >= (1ll << 38)) return fail(QMRI_ERR_UNSUPPORTED, "N must be below 2^38 voxels per call");
     if (a->init < QMRI_INIT_SCALAR || a->init > QMRI_INIT_LOGLIN)
         return fail(QMRI_ERR_ARG, "unknown init mode %d", a->init);
     if (a->maxfev <= 0 || a->ftol < 0 || a->xtol < 0 || a->gtol < 0 || a->factor <= 0)

@@ -36,8 +36,8 @@ int ufail(int code, const char *fmt, ...) {
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess)                                                                   \
-            return ufail(QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                         __FILE__, __LINE__);                                                   \
+            return ufail(e_ == hipErrorOutOfMemory ? QMRI_ERR_NOMEM : QMRI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                         hipGetErrorString(e_), __FILE__, __LINE__);                            \
     } while (0)
 
 unsigned short f32_to_bf16_rne(float f) {
@@ -338,8 +338,10 @@ struct Unet {
     // 12 / 16-bit intensities (oaiunet2d.py:322-323).  Every kernel that writes the layout sets `sat` when it meets such a
     // value, and the forward is then REPEATED with the whole network scaled by 2^-act_shift: input * 2^-S, every bias and
     // BatchNorm shift * 2^-S, classifier weights * 2^S.  ReLU, max-pooling, convolution and the BatchNorm scale commute with
-    // a positive factor, so every activation is exactly 2^-S times what it was and the logits are unchanged -- bit for bit
-    // (powers of two; nothing here is near the subnormal range) -- while the stored values move back into range.
+    // a positive factor, so in exact arithmetic every activation is 2^-S times what it was and the logits are unchanged, while the
+    // stored values move back into range.  In the fp16 hi + lo layout the scaled network is NOT bit-identical for small
+    // activations (their lo parts reach the fp16 subnormal range after the scaling and lose bits): what is tested, and claimed,
+    // is the 1e-3 logit bound of the parity mode (tests/test_unet_gpu.py::test_raw_intensity_input_runs_in_range).
     DevBuf sat;                       // int flag (device)
     int act_shift = 0;                // S the device-side parameters currently carry
     int act_bump = 0;                 // what saturating forwards have added to the exponent chosen from the input so far
@@ -971,6 +973,7 @@ static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hi
         return rc0 != QMRI_OK ? rc0 : body();
     }
     int S = 0;
+    bool nonfinite_in = false;
     if (!whitened) {  // raw intensities (IWOAIOAIUnet2D, oaiunet2d.py:322-323): bring max |x| below 128 to start with
         unsigned int bits = 0;
         U_TRY(qmri::absmax_launch(xd, n, reinterpret_cast<unsigned int *>(U->sat_ptr() + 1), st));
@@ -978,7 +981,10 @@ static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hi
         U_TRY(hipStreamSynchronize(st));
         float m;
         std::memcpy(&m, &bits, 4);
-        if (std::isfinite(m) && m >= 128.f) S = std::ilogb(m) - 6;
+        // an input holding Inf / NaN has no exponent that brings it into range: it goes through ONCE, unscaled, and the
+        // affected slices come out as the reference's do (NaN logits, empty masks) -- no retries, no "exceeds fp16" error
+        nonfinite_in = bits >= 0x7f800000u;
+        if (!nonfinite_in && m >= 128.f) S = std::ilogb(m) - 6;
     }
     const int bump_at_entry = U->act_bump;
     S += U->act_bump;
@@ -992,7 +998,7 @@ static int run_in_range(Unet *U, const float *xd, long long n, bool whitened, hi
         int flag = 0;
         U_TRY(hipMemcpyAsync(&flag, U->sat.p, sizeof(int), hipMemcpyDeviceToHost, st));
         U_TRY(hipStreamSynchronize(st));
-        if (!flag) {
+        if (!flag || nonfinite_in) {
             U->trace += "act_shift:" + std::to_string(S) + ";";  // (tests: which exponent the forward ran at)
             return QMRI_OK;
         }

@@ -998,11 +998,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
 
 // ---- activation exponent of the parity mode (unet_engine.hip: Unet::sat): max |x| of the input, and y = x * 2^-S ----
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long long n, unsigned int *__restrict__ out) {
-    float m = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(x[i]));
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+    // on the BIT PATTERNS of |x|: non-negative floats order like their patterns, +inf sorts above every finite value and a NaN
+    // above +inf (fmaxf would drop it) -- the host sees a non-finite input as a pattern >= 0x7f800000
+    unsigned int m = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned int b = __float_as_uint(fabsf(x[i]));
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int other = (unsigned int)__shfl_down((int)m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict__ x, long long n, float f, float *__restrict__ y) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

@@ -21,8 +21,17 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str = None):
-    """Initialise the process group (no-op for a single process).  Returns (rank, local_rank, world).
+def launched_by_torchrun() -> bool:
+    """True under ``python -m torch.distributed.run`` (also with ``--nproc-per-node 1``): it exports the rendezvous."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+
+
+def init(backend: str = None, force: bool = False):
+    """Initialise the process group.  Returns (rank, local_rank, world).
+
+    A plain single process (``python script.py``) stays without a group: every helper below then degenerates to the
+    identity.  Under ``torch.distributed.run`` -- with ANY number of ranks, one included -- or with ``force=True`` the
+    group is created, so that a world of one runs the same RCCL calls an 8-GPU node will (tests/test_dist.py).
 
     backend: "nccl" (= RCCL over xGMI on ROCm) when a GPU is visible, else "gloo".
     """
@@ -30,7 +39,7 @@ def init(backend: str = None):
     import torch.distributed as dist
 
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force or launched_by_torchrun()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -97,18 +106,10 @@ def allgather_scalars(values: Sequence[float]) -> np.ndarray:
     return np.stack([o.cpu().numpy() for o in out], axis=0)
 
 
-def sharded_map(n_items: int, fn: Callable[[int], Dict[str, float]]):
-    """Run ``fn(v)`` for every batch item this rank owns; gather every item's scalar summary everywhere.
-
-    ``fn`` does the per-volume work on this rank's GPU (e.g. ``MonoExponentialFit.fit`` + ``generate_mask``)
-    and returns a dict of scalars (same keys for every item), e.g. voxel counts and mean tc.
-    Returns (local: {v: fn(v)}, summary: {key: ndarray[n_items]}) -- the summary is identical on all ranks.
-    """
-    rank, _, world = env_world()
-    mine = partition(n_items, world, rank)
-    local = {v: fn(v) for v in mine}
+def _gather_item_scalars(n_items: int, mine: List[int], local: Dict[int, Dict[str, float]], world: int) -> Dict[str, np.ndarray]:
+    """All-gather the per-item scalar dictionaries: {key: ndarray[n_items]}, identical on every rank.  Every rank
+    contributes a vector of the same length (items per rank padded to the maximum, NaN index = no item)."""
     keys = sorted(next(iter(local.values())).keys()) if local else []
-    # every rank must contribute the same vector length: pad to the max items per rank
     per_rank = (n_items + world - 1) // world
     nk = int(allreduce_max(float(len(keys))))
     if not keys:
@@ -125,7 +126,20 @@ def sharded_map(n_items: int, fn: Callable[[int], Dict[str, float]]):
             if not np.isnan(idx):
                 for j, k in enumerate(keys):
                     summary[k][int(idx)] = gathered[r, slot, 1 + j]
-    return local, summary
+    return summary
+
+
+def sharded_map(n_items: int, fn: Callable[[int], Dict[str, float]]):
+    """Run ``fn(v)`` for every batch item this rank owns; gather every item's scalar summary everywhere.
+
+    ``fn`` does the per-volume work on this rank's GPU (e.g. ``MonoExponentialFit.fit`` + ``generate_mask``)
+    and returns a dict of scalars (same keys for every item), e.g. voxel counts and mean tc.
+    Returns (local: {v: fn(v)}, summary: {key: ndarray[n_items]}) -- the summary is identical on all ranks.
+    """
+    rank, _, world = env_world()
+    mine = partition(n_items, world, rank)
+    local = {v: fn(v) for v in mine}
+    return local, _gather_item_scalars(n_items, mine, local, world)
 
 
 def broadcast_array(arr: np.ndarray, src: int = 0) -> np.ndarray:
@@ -188,24 +202,7 @@ def run_batch(n_volumes: int, per_volume: Callable[[int], Dict[str, float]], *, 
     mine_s = time.perf_counter() - t0
     barrier()
     wall = allreduce_max(time.perf_counter() - t0)
-    # gather the per-volume scalars (same layout as sharded_map)
-    keys = sorted(next(iter(local.values())).keys()) if local else []
-    nk = int(allreduce_max(float(len(keys))))
-    if not keys:
-        keys = [f"_{i}" for i in range(nk)]
-    per_rank = (n_volumes + world - 1) // world
-    buf = np.full((per_rank, 1 + nk), np.nan)
-    for slot, v in enumerate(mine):
-        buf[slot, 0] = v
-        buf[slot, 1:] = [local[v][k] for k in keys]
-    gathered = allgather_scalars(buf.reshape(-1)).reshape(world, per_rank, 1 + nk)
-    summary = {k: np.full(n_volumes, np.nan) for k in keys}
-    for r in range(world):
-        for slot in range(per_rank):
-            idx = gathered[r, slot, 0]
-            if not np.isnan(idx):
-                for j, k in enumerate(keys):
-                    summary[k][int(idx)] = gathered[r, slot, 1 + j]
+    summary = _gather_item_scalars(n_volumes, mine, local, world)  # control plane, once, after the clock
     busy = allgather_scalars([mine_s])[:, 0]
     return {"wall_s": wall, "volumes": n_volumes, "volumes_per_s": n_volumes / wall if wall > 0 else float("inf"),
             "per_rank": [len(partition(n_volumes, world, r)) for r in range(world)],

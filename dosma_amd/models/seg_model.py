@@ -99,8 +99,8 @@ class HipSegModel(SegModel):
             try:
                 return _lib.Unet2dEngine(tensors, input_shape[0], input_shape[1], n_classes=n_classes,
                                          max_batch=max_batch, precision=self.precision, device=self.device)
-            except _lib.QmriError as e:
-                if max_batch <= floor or "memory" not in str(e).lower():
+            except _lib.QmriOutOfMemory:  # the library's status code (QMRI_ERR_NOMEM), not the wording of the message
+                if max_batch <= floor:
                     raise
                 max_batch = max(floor, max_batch // 2)
 

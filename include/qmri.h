@@ -37,8 +37,10 @@ typedef enum qmri_status {
     QMRI_ERR_ARG = -1,         /* bad argument (shape, dtype, NULL)        -> ValueError          */
     QMRI_ERR_UNSUPPORTED = -2, /* valid request this build does not cover -> NotImplementedError */
     QMRI_ERR_HIP = -3,         /* HIP runtime error / no device            -> RuntimeError        */
-    QMRI_ERR_NONFINITE = -4    /* y holds NaN/Inf: the reference raises ValueError for the whole
+    QMRI_ERR_NONFINITE = -4,   /* y holds NaN/Inf: the reference raises ValueError for the whole
                                   call (scipy check_finite, via fitting.py:1030)                   */
+    QMRI_ERR_NOMEM = -5        /* device memory exhausted (hipErrorOutOfMemory): the caller may
+                                  retry with a smaller batch                   -> MemoryError        */
 } qmri_status;
 
 /* element type of y (what a MedicalVolume of DICOM / NIfTI data holds) */

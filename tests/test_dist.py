@@ -173,3 +173,83 @@ def test_knee_batch_example(ranks):
     assert "voxels" in rows and "seconds" in rows and any(k.startswith("t2_mean_") for k in rows)
     # every volume was processed exactly once, whichever rank owned it: three voxel counts of 64 * 96 * 4
     assert rows["voxels"].count("24576") == 3, rows["voxels"]
+
+
+RCCL_WORKER = r"""
+import os, sys, json, zlib
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as td
+from dosma_amd import dist as qd
+from dosma_amd.models import weights as W
+
+rank, local_rank, world = qd.init()          # launched like torch.distributed.run does it: nccl because a GPU is visible
+assert world == 1 and td.is_initialized() and td.get_backend() == "nccl", (world, td.is_initialized())
+assert qd._device_for_collectives().type == "cuda"
+tmax = qd.allreduce_max(3.25)
+g = qd.allgather_scalars([1.5, -2.0, 7.0])
+wts = W.random_weights(seed=0)
+before = {k: zlib.crc32(np.ascontiguousarray(v, dtype=np.float32).tobytes()) for k, v in wts.items()}
+nbytes = int(sum(np.asarray(v).size for v in wts.values()) * 4)
+out = qd.broadcast_weights(wts, src=0)       # ONE packed broadcast through RCCL: host -> device -> collective -> host
+after = {k: zlib.crc32(np.ascontiguousarray(v, dtype=np.float32).tobytes()) for k, v in out.items()}
+shapes_ok = all(out[k].shape == np.asarray(wts[k]).shape for k in wts)
+resident = []
+def vol(v):
+    t = torch.full((1024,), float(v), device="cuda")
+    return {"sum": float(t.sum().item()), "v": float(v)}
+batch = qd.run_batch(3, vol, setup=resident.extend)
+local, summ = qd.sharded_map(4, lambda v: {"sq": float(v * v)})
+qd.barrier()
+td.destroy_process_group()
+print("RESULT " + json.dumps({"tmax": tmax, "g": g.tolist(), "nbytes": nbytes, "same": before == after, "shapes_ok": shapes_ok,
+                              "resident": resident, "per_rank": batch["per_rank"], "sum": batch["summary"]["sum"].tolist(),
+                              "wall": batch["wall_s"], "sq": summ["sq"].tolist()}))
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one(tmp_path):
+    """Every collective helper of dosma_amd.dist through the REAL "nccl" (= RCCL) backend on the box's GPU, world size 1:
+    init_process_group(device_id=...), the CUDA branch of _device_for_collectives, all_reduce MAX, all_gather, the
+    device round trip of the 138 MB packed weight broadcast (CRC per tensor), run_batch / sharded_map.  What an 8-GPU
+    run adds to this is ranks, not code."""
+    import json
+
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.pop("QMRI_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads(next(l for l in p.stdout.splitlines() if l.startswith("RESULT "))[7:])
+    assert r["tmax"] == 3.25 and r["g"] == [[1.5, -2.0, 7.0]]
+    assert r["nbytes"] > 1.3e8 and r["same"] and r["shapes_ok"]
+    assert r["resident"] == [0, 1, 2] and r["per_rank"] == [3] and r["sum"] == [0.0, 1024.0, 2048.0] and r["wall"] > 0
+    assert r["sq"] == [0.0, 1.0, 4.0, 9.0]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_through_rccl():
+    """bench.py launched by torch.distributed.run with ONE rank: the nccl init_process_group(device_id=...) line, the
+    barriers, the MAX all-reduces of the timings and cfg5's weight broadcast + scalar all-gathers all run through RCCL
+    on the leased GPU -- the first 8-GPU run is then not the first RCCL call of this code."""
+    import json
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "QMRI_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--cfg5-volumes-per-gpu", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["process_group"] == {"backend": "nccl", "world_size": 1, "collectives_on": "cuda:0"}
+    c5 = out["cfg5"]
+    assert c5["per_rank"] == [1] and c5["weights_broadcast"]["identical_on_all_ranks"] and c5["weights_broadcast"]["bytes"] > 1.3e8
+    assert out["parity"]["nfev_equal_frac"] > 0.999 and out["unet2d"]["value"] > 100

@@ -105,6 +105,46 @@ def test_512_logits_parity_mode(net):
     eng.close()
 
 
+# slices compared at the bench's batch size: first / last, both sides of an XCD work-range boundary of the 8 x 32-tile levels
+# (160 slices over 8 XCDs = 20 per XCD: 19 | 20, 79 | 80), and one whose flattened-level tiles straddle tile boundaries
+# (a tile of the flattened levels is 256 / 512 flat positions: no slice starts on one except slice 0)
+_BATCH_SAMPLE = [0, 19, 20, 79, 80, 121, 159]
+
+
+def _bench_batch_parity(net, H, W, seed):
+    """ONE pass of 160 slices through max_batch = 160 -- the shape bench.py times (`unet2d` at 384 x 384, `cfg5` at
+    512 x 512; /root/reference/dosma/models/oaiunet2d.py:291-320 predicts the whole volume, reference test
+    tests/models/test_oaiunet2d.py:19-41) -- compared on sampled slices with the restatement run on THOSE slices of the volume
+    whitened with the whole volume's statistics (seg_model.py:114-127)."""
+    w, tensors = net
+    S = 160
+    vol = _volume(S, H, W, seed)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)   # statistics of all 160 slices
+    ref = uo.forward(w, xw[_BATCH_SAMPLE], dtype="float64")
+    eng = L.Unet2dEngine(tensors, H, W, max_batch=S, precision="fp16x3")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    assert logits.shape == (S, H, W, 4)
+    err = np.abs(logits[_BATCH_SAMPLE] - ref)
+    assert err.max() < 1e-3, f"max |dlogit| {err.max():.3e} per slice {err.reshape(len(_BATCH_SAMPLE), -1).max(1)}"
+    band = np.abs(ref) < 1e-3                                            # the mask may differ only inside the tolerance band
+    assert np.array_equal(mask[_BATCH_SAMPLE][~band], (ref > 0)[~band].astype(np.uint8))
+    assert np.array_equal(mask, (logits > 0).astype(np.uint8))
+    # every slice went through the network (none left at its buffer's previous content)
+    assert np.isfinite(logits).all() and np.abs(logits).reshape(S, -1).max(1).min() > 0
+    _expect_families(eng.trace(), H, W)
+    eng.close()
+
+
+def test_384_logits_at_bench_batch(net):
+    """BASELINE configs[3] at the batch the bench times: 160 slices of 384 x 384 in one pass."""
+    _bench_batch_parity(net, 384, 384, 3840)
+
+
+def test_512_logits_at_cfg5_batch(net):
+    """BASELINE configs[4]'s segmentation shape: 160 slices of 512 x 512 in one pass (bench.py `cfg5`)."""
+    _bench_batch_parity(net, 512, 512, 5120)
+
+
 def test_odd_level_widths_take_the_general_kernel(net):
     """224 x 224: 224 = 7 x 32 (8 x 32 tiles), 112 and 56 are neither multiples of 32 nor <= 48 (general kernel on the split
     layout), 28 / 14 / 7 flattened -- all three families in one network, same 1e-3 bar."""

@@ -248,8 +248,18 @@ struct ConvS3Args {
     // tracks max |v| of what it stores and sets *sat = 1 when it exceeds 65504; the engine then repeats the forward with the
     // whole network scaled down by a power of two (exact: unet_engine.hip, `act_shift`) instead of returning clamped results.
     int *sat;
+    // conv_c4_kernel (unet_c4.hip): the same layer on one wave per SIMD with 128 x 128 register tiles, for Cout % 128 == 0.
+    // w_c4 = the weights packed per (channel block, chunk, 16-channel half, tap) as the 8 KB LDS image of a ring slot
+    // ([plane][128 rows][2 x 16 B], piece g of row n at position g ^ ((n >> 3) & 1)); nullable.  c4_mode: 0 = the launcher's
+    // cost model picks the kernel per layer, 1 = conv_c4_kernel (error if it does not take the layer), -1 = conv_s3_kernel.
+    const void *w_c4;
+    int c4_mode;
 };
 bool conv_s3_supported(const ConvS3Args &k);
+bool conv_c4_supported(const ConvS3Args &k);
+bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu);  // will conv_s3_launch run this layer on conv_c4_kernel
+int conv_c4_work_items(const ConvS3Args &k);
+hipError_t conv_c4_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 int conv_s3_block_channels(int Cout, int deconv);  // channel-block size the kernel uses for a layer: the weight packing depends on it
 hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 // streaming kernels on the split layout (unet_s3.hip)

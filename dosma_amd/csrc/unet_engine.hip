@@ -100,6 +100,8 @@ struct ConvLayer {
     DevBuf w_hi, w_lo, bias, scale, shift;
     DevBuf h_hi, h_lo;   // parity mode, general kernel: fp16 hi / lo parts, same K-major layout as w_hi
     DevBuf w_s3;         // parity mode, conv_s3_kernel: per channel block and K step the [plane][BN][64 B] LDS image
+    DevBuf w_c4;         // parity mode, conv_c4_kernel (Cout % 128 == 0): per channel block and k-step (chunk, 16-channel half, tap)
+                         // the 8 KB LDS image [plane][128 rows][2 x 16 B], piece g of row r at position g ^ ((r >> 3) & 1)
     DevBuf w_s3b;        // plain-bf16 mode on conv_s3_kernel (Cin % 64 == 0): the same image geometry with 64-channel chunks,
                          // plane p = channels 32 p .. 32 p + 31 of the chunk, bf16 values
     float winv = 1.f;    // 2^-wshift
@@ -141,6 +143,27 @@ struct ConvLayer {
                         }
         e = w_s3.alloc(img.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        if (e != hipSuccess || deconv || Cout % 128 || ntaps != 9) return e;
+        // conv_c4_kernel: [nb][chunk][half][tap] slots of [plane][128 rows][2 positions x 8 halfs]
+        const int chunks = Cin / 32;
+        std::vector<unsigned short> im4((size_t)Cout * K * 2);
+        for (int nb = 0; nb < Cout / 128; ++nb)
+            for (int ch = 0; ch < chunks; ++ch)
+                for (int half = 0; half < 2; ++half)
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const size_t slot = ((((size_t)nb * chunks + ch) * 2 + half) * 9 + tap) * 4096;
+                        for (int plane = 0; plane < 2; ++plane)
+                            for (int r = 0; r < 128; ++r)
+                                for (int g = 0; g < 2; ++g) {
+                                    const int pos = g ^ ((r >> 3) & 1);
+                                    const size_t src = (size_t)(nb * 128 + r) * K + ((size_t)ch * 9 + tap) * 32 + half * 16 + g * 8;
+                                    const size_t dst = slot + (size_t)plane * 2048 + (size_t)r * 16 + pos * 8;
+                                    const unsigned short *from = (plane ? lo.data() : hi.data()) + src;
+                                    for (int k = 0; k < 8; ++k) im4[dst + k] = from[k];
+                                }
+                    }
+        e = w_c4.alloc(im4.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(w_c4.p, im4.data(), im4.size() * 2, hipMemcpyHostToDevice);
         return e;
     }
 
@@ -631,6 +654,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         k.B = Bt; k.H = H; k.W = W;
         k.Cin = L.Cin; k.Cout = L.Cout;
         k.w = L.w_s3.p;
+        k.w_c4 = L.w_c4.p;
         k.winv = L.winv;
         k.bias = L.bias.as<float>();
         k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
@@ -648,8 +672,12 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
             k.head_w = U->head_w.as<float>(); k.head_b = U->head_b.as<float>(); k.head_nc = U->ncls;
             k.logits = logits; k.mask = mask;
         }
+        const bool c4 = qmri::conv_s3_takes_c4(k, U->num_cu);  // (the launcher's own choice: one wave per SIMD, 128 x 128 register tiles)
         U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
-        snprintf(buf, sizeof(buf), "%s:s3/%s/bn%d%s%s;", name, flat ? "flat" : "2d", bn, fuse_pool ? "+pool" : "", fuse_head ? "+head" : "");
+        if (c4)
+            snprintf(buf, sizeof(buf), "%s:s3/%s/c4%s;", name, flat ? "flat" : "2d", fuse_pool ? "+pool" : "");
+        else
+            snprintf(buf, sizeof(buf), "%s:s3/%s/bn%d%s%s;", name, flat ? "flat" : "2d", bn, fuse_pool ? "+pool" : "", fuse_head ? "+head" : "");
         U->trace += buf;
         if (pool_y && !fuse_pool) {
             U_TRY(qmri::maxpool2_split_launch(y, ldy, yoff, Bt, H, W, L.Cout, pool_y, st));
@@ -1192,6 +1220,7 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         hipDeviceProp_t prop;
         U_TRY(hipGetDeviceProperties(&prop, device));
         // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
+        // 4: conv_c4_kernel or an error; 5: conv_s3_kernel whatever the cost model says (tests compare the two)
         const bool s3 = !ab && precision != 2 && s3_width_ok(W);
         if (!ab) U_TRY(L.upload_parity(wk, s3));
         if (precision == 3) {
@@ -1215,6 +1244,8 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
             k.x = dxb.p; k.ldx = Cin; k.B = B; k.H = H; k.W = W; k.Cin = Cin; k.Cout = Cout;
             k.deconv = transposed ? 1 : 0;
             k.w = L.w_s3.p; k.winv = L.winv;
+            k.w_c4 = L.w_c4.p;
+            k.c4_mode = precision == 4 ? 1 : precision == 5 ? -1 : 0;
             k.bias = L.bias.as<float>();
             k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
             k.shift = L.has_affine ? L.shift.as<float>() : nullptr;

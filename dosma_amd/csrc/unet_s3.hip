@@ -53,6 +53,7 @@ constexpr int kMTile = 256;        // output positions per tile: 8 MFMA row-tile
 constexpr int kPitch2D = 34;       // halo row pitch of the 8 x 32 tile
 constexpr int kHalo2D = 10 * kPitch2D;
 constexpr int kRing = 4;           // weight ring slots
+constexpr double kC4Gain = 1.10;   // conv_c4_kernel's MFMA issue rate over conv_s3_kernel<128>'s at equal work (measured: DESIGN 6.4)
 
 // LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16 (M0), global source per lane.
 // Issued through inline asm so that hipcc neither counts it (it would drain vmcnt(0) before every ds_read it cannot
@@ -883,8 +884,37 @@ int conv_s3_block_channels(int Cout, int deconv) {
     return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
 }
 
+// Which kernel for a >= 128-channel-block layer?  conv_c4_kernel (unet_c4.hip) issues MFMAs faster but works in items of
+// 512 positions x 128 channels, twice conv_s3_kernel<128>'s: with one persistent block per CU the layer takes
+// ceil(items / CUs) rounds, and a level whose item count leaves the last round mostly empty can lose more to that than the
+// faster kernel gains.  QMRI_C4 = 0 never / 1 by this model (default) / 2 wherever it is supported.
+bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
+    static const int mode = [] {
+        const char *e = std::getenv("QMRI_C4");
+        return e ? std::atoi(e) : 1;
+    }();
+    if (!k.w_c4 || k.c4_mode < 0 || !conv_c4_supported(k)) return false;
+    if (k.c4_mode > 0 || mode >= 2) return true;
+    if (mode <= 0) return false;
+    const bool flat = k.W % 32 != 0;
+    long long items_s3;
+    if (flat) {
+        const int P = k.W + 2;
+        items_s3 = ((long long)k.B * (k.H + 1) * P - P + kMTile - 1) / kMTile;
+    } else {
+        items_s3 = (long long)k.B * (k.W / 32) * ((k.H + 7) / 8);
+    }
+    items_s3 *= k.Cout / 128;
+    const long long items_c4 = conv_c4_work_items(k);
+    const double t_s3 = (double)((items_s3 + num_cu - 1) / num_cu);             // in units of one conv_s3 item
+    const double t_c4 = (double)((items_c4 + num_cu - 1) / num_cu) * 2.0 / kC4Gain;
+    return t_c4 < t_s3;
+}
+
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
     ConvS3Args k = k0;
+    if (conv_s3_takes_c4(k, num_cu)) return conv_c4_launch(k, num_cu, stream);
+    if (k.c4_mode > 0) return hipErrorInvalidValue;
     if (!conv_s3_supported(k)) return hipErrorInvalidValue;
     const int bn = conv_s3_block_channels(k.Cout, k.deconv);
     const bool flat = k.W % 32 != 0;

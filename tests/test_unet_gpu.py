@@ -73,6 +73,36 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     assert np.abs(y - ref2).max() < 3e-5
 
 
+@pytest.mark.parametrize("cin,cout,hw,B", [
+    (128, 128, (16, 96), 3),    # 2D tiles, exactly one tile row
+    (96, 256, (8, 32), 3),      # 2D, H < 16: rows 8..15 of every tile are outside the image; 3 K chunks, 2 channel blocks
+    (128, 128, (20, 64), 2),    # 2D, partial second tile row
+    (32, 128, (48, 32), 5),     # 2D, one chunk (two k-halves), several tiles per image: the K stream crosses tile boundaries
+    (64, 128, (48, 48), 3),     # flattened, several 512-position tiles
+    (64, 256, (24, 24), 3),     # flattened, tiles straddle images
+    (256, 128, (12, 12), 7),    # flattened 12 x 12 (the 384-pixel network's deepest level), 8 chunks
+    (128, 384, (5, 6), 2),      # flattened, less than one tile, three channel blocks
+])
+def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
+    """conv_c4_kernel (one wave per SIMD, 128 x 128 register tiles; unet_c4.hip) forced on, against the fp64 convolution
+    and against conv_s3_kernel on the same layer (/root/reference/dosma/models/oaiunet2d.py:213-226)."""
+    rng = np.random.default_rng(cin * 11 + cout + hw[0])
+    H, W = hw
+    x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    ref = np.maximum(torch_conv(x, k, b, False, False), 0) * sc + sh
+    y4 = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, precision="fp16x3-c4")
+    assert y4.shape == ref.shape
+    assert np.abs(y4 - ref).max() < 3e-5, np.abs(y4 - ref).max()
+    y3 = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, precision="fp16x3-s3")
+    assert np.abs(y3 - ref).max() < 3e-5
+    again = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, precision="fp16x3-c4")
+    assert np.array_equal(y4, again)  # no atomics, no timing dependence: same bits every run
+
+
 def test_deconv_matches_the_scatter_definition():
     rng = np.random.default_rng(1)
     x = rng.standard_normal((1, 3, 4, 32)).astype(np.float32)

@@ -254,11 +254,14 @@ struct ConvS3Args {
     // cost model picks the kernel per layer, 1 = conv_c4_kernel (error if it does not take the layer), -1 = conv_s3_kernel.
     const void *w_c4;
     int c4_mode;
+    int c4_split;        // filled by conv_c4_launch: split the items of the last, partial round by channels (QMRI_C4_SPLIT=0 turns it off)
 };
 bool conv_s3_supported(const ConvS3Args &k);
 bool conv_c4_supported(const ConvS3Args &k);
+int conv_c4_block_channels(int Cout);  // 128, or 64 for Cout = 64 (mod 128): the packing of w_c4 depends on it
 bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu);  // will conv_s3_launch run this layer on conv_c4_kernel
 int conv_c4_work_items(const ConvS3Args &k);
+double conv_c4_rounds(const ConvS3Args &k, int num_cu);
 hipError_t conv_c4_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 int conv_s3_block_channels(int Cout, int deconv);  // channel-block size the kernel uses for a layer: the weight packing depends on it
 hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);

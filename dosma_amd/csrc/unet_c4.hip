@@ -30,10 +30,15 @@
 //     request costs no vector ALU, and a lane outside the image reads beyond num_records = ZERO (the SAME padding; no zero
 //     line, no select; scripts/probes/buffer_lds.hip).  Waits are counted (s_waitcnt vmcnt(N): everything issued three or
 //     more steps ago has landed), one s_barrier per step of 48 MFMAs per wave.
-//   * the operand fragments of step s + 1 are read while step s multiplies (two register sets); the A-operand offsets of
-//     all nine tap shifts are per-lane constants (36 registers), the second halo buffer is an immediate offset.
+//   * the operand fragments of step s + 1 are read while step s multiplies (two register sets); the second halo buffer is an
+//     immediate offset; the first k-step of an item starts from the MFMA's constant-zero C operand (no zeroing pass).
+//   * work items are big, so the last, partial round of a launch is split by CHANNELS: each leftover item becomes four
+//     sub-items of one 32-channel column tile, one per block (the 24 x 24 level: 3.3 instead of 4 rounds).
 //   * epilogue as in unet_s3.hip (wave-private 4 KB staging window in the finished half-chunk's halo buffer, 16-byte stores
 //     of whole 128-byte pixel-chunks, fused 2x2 max-pool on row pairs, saturation tracking).
+//   * which layers run here is conv_s3_takes_c4's decision (unet_s3.hip): by layer shape only, so that a slice's bits do not
+//     depend on the batch.  64-channel blocks (CT = 2) are built and tested but never picked: 24 MFMAs per barrier lose to
+//     conv_s3_kernel<64>.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -57,15 +62,14 @@ typedef __attribute__((address_space(3))) f16x8 lds_f16x8;
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
 constexpr int kMTile = 512;              // output positions per tile: 16 MFMA row-tiles of 32
-constexpr int kRT = 4, kCT = 4;          // 32-pixel row-tiles / 32-channel column tiles per wave
-constexpr int kBN = 128;                 // output channels per block
+constexpr int kRT = 4;                   // 32-pixel row-tiles per wave; the column tiles (32 channels each) are the template parameter CT:
+                                         // 4 = 128-channel blocks (256 accumulators), 2 = 64-channel blocks (Cout = 64 layers)
 constexpr int kPitch2D = 34;
 constexpr int kHalo2D = 18 * kPitch2D;   // 612 halo pixels of the 16 x 32 tile
 constexpr int kNJ = 39;                  // DMA instructions (16 pixels x 64 B) per halo buffer: 624 >= 612 (2D), >= 512 + 2 * 50 + 2 (flat)
 constexpr int kHBuf = kNJ * 1024;        // bytes per halo buffer
 constexpr int kHSlots = 10;              // halo pieces per wave (4 * 10 >= 39; the 40th repeats the wave's first)
-constexpr int kRing = 8;                 // weight ring slots
-constexpr int kSlot = 8192;              // [2 planes][128 rows][32 B]
+constexpr int kRing = 8;                 // weight ring slots of [2 planes][32 CT rows][32 B] = 2048 CT bytes
 constexpr int kAhead = 5;                // weights are requested this many steps ahead
 constexpr unsigned kPadOff = 0xFFF00000u;  // a voffset beyond num_records: the lane's 16 bytes arrive as zeros
 
@@ -95,6 +99,11 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *base) {
     return r;
 }
 
+// requests a wave issues in tap t: the step's weight pieces + two halo pieces in taps 0-4; the counted wait at the end of tap t
+// lets the requests of t, t - 1 and t - 2 (taps wrap: every half-chunk has the same pattern) stay in flight
+constexpr int c4_issued(int t, int w) { return w + (t <= 4 ? 2 : 0); }
+constexpr int c4_in_flight(int t, int w) { return c4_issued(t, w) + c4_issued((t + 8) % 9, w) + c4_issued((t + 7) % 9, w); }
+
 // decode a flat position of the zero-framed image stack: f = R * P + c, R = b * (H + 1) + y + 1, c = x + 1
 __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
     if (f < P) return -1;
@@ -106,23 +115,46 @@ __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
     return (b * H + y) * W + (c - 1);
 }
 
-// An accumulator element for the vector ALU: the tiles live in AccVGPRs (256 of them per lane), VALU instructions cannot
-// read those, and left to itself hipcc gives the 16-register tuples an ArchVGPR class as soon as plain code touches their
-// elements (343 spilled registers).  The explicit read keeps them where the MFMAs leave them.
-__device__ __forceinline__ float acc_get(const float &a) {
-    float v;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-    return v;
+// v - float(hi) for the two halves of a packed fp16 pair, one instruction each (v_fma_mix_f32: v * 1.0 - hi, a single rounding
+// like the subtraction it replaces; hipcc emits v_cvt_f32_f16 + v_sub_f32)
+__device__ __forceinline__ float sub_hi0(float v, unsigned hpair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpair));
+    return r;
+}
+__device__ __forceinline__ float sub_hi1(float v, unsigned hpair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpair));
+    return r;
+}
+// split four fp32 values into fp16 hi parts (round toward zero, saturating) and lo = rtz(v - hi): 2 x (hi pair, lo pair)
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 &hi, uint2 &lo) {
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+    const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(sub_hi0(v[0], h0), sub_hi1(v[1], h0));
+    const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(sub_hi0(v[2], h1), sub_hi1(v[3], h1));
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
+template <int CT>
 struct Frags {
-    f16x8 ah[kRT], al[kRT], bh[kCT], bl[kCT];
+    f16x8 ah[kRT], al[kRT], bh[CT], bl[CT];
 };
 
 }  // namespace
 
-template <bool FLAT>
+#ifdef QMRI_C4_EXPERIMENTS  // timing experiments (results wrong by construction): QMRI_C4_DBG = 1 no epilogue | 2 halo sources computed once | 4 no MFMAs | 8 no LDS reads | 16 no DMA requests
+#define C4_DBG(bit) (A.dbg & (bit))
+#else
+#define C4_DBG(bit) 0
+#endif
+
+template <bool FLAT, int CT>
 __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A) {
+    constexpr int kCT = CT, kBN = 32 * CT, kSlot = 2048 * CT;
+    constexpr int kWPieces = kSlot / (kWaves * 1024);  // weight DMA instructions per wave and step: 2 (CT = 4) or 1 (CT = 2)
+    using Frags = Frags<CT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *halo = smem;                                        // [2][kNJ * 16 pixels][64 B swizzled]
     unsigned char *ring = smem + 2 * kHBuf;                            // [kRing][2 planes][128][32 B swizzled]
@@ -143,18 +175,36 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     const i32x4 wr = make_rsrc(A.w_c4);
     const unsigned halo_lds = lds_off(halo), ring_lds = lds_off(ring);
 
-    // ---- work distribution: as conv_s3_kernel (XCD x walks a contiguous eighth of the work items) ----
-    int wstride = gridDim.x, w_end = A.nwork;
-    int work = blockIdx.x;
+    // ---- work distribution ----
+    // XCD x (= blockIdx % 8, observed; speed only) walks a contiguous eighth of the work items, its blocks striding through it
+    // (neighbouring tiles and one channel block's weights stay in one L2) -- as conv_s3_kernel.  New here: THE LAST, PARTIAL
+    // ROUND IS SPLIT BY CHANNELS.  Items are big (512 positions x 128 channels) and a range of n items over nblk blocks takes
+    // ceil(n / nblk) rounds: the 24 x 24 level (816 items on 256 CUs) would run 4 rounds for 3.19 rounds of work.  When the
+    // leftover L = n mod nblk satisfies CT * L <= nblk, each leftover item becomes CT sub-items of one 32-channel column tile
+    // (same tile, same halo, same weight slots -- only the column tile differs), one per block: a quarter-length last round.
+    int lo = 0, hi = A.nwork, lb = blockIdx.x, nblk = gridDim.x;
     if ((gridDim.x & 7) == 0 && A.nwork >= 64) {
         const int per_xcd = (A.nwork + 7) >> 3;
         const int xcd = blockIdx.x & 7;
-        wstride = gridDim.x >> 3;
-        work = xcd * per_xcd + (blockIdx.x >> 3);
-        w_end = (xcd + 1) * per_xcd < A.nwork ? (xcd + 1) * per_xcd : A.nwork;
+        lo = xcd * per_xcd;
+        hi = lo + per_xcd < A.nwork ? lo + per_xcd : A.nwork;
+        lb = blockIdx.x >> 3;
+        nblk = gridDim.x >> 3;
     }
-    const int nwork = w_end;
-    if (work >= nwork) return;
+    const int n_range = hi > lo ? hi - lo : 0;
+    const int r_full = n_range / nblk, l_over = n_range - r_full * nblk;
+    const bool split = A.c4_split && l_over > 0 && kCT * l_over <= nblk;
+    const int my_full = r_full + ((!split && lb < l_over) ? 1 : 0);       // whole items of this block
+    const bool has_sub = split && lb < kCT * l_over;                      // + one sub-item (its last)
+    const int my_items = my_full + (has_sub ? 1 : 0);
+    if (my_items == 0) return;
+    const int sub_cq = lb % kCT;                                          // the sub-item's column tile
+    // k-th item of this block -> work item index (a sub-item is its parent; past the end: the last one again -- requests made
+    // for it are never read)
+    auto item_at = [&](int k) -> int {
+        if (k >= my_items) k = my_items - 1;
+        return k < my_full ? lo + lb + k * nblk : lo + r_full * nblk + lb / kCT;
+    };
 
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
@@ -173,7 +223,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             f0 = 0;
         }
     };
-    decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
+    int cur = 0;  // ordinal of the item being computed
+    decode_work(item_at(0), t_nb, t_b, t_y0, t_x0, t_f0);
 
     // ---- halo requests: piece i of this wave is DMA instruction j = wave + 4 i (16 pixels x 64 B) of a halo buffer ----
     // lane -> halo pixel hp = 16 j + (lane >> 2), LDS position pos = lane & 3 holds piece c = pos ^ ((hp >> 2) & 3) = plane * 2 + g:
@@ -182,6 +233,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     // not ten registers: each value is used once per half-chunk, the register allocator spills such values to scratch, and a
     // scratch reload is a vector-memory load -- hipcc waits for it with vmcnt(0), i.e. for every DMA request in flight.
     auto set_halo_sources = [&](int b, int y0, int x0, int f0) {
+        int lane_h = lane;
+        asm volatile("" : "+v"(lane_h));  // (opaque: the per-piece pixel coordinates are otherwise computed before the main loop and spilled)
+        const int lane = lane_h;
 #pragma unroll
         for (int i = 0; i < kHSlots; ++i) {
             int j = wave + kWaves * i;
@@ -202,8 +256,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             hofft[i * kThreads + tid] = pix >= 0 ? (unsigned)pix * (unsigned)A.ldx * 4u + srcb : kPadOff;
         }
     };
-    // the half-chunk being requested: work item, half-chunk index hc = 2 chunk + half, destination buffer = hc & 1
-    int req_work = work, req_hc = 0;
+    // the half-chunk being requested: item ordinal, half-chunk index hc = 2 chunk + half, destination buffer = hc & 1
+    int req_k = 0, req_hc = 0;
     const int nhc = 2 * A.chunks;
     auto halo_soff = [&](int hc) -> unsigned { return (unsigned)(A.xoff * 4 + (hc >> 1) * 128 + (hc & 1) * 32); };
     auto issue_halo = [&](int i, int hc) {
@@ -212,31 +266,28 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         dma_buf16(hofft[i * kThreads + tid], xr, halo_soff(hc), halo_lds + (unsigned)((hc & 1) * kHBuf + j * 1024));
     };
 
-    // ---- weight requests: this wave's two 1 KB pieces (2 wave, 2 wave + 1) of the slot of step (w_nb, w_s) ----
-    // The request pointer runs kAhead steps ahead of the computation and therefore crosses into the NEXT work item's weights
-    // during the last steps of the current one: w_next = scalar offset of that work item's first slot, refreshed once per
-    // work item (past the end of the work: this item's own first slots again -- requested, never read).  No branch per step.
+    // ---- weight requests: this wave's share (kSlot / 4 bytes) of the slot of the step kAhead ahead ----
+    // The request pointer crosses into the NEXT item's weights during the last steps of the current one: w_next = scalar offset
+    // of that item's first slot, refreshed once per item.  No branch per step.  (A sub-item requests whole slots like everyone:
+    // the 6 KB it does not read are L2 hits of a last round.)
     const unsigned wlane = (unsigned)lane * 16u;
-    auto first_slot_of = [&](int nb) -> unsigned { return (unsigned)nb * (unsigned)wsteps * (unsigned)kSlot + (unsigned)wave * 2048u; };
-    unsigned w_so = first_slot_of(t_nb);   // scalar offset of the next slot to request (this wave's 2 KB of it)
+    auto first_slot_of = [&](int nb) -> unsigned { return (unsigned)nb * (unsigned)wsteps * (unsigned)kSlot + (unsigned)wave * (unsigned)(kSlot / kWaves); };
+    unsigned w_so = first_slot_of(t_nb);   // scalar offset of the next slot to request (this wave's share of it)
     unsigned w_next = w_so;
     int w_left = wsteps;                   // slots of the current stretch still to request
     int w_slot = 0;
     auto issue_weights = [&]() {
-        const unsigned dst = ring_lds + (unsigned)(w_slot * kSlot) + (unsigned)wave * 2048u;
+        const unsigned dst = ring_lds + (unsigned)(w_slot * kSlot) + (unsigned)wave * (unsigned)(kSlot / kWaves);
         dma_buf16(wlane, wr, w_so, dst);
-        dma_buf16(wlane, wr, w_so + 1024u, dst + 1024u);
+        if constexpr (kWPieces == 2) dma_buf16(wlane, wr, w_so + 1024u, dst + 1024u);
         w_slot = (w_slot + 1) & (kRing - 1);
         --w_left;
         const bool wrap = w_left == 0;
         w_so = wrap ? w_next : w_so + (unsigned)kSlot;
         w_left = wrap ? wsteps : w_left;
     };
-    auto refresh_w_next = [&](int cur_work, int cur_nb) {
-        const int nw = cur_work + wstride;
-        w_next = first_slot_of(nw < nwork ? nw / ntiles : cur_nb);
-    };
-    refresh_w_next(work, t_nb);
+    auto refresh_w_next = [&](int k) { w_next = first_slot_of(item_at(k + 1) / ntiles); };
+    refresh_w_next(0);
 
     // ---- per-lane LDS read offsets ----
     // B operand (pixels): row-tile i, tap t, plane 0: halo pixel hp = abase[i] + shift(t) (this lane's pixel of the row-tile),
@@ -259,11 +310,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             ao[i] = halo_lds + (unsigned)(hp * 64 + ((khalf ^ ((hp >> 2) & 3)) * 16));
         }
     };
-    // A operand (weights): column tile j, plane p: row n = 32 j + (lane & 31) -> j and p are immediates (1024 j + 4096 p)
+    // A operand (weights): column tile j, plane p: row n = 32 j + (lane & 31) -> j and p are immediates (1024 j + kSlot / 2 p);
+    // a sub-item reads its one column tile (sub_cq) into fragment 0
     const unsigned boff = ring_lds + (unsigned)((lane & 31) * 32 + ((khalf ^ (((lane & 31) >> 3) & 1)) * 16));
+    const unsigned boff_sub = boff + (unsigned)(sub_cq * 1024);
 
     auto lds16 = [](unsigned off) -> f16x8 { return *reinterpret_cast<const lds_f16x8 *>((size_t)off); };
-    auto load_frags = [&](Frags &f, int tap, int buf_imm, unsigned wb) {
+    auto load_frags = [&](Frags &f, int tap, int buf_imm, int slot_, auto sub) {
+        constexpr bool kSub = decltype(sub)::value;
         unsigned ao[kRT];
         a_offsets(ao, tap);
 #pragma unroll
@@ -271,25 +325,37 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             f.ah[i] = lds16(ao[i] + (unsigned)buf_imm);
             f.al[i] = lds16((ao[i] ^ 32u) + (unsigned)buf_imm);
         }
+        const unsigned wb = (kSub ? boff_sub : boff) + (unsigned)(slot_ * kSlot);
 #pragma unroll
-        for (int j = 0; j < kCT; ++j) {
+        for (int j = 0; j < (kSub ? 1 : kCT); ++j) {
             f.bh[j] = lds16(wb + (unsigned)(j * 1024));
-            f.bl[j] = lds16(wb + (unsigned)(j * 1024 + 4096));
+            f.bl[j] = lds16(wb + (unsigned)(j * 1024 + kSlot / 2));
         }
     };
 
     f32x16 acc[kRT][kCT];
+    // the 3 CT MFMAs of row-tile i: lo x hi, hi x lo, hi x hi over the column tiles (same accumulator every CT-th instruction).
     // `first`: the first k-step of a work item starts the accumulators from the MFMA's constant-zero C operand -- 256 registers
     // are never zeroed by hand (hipcc materialises the zeros in 256 ArchVGPRs first and spills everything else around them)
-    auto mma_row = [&](const Frags &f, int i, auto first) {
+    auto mma_row = [&](const Frags &f, int i, auto first, auto sub) {
         constexpr bool kFirst = decltype(first)::value;
+        constexpr int kJ = decltype(sub)::value ? 1 : kCT;
+        if (C4_DBG(4)) return;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < kCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], kFirst ? zero : acc[i][j], 0, 0, 0);
+        for (int j = 0; j < kJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], kFirst ? zero : acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < kCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < kJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < kCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < kJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+    };
+
+    auto load_prm = [&](int nb) {
+        for (int i = tid; i < 3 * kBN; i += kThreads) {
+            const int c = i % kBN, which = i / kBN;
+            const int n = nb * kBN + c;
+            prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
+        }
     };
 
     // ---- prologue: halo (chunk 0, half 0) of the first tile, weights of steps 0 .. kAhead - 1, epilogue parameters ----
@@ -299,256 +365,285 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     req_hc = 1;
 #pragma unroll
     for (int r = 0; r < kAhead; ++r) issue_weights();
-    for (int i = tid; i < 3 * kBN; i += kThreads) {
-        const int c = i % kBN, which = i / kBN;
-        const int n = t_nb * kBN + c;
-        prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
-    }
+    load_prm(t_nb);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     float amax = 0.f;
     int slot = 0;   // ring slot of the step being computed
     int chunk = 0;  // chunk being computed
     Frags f0, f1;
-    load_frags(f0, 0, 0, boff);  // operands of the very first step
+    using Full = std::false_type;
+    using Sub = std::true_type;
 
     // One step = one k-step of 16: (half H, tap T) of the current chunk.  CUR holds its operands; the operands of the next step
     // (half NH, tap NT: buffer NH, next ring slot) are read into NXT while it multiplies.  Requests: the weights of the step
-    // kAhead ahead (2 per wave), and in taps 0-4 two halo pieces of the half-chunk after this one.  The counted wait at the end
-    // lets the requests of this step and the two before it stay in flight (c(T) = 4, 4, 4, 4, 4, 2, 2, 2, 2 per tap).
+    // kAhead ahead, and in taps 0-4 two halo pieces of the half-chunk after this one.  The counted wait at the end lets the
+    // requests of this step and the two before it stay in flight (c4_in_flight).
 #define C4_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
-#define C4_STEP_(H, T, CUR, NXT, FIRST)                                                                                  \
+#define C4_STEP_(H, T, CUR, NXT, FIRST, SUB)                                                                       \
     {                                                                                                              \
         constexpr int NH_ = (T) == 8 ? 1 - (H) : (H);                                                              \
         constexpr int NT_ = (T) == 8 ? 0 : (T) + 1;                                                                \
-        const unsigned wbn_ = boff + (unsigned)(((slot + 1) & (kRing - 1)) * kSlot);                               \
-        load_frags(NXT, NT_, NH_ * kHBuf, wbn_);                                                             \
-        mma_row(CUR, 0, FIRST);                                                                                        \
-        issue_weights();                                                                                           \
-        mma_row(CUR, 1, FIRST);                                                                                        \
-        if constexpr ((T) <= 4) {                                                                                  \
+        /* (the last step of a work item reads nothing ahead: the epilogue does not need 64 live operand registers) */ \
+        if (!((H) == 1 && (T) == 8 && chunk + 1 == A.chunks) && !C4_DBG(8)) load_frags(NXT, NT_, NH_ * kHBuf, (slot + 1) & (kRing - 1), SUB{}); \
+        mma_row(CUR, 0, FIRST{}, SUB{});                                                                           \
+        if (!C4_DBG(16)) issue_weights();                                                                          \
+        mma_row(CUR, 1, FIRST{}, SUB{});                                                                           \
+        if constexpr ((T) <= 4) if (!C4_DBG(16)) {                                                                                \
             issue_halo(2 * (T), req_hc);                                                                           \
             issue_halo(2 * (T) + 1, req_hc);                                                                       \
         }                                                                                                          \
-        mma_row(CUR, 2, FIRST);                                                                                        \
-        mma_row(CUR, 3, FIRST);                                                                                        \
-        /* the step opens with an MFMA; the 16 reads ride two per MFMA behind the first eight */                    \
+        mma_row(CUR, 2, FIRST{}, SUB{});                                                                           \
+        mma_row(CUR, 3, FIRST{}, SUB{});                                                                           \
+        /* the step opens with an MFMA; the reads ride two per MFMA behind the first eight */                      \
         _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                     \
         }                                                                                                          \
-        constexpr int kN_ = (T) == 0 ? 8 : (T) == 1 ? 10 : (T) <= 4 ? 12 : (T) == 5 ? 10 : (T) == 6 ? 8 : 6;       \
+        constexpr int kN_ = c4_in_flight((T), kWPieces);                                                           \
         C4_WAIT(kN_);                                                                                              \
         slot = (slot + 1) & (kRing - 1);                                                                           \
     }
-#define C4_STEP(H, T, CUR, NXT) C4_STEP_(H, T, CUR, NXT, std::false_type{})
-#define C4_HALF(H)                \
-    if (chunk == 0)               \
-        C4_STEP_(H, 0, f0, f1, std::true_type{}) \
-    else                          \
-        C4_STEP(H, 0, f0, f1)     \
-    C4_STEP(H, 1, f1, f0)         \
-    C4_STEP(H, 2, f0, f1)         \
-    C4_STEP(H, 3, f1, f0)         \
-    C4_STEP(H, 4, f0, f1)         \
-    C4_STEP(H, 5, f1, f0)         \
-    C4_STEP(H, 6, f0, f1)         \
-    C4_STEP(H, 7, f1, f0)         \
-    C4_STEP(H, 8, f0, f1)
+#define C4_STEP(H, T, CUR, NXT, SUB) C4_STEP_(H, T, CUR, NXT, std::false_type, SUB)
+#define C4_HALF(H, SUB)                                 \
+    if (chunk == 0)                                     \
+        C4_STEP_(H, 0, f0, f1, std::true_type, SUB)     \
+    else                                                \
+        C4_STEP(H, 0, f0, f1, SUB)                      \
+    C4_STEP(H, 1, f1, f0, SUB)                          \
+    C4_STEP(H, 2, f0, f1, SUB)                          \
+    C4_STEP(H, 3, f1, f0, SUB)                          \
+    C4_STEP(H, 4, f0, f1, SUB)                          \
+    C4_STEP(H, 5, f1, f0, SUB)                          \
+    C4_STEP(H, 6, f0, f1, SUB)                          \
+    C4_STEP(H, 7, f1, f0, SUB)                          \
+    C4_STEP(H, 8, f0, f1, SUB)
     // (nine steps swap the roles of f0 / f1: the second half of a chunk runs with them exchanged)
-#define C4_HALF_X(H)              \
-    C4_STEP(H, 0, f1, f0)         \
-    C4_STEP(H, 1, f0, f1)         \
-    C4_STEP(H, 2, f1, f0)         \
-    C4_STEP(H, 3, f0, f1)         \
-    C4_STEP(H, 4, f1, f0)         \
-    C4_STEP(H, 5, f0, f1)         \
-    C4_STEP(H, 6, f1, f0)         \
-    C4_STEP(H, 7, f0, f1)         \
-    C4_STEP(H, 8, f1, f0)
+#define C4_HALF_X(H, SUB)                               \
+    C4_STEP(H, 0, f1, f0, SUB)                          \
+    C4_STEP(H, 1, f0, f1, SUB)                          \
+    C4_STEP(H, 2, f1, f0, SUB)                          \
+    C4_STEP(H, 3, f0, f1, SUB)                          \
+    C4_STEP(H, 4, f1, f0, SUB)                          \
+    C4_STEP(H, 5, f0, f1, SUB)                          \
+    C4_STEP(H, 6, f1, f0, SUB)                          \
+    C4_STEP(H, 7, f0, f1, SUB)                          \
+    C4_STEP(H, 8, f1, f0, SUB)
+    // all chunks of the current item.  Requests during half 0: (chunk, half 1) -> buffer 1; during half 1: (chunk + 1, half 0),
+    // or the next item's first half-chunk -> buffer 0 (its halo sources are computed when the request pointer gets there)
+#define C4_CHUNKS(SUB)                                                                                             \
+    for (chunk = 0; chunk < A.chunks; ++chunk) {                                                                   \
+        C4_HALF(0, SUB)                                                                                            \
+        ++req_hc;                                                                                                  \
+        if (req_hc == nhc) {                                                                                       \
+            req_hc = 0;                                                                                            \
+            ++req_k;                                                                                               \
+            int nb_, b_, y0_, x0_, f0_;                                                                            \
+            decode_work(item_at(req_k), nb_, b_, y0_, x0_, f0_);                                                   \
+            if (!C4_DBG(2)) set_halo_sources(b_, y0_, x0_, f0_);                                                   \
+        }                                                                                                          \
+        C4_HALF_X(1, SUB)                                                                                          \
+        ++req_hc;                                                                                                  \
+    }
 
-    while (true) {
-        // ---- one 32-channel chunk: half 0 (buffer 0), half 1 (buffer 1) ----
-        // requests during half 0: (chunk, half 1) -> buffer 1; during half 1: (chunk + 1, half 0) or the next tile's first -> buffer 0
-        C4_HALF(0)
-        ++req_hc;
-        if (req_hc == nhc) {  // the next request opens a new tile: where do its halo pixels come from
-            req_hc = 0;
-            req_work += wstride;
-            int nb_, b_, y0_, x0_, f0_;
-            decode_work(req_work < nwork ? req_work : work, nb_, b_, y0_, x0_, f0_);  // (past the end: this tile again, never read)
-            set_halo_sources(b_, y0_, x0_, f0_);
-        }
-        C4_HALF_X(1)
-        ++req_hc;
-        if (++chunk < A.chunks) continue;
-
-        // ======================= epilogue of this work item =======================
-        // staging: buffer 1 (the half-chunk that just finished; buffer 0 already holds the next tile's first), 4 KB per wave
-        {
-            unsigned char *stage = halo + kHBuf + wave * 4096;
-            if (FLAT) {
-                for (int i = tid; i < kMTile; i += kThreads) outpix[i] = flat_to_pix(t_f0 + i, P, A.H, A.W, A.B);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            auto out_pixel = [&](int i, int t) -> int {  // output pixel of this lane's store t of row-tile i (lane >> 3 = pixel of 8)
-                if (FLAT) return outpix[(wave * kRT + i) * 32 + t * 8 + (lane >> 3)];
-                const int yy = t_y0 + wave * kRT + i, xx = t_x0 + t * 8 + (lane >> 3);
-                if (yy >= A.H) return -1;
-                return (t_b * A.H + yy) * A.W + xx;
-            };
-            const float winv = A.winv;
-            struct Prm4 {
-                f32x4 b, s, t;
-            };
-            auto load_prm = [&](int j, int q) -> Prm4 {
-                Prm4 p;
-                const float *pp = prm + j * 32 + 8 * q + 4 * khalf;
-                p.b = *reinterpret_cast<const f32x4 *>(pp);
-                p.s = *reinterpret_cast<const f32x4 *>(pp + kBN);
-                p.t = *reinterpret_cast<const f32x4 *>(pp + 2 * kBN);
-                return p;
-            };
-            auto affine = [&](float a, const Prm4 &p, int r) -> float {
-                float v = fmaf(a, winv, p.b[r]);
-                if (A.relu) v = fmaxf(v, 0.f);
-                return fmaf(v, p.s[r], p.t[r]);
-            };
-            const int n0 = t_nb * kBN;
-            const int px_l = lane & 31;
-            auto stage_piece = [&](int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); };
-#pragma unroll
-            for (int j = 0; j < kCT; ++j) {
-                const int cbase = n0 + j * 32;
-#pragma unroll
-                for (int i = 0; i < kRT; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const Prm4 p = load_prm(j, q);
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = affine(acc_get(acc[i][j][4 * q + r]), p, r);
-                        amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-                        amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
-                        asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps all 256 values alive -- in scratch -- until then)
-                        const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                        const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
-                        const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
-                        *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, q) + 8 * khalf) =
-                            make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-                        *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, 4 + q) + 8 * khalf) =
-                            make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window swizzle)
-                    uint4 v[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int pix = out_pixel(i, t);
-                        const int p8 = (lane & 7) ^ (((t * 8 + (lane >> 3)) >> 1) & 7);
-                        if (pix >= 0) {
-                            const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
-                            nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is rewritten by the next tile)
-                    // one accumulator tile at a time: left alone the scheduler reads many tiles out of the AccVGPRs ahead of their
-                    // use (v_accvgpr_read has no memory dependence to hold it back) and spills the main loop's registers
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // ---- fused MaxPooling2D(2x2): row pairs (0, 1) and (2, 3) of this wave -> 16 pooled pixels x 32 channels each ----
-                if (!FLAT && A.pool_y) {
-#pragma unroll
-                    for (int pr = 0; pr < kRT / 2; ++pr) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const Prm4 p = load_prm(j, q);
-                            float m[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float vmax = fmaxf(affine(acc_get(acc[2 * pr][j][4 * q + r]), p, r), affine(acc_get(acc[2 * pr + 1][j][4 * q + r]), p, r));
-                                const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vmax), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
-                                m[r] = fmaxf(vmax, other);
-                            }
-                            const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(m[0], m[1]), h1 = __builtin_amdgcn_cvt_pkrtz(m[2], m[3]);
-                            const h16x2 l0 = __builtin_amdgcn_cvt_pkrtz(m[0] - (float)h0[0], m[1] - (float)h0[1]);
-                            const h16x2 l1 = __builtin_amdgcn_cvt_pkrtz(m[2] - (float)h1[0], m[3] - (float)h1[1]);
-                            if (!(px_l & 1)) {
-                                const int pp = (px_l >> 1) + 16 * pr;  // pooled column 0..15 of pair pr -> window pixel 0..31
-                                *reinterpret_cast<uint2 *>(stage + stage_piece(pp, q) + 8 * khalf) =
-                                    make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-                                *reinterpret_cast<uint2 *>(stage + stage_piece(pp, 4 + q) + 8 * khalf) =
-                                    make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const int Hp = A.H >> 1, Wp = A.W >> 1;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {  // 32 window pixels x 8 pieces = 256 stores of 16 bytes: four per lane
-                        const int id = t * 64 + lane, px = id >> 3, pos = id & 7;
-                        const int pr = px >> 4, pc = px & 15;
-                        const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
-                        if (yy < Hp) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pos * 16);
-                            const int p8 = pos ^ ((px >> 1) & 7);
-                            const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + pc;
-                            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + p8 * 16;
-                            nt_store16(dst, v);
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-        }
-        // ---- next work item ----
-        work += wstride;
-        if (work >= nwork) break;
-        const int prev_nb = t_nb;
-        decode_work(work, t_nb, t_b, t_y0, t_x0, t_f0);
-        refresh_w_next(work, t_nb);
-        chunk = 0;
-        // every wave is done with its staging window (the next half-chunk's DMA lands there) and with the parameters
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t_nb != prev_nb) {
-            for (int i = tid; i < 3 * kBN; i += kThreads) {
-                const int c = i % kBN, which = i / kBN;
-                const int n = t_nb * kBN + c;
-                prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
-            }
+    // ======================= epilogue of a work item =======================
+    // staging: buffer 1 (the half-chunk that just finished; buffer 0 already holds the next item's first), 4 KB per wave
+    auto epilogue = [&](auto sub) {
+        constexpr bool kSub = decltype(sub)::value;
+        // (the lane index is made opaque here: hipcc otherwise computes every per-lane address of the epilogue before the main
+        //  loop, cannot keep them in registers through it, and reloads them from scratch for every tile)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int lane = lane_e, khalf = lane_e >> 5;
+        unsigned char *stage = halo + kHBuf + wave * 4096;
+        if (FLAT) {
+            for (int i = tid; i < kMTile; i += kThreads) outpix[i] = flat_to_pix(t_f0 + i, P, A.H, A.W, A.B);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        load_frags(f0, 0, 0, boff + (unsigned)(slot * kSlot));  // operands of the new work item's first step (landed: see C4_STEP)
+        auto out_pixel = [&](int i, int t) -> int {  // output pixel of this lane's store t of row-tile i (lane >> 3 = pixel of 8)
+            if (FLAT) return outpix[(wave * kRT + i) * 32 + t * 8 + (lane >> 3)];
+            const int yy = t_y0 + wave * kRT + i, xx = t_x0 + t * 8 + (lane >> 3);
+            if (yy >= A.H) return -1;
+            return (t_b * A.H + yy) * A.W + xx;
+        };
+        const float winv = A.winv;
+        struct Prm4 {
+            f32x4 b, s, t;
+        };
+        auto load_prm4 = [&](int jc, int q) -> Prm4 {  // jc = column tile within the channel block
+            Prm4 p;
+            const float *pp = prm + jc * 32 + 8 * q + 4 * khalf;
+            p.b = *reinterpret_cast<const f32x4 *>(pp);
+            p.s = *reinterpret_cast<const f32x4 *>(pp + kBN);
+            p.t = *reinterpret_cast<const f32x4 *>(pp + 2 * kBN);
+            return p;
+        };
+        const float floor_ = A.relu ? 0.f : -__builtin_inff();  // ReLU as a lower bound: one v_max, no select on the flag
+        auto affine = [&](float a, const Prm4 &p, int r) -> float {
+            const float v = fmaxf(fmaf(a, winv, p.b[r]), floor_);
+            return fmaf(v, p.s[r], p.t[r]);
+        };
+        const int n0 = t_nb * kBN;
+        const int px_l = lane & 31;
+        auto stage_piece = [&](int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); };
+#pragma unroll
+        for (int j = 0; j < (kSub ? 1 : kCT); ++j) {
+            const int jc = kSub ? sub_cq : j;
+            const int cbase = n0 + jc * 32;
+#pragma unroll
+            for (int i = 0; i < kRT; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const Prm4 p = load_prm4(jc, q);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = affine(acc[i][j][4 * q + r], p, r);
+                    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+                    amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+                    asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps all 256 values alive -- in scratch -- until then)
+                    uint2 hi2, lo2;
+                    split4(v, hi2, lo2);
+                    *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, q) + 8 * khalf) = hi2;
+                    *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, 4 + q) + 8 * khalf) = lo2;
+                }
+                // (no wait between the window's writes and reads: a wave's LDS instructions execute in issue order; hipcc waits for the
+                //  read RESULTS before the stores, and the next tile's arithmetic overlaps this tile's LDS round trip)
+                // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window swizzle)
+                uint4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int pix = out_pixel(i, t);
+                    const int p8 = (lane & 7) ^ (((t * 8 + (lane >> 3)) >> 1) & 7);
+                    if (pix >= 0) {
+                        const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
+                        nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
+                    }
+                }
+            }
+            // ---- fused MaxPooling2D(2x2): row pairs (0, 1) and (2, 3) of this wave -> 16 pooled pixels x 32 channels each ----
+            if (!FLAT && A.pool_y) {
+#pragma unroll
+                for (int pr = 0; pr < kRT / 2; ++pr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const Prm4 p = load_prm4(jc, q);
+                        float m[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float vmax = fmaxf(affine(acc[2 * pr][j][4 * q + r], p, r), affine(acc[2 * pr + 1][j][4 * q + r], p, r));
+                            const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vmax), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
+                            m[r] = fmaxf(vmax, other);
+                        }
+                        uint2 hi2, lo2;
+                        split4(m, hi2, lo2);
+                        if (!(px_l & 1)) {
+                            const int pp = (px_l >> 1) + 16 * pr;  // pooled column 0..15 of pair pr -> window pixel 0..31
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, q) + 8 * khalf) = hi2;
+                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, 4 + q) + 8 * khalf) = lo2;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int Hp = A.H >> 1, Wp = A.W >> 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // 32 window pixels x 8 pieces = 256 stores of 16 bytes: four per lane
+                    const int id = t * 64 + lane, px = id >> 3, pos = id & 7;
+                    const int pr = px >> 4, pc = px & 15;
+                    const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
+                    if (yy < Hp) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pos * 16);
+                        const int p8 = pos ^ ((px >> 1) & 7);
+                        const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + pc;
+                        unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + p8 * 16;
+                        nt_store16(dst, v);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // between two items: geometry and epilogue parameters of the next one, and everyone done with the staging windows (the next
+    // half-chunk's DMA lands there).  Returns false after the block's last item.
+    auto next_item = [&]() -> bool {
+        if (++cur >= my_items) return false;
+        const int prev_nb = t_nb;
+        decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
+        refresh_w_next(cur);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t_nb != prev_nb) {
+            load_prm(t_nb);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return true;
+    };
+
+    bool more = true;
+    if (my_full > 0) {
+        load_frags(f0, 0, 0, slot, Full{});  // operands of the very first step
+        while (true) {
+            C4_CHUNKS(Full)
+            if (!C4_DBG(1)) epilogue(Full{});
+            more = next_item();
+            if (!more || cur >= my_full) break;
+            load_frags(f0, 0, 0, slot, Full{});  // operands of the new item's first step (landed: see C4_STEP_)
+        }
+    }
+    if (more && has_sub) {  // the block's last item: one 32-channel column tile of a leftover item
+        load_frags(f0, 0, 0, slot, Sub{});
+        C4_CHUNKS(Sub)
+        epilogue(Sub{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
     if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
-static size_t c4_lds_bytes() { return (size_t)2 * kHBuf + (size_t)kRing * kSlot + kMTile * 4 + (size_t)3 * kBN * 4 + (size_t)kHSlots * kThreads * 4; }
+static size_t c4_lds_bytes(int ct) { return (size_t)2 * kHBuf + (size_t)kRing * 2048 * ct + kMTile * 4 + (size_t)3 * 32 * ct * 4 + (size_t)kHSlots * kThreads * 4; }
 
 // which layers the kernel takes: >= 128 output channels in blocks of 128, 32-channel input chunks, a level it tiles
+int conv_c4_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
+
 bool conv_c4_supported(const ConvS3Args &k) {
     if (k.deconv || k.one || k.head_w) return false;
-    if (k.Cin % 32 || k.Cout % 128) return false;
+    if (k.Cin % 32 || k.Cout % 64) return false;
+    // 32-bit source offsets: pixel * ldx * 4 (+ the chunk's 128 bytes) must stay below the descriptor's num_records
+    if ((unsigned long long)k.B * k.H * k.W * (unsigned long long)k.ldx * 4ull >= (unsigned long long)kPadOff) return false;
     if (k.W % 32 == 0) return !k.pool_y || (!(k.H & 1) && !(k.W & 1));
     return k.W + 2 <= 50 && !k.pool_y;  // flattened zero-framed stack (halo: 512 + 2 (W + 2) + 2 <= 624 pixels)
 }
 
 // number of work items (channel blocks x tiles) of a layer on this kernel: the dispatcher's cost model wants it
 int conv_c4_work_items(const ConvS3Args &k) {
-    const int nb = k.Cout / kBN;
+    const int nb = k.Cout / conv_c4_block_channels(k.Cout);
     if (k.W % 32 == 0) return nb * k.B * (k.W / 32) * ((k.H + 15) / 16);
     const int P = k.W + 2;
     const long long span = (long long)k.B * (k.H + 1) * P - P;
     return nb * (int)((span + kMTile - 1) / kMTile);
 }
 
-template <bool FLAT>
+// Rounds a layer takes on this kernel with one persistent block per CU, in units of one whole item: the per-XCD ranges of
+// conv_c4_kernel's work distribution, a split last round counted as 0.3 (a quarter of the MFMAs at a lower issue rate).
+double conv_c4_rounds(const ConvS3Args &k, int num_cu) {
+    const int items = conv_c4_work_items(k);
+    const int grid = items < num_cu ? items : num_cu;
+    int n = items, nblk = grid;
+    if ((grid & 7) == 0 && items >= 64) {
+        n = (items + 7) >> 3;
+        nblk = grid >> 3;
+    }
+    const int ct = conv_c4_block_channels(k.Cout) / 32;
+    const int r = n / nblk, l = n - r * nblk;
+    static const bool split_on = !(std::getenv("QMRI_C4_SPLIT") && std::atoi(std::getenv("QMRI_C4_SPLIT")) == 0);
+    if (l == 0) return r;
+    return r + ((split_on && ct * l <= nblk) ? 0.3 : 1.0);
+}
+
+template <bool FLAT, int CT>
 static hipError_t c4_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
-    auto fn = conv_c4_kernel<FLAT>;
-    const size_t lds = c4_lds_bytes();
+    auto fn = conv_c4_kernel<FLAT, CT>;
+    const size_t lds = c4_lds_bytes(CT);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int grid = k.nwork < num_cu ? k.nwork : num_cu;
@@ -562,7 +657,8 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     const bool flat = k.W % 32 != 0;
     k.chunks = k.Cin / 32;
     k.steps = k.chunks * 18;
-    k.nb = k.Cout / kBN;
+    const int bn = conv_c4_block_channels(k.Cout);
+    k.nb = k.Cout / bn;
     if (flat) {
         k.P = k.W + 2;
         const long long span = (long long)k.B * (k.H + 1) * k.P - k.P;
@@ -576,11 +672,19 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     }
     k.nj = kNJ;
     k.nwork = k.nb * k.ntiles;
-    // 32-bit source offsets: pixel * ldx * 4 + 128 must stay below the descriptor's num_records
-    const unsigned long long span_bytes = (unsigned long long)k.B * k.H * k.W * (unsigned long long)k.ldx * 4ull;
-    if (span_bytes >= (unsigned long long)kPadOff) return hipErrorInvalidValue;
+    static const int split = [] {
+        const char *e = std::getenv("QMRI_C4_SPLIT");
+        return e ? std::atoi(e) : 1;
+    }();
+    k.c4_split = split;
+    static const int dbg = [] {
+        const char *e = std::getenv("QMRI_C4_DBG");
+        return e ? std::atoi(e) : 0;
+    }();
+    k.dbg = dbg;
     (void)hipGetLastError();
-    return flat ? c4_launch_t<true>(k, num_cu, stream) : c4_launch_t<false>(k, num_cu, stream);
+    if (bn == 128) return flat ? c4_launch_t<true, 4>(k, num_cu, stream) : c4_launch_t<false, 4>(k, num_cu, stream);
+    return flat ? c4_launch_t<true, 2>(k, num_cu, stream) : c4_launch_t<false, 2>(k, num_cu, stream);
 }
 
 }  // namespace qmri

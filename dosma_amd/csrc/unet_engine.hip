@@ -143,21 +143,22 @@ struct ConvLayer {
                         }
         e = w_s3.alloc(img.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
-        if (e != hipSuccess || deconv || Cout % 128 || ntaps != 9) return e;
-        // conv_c4_kernel: [nb][chunk][half][tap] slots of [plane][128 rows][2 positions x 8 halfs]
+        if (e != hipSuccess || deconv || Cout % 64 || ntaps != 9) return e;
+        // conv_c4_kernel: [nb][chunk][half][tap] slots of [plane][B4 rows][2 positions x 8 halfs], B4 = 128 or 64 channels per block
         const int chunks = Cin / 32;
+        const int B4 = qmri::conv_c4_block_channels(Cout);
         std::vector<unsigned short> im4((size_t)Cout * K * 2);
-        for (int nb = 0; nb < Cout / 128; ++nb)
+        for (int nb = 0; nb < Cout / B4; ++nb)
             for (int ch = 0; ch < chunks; ++ch)
                 for (int half = 0; half < 2; ++half)
                     for (int tap = 0; tap < 9; ++tap) {
-                        const size_t slot = ((((size_t)nb * chunks + ch) * 2 + half) * 9 + tap) * 4096;
+                        const size_t slot = ((((size_t)nb * chunks + ch) * 2 + half) * 9 + tap) * (size_t)(B4 * 32);
                         for (int plane = 0; plane < 2; ++plane)
-                            for (int r = 0; r < 128; ++r)
+                            for (int r = 0; r < B4; ++r)
                                 for (int g = 0; g < 2; ++g) {
                                     const int pos = g ^ ((r >> 3) & 1);
-                                    const size_t src = (size_t)(nb * 128 + r) * K + ((size_t)ch * 9 + tap) * 32 + half * 16 + g * 8;
-                                    const size_t dst = slot + (size_t)plane * 2048 + (size_t)r * 16 + pos * 8;
+                                    const size_t src = (size_t)(nb * B4 + r) * K + ((size_t)ch * 9 + tap) * 32 + half * 16 + g * 8;
+                                    const size_t dst = slot + (size_t)plane * (B4 * 16) + (size_t)r * 16 + pos * 8;
                                     const unsigned short *from = (plane ? lo.data() : hi.data()) + src;
                                     for (int k = 0; k < 8; ++k) im4[dst + k] = from[k];
                                 }
@@ -675,7 +676,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         const bool c4 = qmri::conv_s3_takes_c4(k, U->num_cu);  // (the launcher's own choice: one wave per SIMD, 128 x 128 register tiles)
         U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
         if (c4)
-            snprintf(buf, sizeof(buf), "%s:s3/%s/c4%s;", name, flat ? "flat" : "2d", fuse_pool ? "+pool" : "");
+            snprintf(buf, sizeof(buf), "%s:s3/%s/c4x%d%s;", name, flat ? "flat" : "2d", qmri::conv_c4_block_channels(L.Cout), fuse_pool ? "+pool" : "");
         else
             snprintf(buf, sizeof(buf), "%s:s3/%s/bn%d%s%s;", name, flat ? "flat" : "2d", bn, fuse_pool ? "+pool" : "", fuse_head ? "+head" : "");
         U->trace += buf;

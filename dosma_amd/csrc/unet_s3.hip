@@ -53,7 +53,6 @@ constexpr int kMTile = 256;        // output positions per tile: 8 MFMA row-tile
 constexpr int kPitch2D = 34;       // halo row pitch of the 8 x 32 tile
 constexpr int kHalo2D = 10 * kPitch2D;
 constexpr int kRing = 4;           // weight ring slots
-constexpr double kC4Gain = 1.10;   // conv_c4_kernel's MFMA issue rate over conv_s3_kernel<128>'s at equal work (measured: DESIGN 6.4)
 
 // LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16 (M0), global source per lane.
 // Issued through inline asm so that hipcc neither counts it (it would drain vmcnt(0) before every ds_read it cannot
@@ -896,19 +895,19 @@ bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     if (!k.w_c4 || k.c4_mode < 0 || !conv_c4_supported(k)) return false;
     if (k.c4_mode > 0 || mode >= 2) return true;
     if (mode <= 0) return false;
+    // 64-channel blocks: a step is only 24 MFMAs per wave between barriers -- measured 5-10 % SLOWER than conv_s3_kernel<64> on every
+    // 192 x 192 layer of the network (824 / 1407 / 2240 / 1310 us against 742 / 1286 / 2195 / 1221): kept for tests, never picked
+    if (conv_c4_block_channels(k.Cout) != 128) return false;
+    // The choice depends on the LAYER only (level geometry and channel counts), never on the batch: the two kernels add the same
+    // products in different orders (tap-major against half-chunk-major), and a slice's logits must not depend on how many slices
+    // travel with it (tests/test_unet_fullsize_gpu.py::test_forward_is_bitwise_repeatable runs one volume through engines of two
+    // batch sizes).  Per-layer A/B at 160 slices of 384 x 384 (profiles/r04_c4_ab.txt): on the flattened levels conv_c4_kernel ties
+    // at 4 input chunks and wins 6-10 % from 8; on 16 x 32 image tiles it loses up to 8 chunks (its per-item fixed costs -- the
+    // epilogue of 16 tiles on ONE wave per SIMD, halo set-up -- weigh more there) and ties at 8.
     const bool flat = k.W % 32 != 0;
-    long long items_s3;
-    if (flat) {
-        const int P = k.W + 2;
-        items_s3 = ((long long)k.B * (k.H + 1) * P - P + kMTile - 1) / kMTile;
-    } else {
-        items_s3 = (long long)k.B * (k.W / 32) * ((k.H + 7) / 8);
-    }
-    items_s3 *= k.Cout / 128;
-    const long long items_c4 = conv_c4_work_items(k);
-    const double t_s3 = (double)((items_s3 + num_cu - 1) / num_cu);             // in units of one conv_s3 item
-    const double t_c4 = (double)((items_c4 + num_cu - 1) / num_cu) * 2.0 / kC4Gain;
-    return t_c4 < t_s3;
+    const int chunks = k.Cin / 32;
+    (void)num_cu;
+    return flat ? chunks >= 8 : chunks >= 16;
 }
 
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {

@@ -73,7 +73,8 @@ def test_384_logits_parity_mode(net, ref384, max_batch):
     _expect_families(tr, 384, 384)
     fams = {t.split(":", 1)[1].split("+")[0] for t in tr if t.startswith(("down", "up")) and "conv" in t and "deconv" not in t}
     # the >= 128-channel layers run on conv_s3_kernel<128> ("bn128") or conv_c4_kernel ("c4"), per layer by the launcher's cost model
-    assert {"mid0", "out0", "s3/2d/bn64"} <= fams and fams & {"s3/2d/bn128", "s3/2d/c4"} and fams & {"s3/flat/bn128", "s3/flat/c4"}, fams
+    assert {"mid0", "out0"} <= fams and fams & {"s3/2d/bn64", "s3/2d/c4x64"} and fams & {"s3/2d/bn128", "s3/2d/c4x128"} \
+        and fams & {"s3/flat/bn128", "s3/flat/c4x128"}, fams
     eng.close()
 
 

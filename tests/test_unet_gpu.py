@@ -82,6 +82,9 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     (64, 256, (24, 24), 3),     # flattened, tiles straddle images
     (256, 128, (12, 12), 7),    # flattened 12 x 12 (the 384-pixel network's deepest level), 8 chunks
     (128, 384, (5, 6), 2),      # flattened, less than one tile, three channel blocks
+    (32, 64, (32, 64), 3),      # 64-channel blocks (CT = 2): one chunk
+    (128, 64, (16, 32), 4),     # 64-channel block, four chunks
+    (64, 192, (30, 46), 2),     # 64-channel blocks x 3, flattened
 ])
 def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     """conv_c4_kernel (one wave per SIMD, 128 x 128 register tiles; unet_c4.hip) forced on, against the fp64 convolution

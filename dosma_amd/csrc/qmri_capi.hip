@@ -794,8 +794,9 @@ static int lmfit_validate(const qmri_lmfit_args *a) {
     if (dtype_size(a->y_dtype) == 0) return fail(QMRI_ERR_ARG, "unknown y_dtype %d", a->y_dtype);
     if (a->E < np)  // scipy: "The number of func parameters must not exceed the number of data points"
         return fail(QMRI_ERR_ARG, "E=%d: need at least as many samples as parameters (%d)", a->E, np);
-    if (a->E > QMRI_MAX_ECHOES)
-        return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds QMRI_MAX_ECHOES=%d", a->E, QMRI_MAX_ECHOES);
+    if (a->E > QMRI_LM_MAX_ECHOES || (np + 3) * a->E > 320)  // the kernel's lane-private columns: (n + 3) * E * 512 B of LDS <= 160 KB
+        return fail(QMRI_ERR_UNSUPPORTED, "E=%d exceeds what the general kernel holds for %d parameters (E <= %d)", a->E, np,
+                    320 / (np + 3) < QMRI_LM_MAX_ECHOES ? 320 / (np + 3) : QMRI_LM_MAX_ECHOES);
     if (a->N < 0 || a->ld < a->N) return fail(QMRI_ERR_ARG, "need 0 <= N <= ld");
     if (a->maxfev <= 0 || !(a->ftol >= 0) || !(a->xtol >= 0) || !(a->gtol >= 0) || !(a->factor > 0))
         return fail(QMRI_ERR_ARG, "maxfev > 0, ftol/xtol/gtol >= 0 and factor > 0 are required");

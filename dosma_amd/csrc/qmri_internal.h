@@ -104,7 +104,7 @@ struct LmKArgs {
     signed char *info;
     short *nfev;
     int *nonfinite;
-    double x[QMRI_MAX_ECHOES];
+    double x[QMRI_LM_MAX_ECHOES];
 };
 int lm_generic_nparams(int model);
 // counter: one zeroed 8-byte device word per launch (E <= 12: the pulling kernel), or nullptr (general-E kernel)

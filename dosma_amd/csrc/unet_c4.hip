@@ -25,11 +25,11 @@
 //     runs per pixel.  LDS image: pixel p at p * 64, piece c = plane * 2 + kgroup at position c ^ ((p >> 2) & 3): every
 //     ds_read_b128 lane group is conflict-free at any tap shift (brute-forced: scripts/lds_bank_check.py).
 //   * weights: ring of 8 slots of 8 KB ([plane][128 channels][2 x 16 B], piece g of row n at position g ^ ((n >> 3) & 1)),
-//     requested FIVE steps ahead; halo pieces of the next half-chunk are requested during taps 0-4.  All by LDS-DMA through
+//     requested SIX steps ahead; halo pieces of the next half-chunk are requested during taps 0-3.  All by LDS-DMA through
 //     buffer_load_dwordx4 ... lds: the address is an SGPR descriptor + a per-lane 32-bit offset + a scalar offset, so a
 //     request costs no vector ALU, and a lane outside the image reads beyond num_records = ZERO (the SAME padding; no zero
-//     line, no select; scripts/probes/buffer_lds.hip).  Waits are counted (s_waitcnt vmcnt(N): everything issued three or
-//     more steps ago has landed), one s_barrier per step of 48 MFMAs per wave.
+//     line, no select; scripts/probes/buffer_lds.hip).  Waits are counted (s_waitcnt vmcnt(N): everything issued two or
+//     more steps ago has landed), one s_barrier per THREE steps = 144 MFMAs per wave (the ring protocol: see kBarEvery).
 //   * the operand fragments of step s + 1 are read while step s multiplies (two register sets); the second halo buffer is an
 //     immediate offset; the first k-step of an item starts from the MFMA's constant-zero C operand (no zeroing pass).
 //   * work items are big, so the last, partial round of a launch is split by CHANNELS: each leftover item becomes four
@@ -70,7 +70,19 @@ constexpr int kNJ = 39;                  // DMA instructions (16 pixels x 64 B) 
 constexpr int kHBuf = kNJ * 1024;        // bytes per halo buffer
 constexpr int kHSlots = 10;              // halo pieces per wave (4 * 10 >= 39; the 40th repeats the wave's first)
 constexpr int kRing = 8;                 // weight ring slots of [2 planes][32 CT rows][32 B] = 2048 CT bytes
-constexpr int kAhead = 5;                // weights are requested this many steps ahead
+// One s_barrier per kBarEvery steps.  What the ring allows: the operands of step u are read during step u - 1, i.e. after the last
+// barrier at or before step u - 2; a wave's counted wait in front of a barrier covers everything it issued kInFlight or more steps
+// earlier, so slots must be requested kAhead >= kBarEvery + kInFlight + 1 steps ahead, and a slot is only rewritten after a barrier
+// that follows its last read: kRing >= kAhead + kBarEvery - 1.  Measured on the nine c4 layers of the 384 x 384 network, same box,
+// alternating (profiles/r04_c4_ab.txt): every step 10.84 ms, every 2nd 10.72, every 3rd (taps 2, 5, 8 of a half-chunk) 10.68.
+#if defined(QMRI_C4_BAR1)                // (A/B switches)
+constexpr int kBarEvery = 1, kInFlight = 3, kAhead = 5;
+#elif defined(QMRI_C4_BAR2)
+constexpr int kBarEvery = 2, kInFlight = 3, kAhead = 6;
+#else
+constexpr int kBarEvery = 3, kInFlight = 2, kAhead = 6;  // weights are requested kAhead steps ahead
+#endif
+static_assert(kAhead >= kBarEvery + kInFlight + 1 && 8 >= kAhead + kBarEvery - 1, "ring protocol");
 constexpr unsigned kPadOff = 0xFFF00000u;  // a voffset beyond num_records: the lane's 16 bytes arrive as zeros
 
 __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)(lds_void *)p; }
@@ -99,10 +111,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *base) {
     return r;
 }
 
-// requests a wave issues in tap t: the step's weight pieces + two halo pieces in taps 0-4; the counted wait at the end of tap t
-// lets the requests of t, t - 1 and t - 2 (taps wrap: every half-chunk has the same pattern) stay in flight
-constexpr int c4_issued(int t, int w) { return w + (t <= 4 ? 2 : 0); }
-constexpr int c4_in_flight(int t, int w) { return c4_issued(t, w) + c4_issued((t + 8) % 9, w) + c4_issued((t + 7) % 9, w); }
+// requests a wave issues in tap t: the step's weight pieces + the halo pieces of c4_halo_pieces(t); the counted wait at the end of
+// tap t lets the requests of the last kInFlight steps (taps wrap: every half-chunk has the same pattern) stay in flight
+constexpr int c4_halo_pieces(int t) { return kBarEvery == 1 ? (t <= 4 ? 2 : 0) : (t <= 1 ? 3 : t <= 3 ? 2 : 0); }
+constexpr int c4_halo_first(int t) { return kBarEvery == 1 ? 2 * t : (t <= 1 ? 3 * t : 6 + 2 * (t - 2)); }
+constexpr int c4_issued(int t, int w) { return w + c4_halo_pieces(t); }
+constexpr int c4_in_flight(int t, int w) {
+    return c4_issued(t, w) + c4_issued((t + 8) % 9, w) + (kInFlight == 2 ? 0 : c4_issued((t + 7) % 9, w));
+}
 
 // decode a flat position of the zero-framed image stack: f = R * P + c, R = b * (H + 1) + y + 1, c = x + 1
 __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
 
     // One step = one k-step of 16: (half H, tap T) of the current chunk.  CUR holds its operands; the operands of the next step
     // (half NH, tap NT: buffer NH, next ring slot) are read into NXT while it multiplies.  Requests: the weights of the step
-    // kAhead ahead, and in taps 0-4 two halo pieces of the half-chunk after this one.  The counted wait at the end lets the
+    // kAhead ahead, and in the first taps the halo pieces of the half-chunk after this one.  The counted wait at the end lets the
     // requests of this step and the two before it stay in flight (c4_in_flight).
 #define C4_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 #define C4_STEP_(H, T, CUR, NXT, FIRST, SUB)                                                                       \
@@ -389,9 +405,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         mma_row(CUR, 0, FIRST{}, SUB{});                                                                           \
         if (!C4_DBG(16)) issue_weights();                                                                          \
         mma_row(CUR, 1, FIRST{}, SUB{});                                                                           \
-        if constexpr ((T) <= 4) if (!C4_DBG(16)) {                                                                                \
-            issue_halo(2 * (T), req_hc);                                                                           \
-            issue_halo(2 * (T) + 1, req_hc);                                                                       \
+        if constexpr (c4_halo_pieces(T) > 0) if (!C4_DBG(16)) {                                                    \
+            _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) issue_halo(c4_halo_first(T) + hp_, req_hc); \
         }                                                                                                          \
         mma_row(CUR, 2, FIRST{}, SUB{});                                                                           \
         mma_row(CUR, 3, FIRST{}, SUB{});                                                                           \
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                     \
         }                                                                                                          \
         constexpr int kN_ = c4_in_flight((T), kWPieces);                                                           \
-        C4_WAIT(kN_);                                                                                              \
+        if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) C4_WAIT(kN_); \
         slot = (slot + 1) & (kRing - 1);                                                                           \
     }
 #define C4_STEP(H, T, CUR, NXT, SUB) C4_STEP_(H, T, CUR, NXT, std::false_type, SUB)

@@ -210,7 +210,9 @@ def curve_fit(
     if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
         warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
 
-    if model != "monoexponential":  # general lmdif kernel (lm_generic.hip)
+    # general lmdif kernel (lm_generic.hip): the bi-exponential, and the mono-exponential beyond the 32 samples per voxel its own
+    # kernel keeps in registers (the reference has no limit: fitting.py:755-870)
+    if model != "monoexponential" or x.reshape(-1).shape[0] > _lib.MAX_ECHOES:
         if x.reshape(-1).shape[0] < len(param_args):
             raise TypeError("The number of func parameters must not exceed the number of data points")  # scipy
         out = _lib.lmfit_host(model, x.astype(np.float64).reshape(-1), _as_kernel_samples(y), p0,
@@ -608,6 +610,10 @@ class CurveFitter(_Fitter):
 
         if model != "monoexponential":
             return self._fit_general(model, x, y, svs, mask_flat, p0, copy_headers, solver)
+        if len(svs) > _lib.MAX_ECHOES:
+            # more samples per voxel than the mono-exponential kernel keeps in registers: the general lmdif kernel (true
+            # forward differences, lane-private LDS columns; up to 64 samples), everything around it as the reference does it
+            return self._fit_many_samples(x, y, svs, mask, mask_flat, p0, copy_headers, solver, _decimals, _tc_only)
 
         post = self._fusable_post()
         if post is not None and _decimals is not None:
@@ -640,6 +646,26 @@ class CurveFitter(_Fitter):
         if "tc" in out:
             self._last_tc = out["tc"]
         return popt_mv, r2_mv
+
+    def _fit_many_samples(self, x, y, rows, mask, mask_flat, p0, copy_headers, solver, decimals, tc_only):
+        if getattr(self, "_loglin_init", False):
+            # tc0 = "polyfit" exactly as the reference builds it (:701-718): degree-1 PolyFitter on log(y + eps * (y == 0)),
+            # p0 = (exp(intercept), slope) per voxel
+            vols = [sv.astype(np.float32) if np.issubdtype(sv.dtype, np.integer) else sv for sv in y]
+            vols = [np.log(sv + 1e-10 * (sv == 0)) for sv in vols]
+            params, _ = PolyFitter(1, r2_threshold=0, num_workers=None, nan_to_num=0.0).fit(x, vols, mask=mask, copy_headers=False)
+            pv = params.volume.reshape(-1, 2)
+            p0 = [np.ascontiguousarray(np.exp(pv[:, 1]), dtype=np.float64), np.ascontiguousarray(pv[:, 0], dtype=np.float64)]
+        svs = np.stack([np.asarray(r) for r in rows], axis=0)
+        popt, r2 = self._fit_general("monoexponential", x, y, svs, mask_flat, p0, copy_headers, solver)
+        if not tc_only:
+            return popt, r2
+        tc = popt.volume[..., 1]
+        if decimals is not None:
+            tc = np.around(tc, decimals)
+        headers = deepcopy(y[0].headers()) if (copy_headers and y[0].headers() is not None) else None
+        return (y[0]._partial_clone(volume=np.ascontiguousarray(tc), headers=headers),
+                y[0]._partial_clone(volume=r2.volume, headers=True if headers is not None else None))
 
     def _fit_general(self, model, x, y, svs, mask_flat, p0, copy_headers, solver):
         """Models on the general lmdif kernel (bi-exponential): gather the masked columns like the

@@ -31,6 +31,11 @@ extern "C" {
 
 #define QMRI_VERSION 100 /* 0.1.0 */
 #define QMRI_MAX_ECHOES 32
+/* qmri_lmfit_*: samples per voxel of the general lmdif kernel.  Its per-lane columns ((n + 3) E doubles) live in LDS:
+ * (n + 3) * E * 512 B <= 160 KB, i.e. E <= 64 for the 2-parameter mono-exponential, E <= 45 for the bi-exponential.  The
+ * mono-exponential entry (qmri_monoexp_fit_*) keeps its samples in registers: E <= QMRI_MAX_ECHOES; beyond that the
+ * Python mirror routes CurveFitter / MonoExponentialFit through qmri_lmfit_* (the reference has no limit, fitting.py:755-870). */
+#define QMRI_LM_MAX_ECHOES 64
 
 typedef enum qmri_status {
     QMRI_OK = 0,
@@ -227,7 +232,7 @@ typedef struct qmri_lmfit_args {
     int32_t model;       /* qmri_model */
     int32_t y_dtype;     /* qmri_dtype */
     const void *y;       /* [E][ld] echo-major */
-    int32_t E;           /* n <= E <= QMRI_MAX_ECHOES */
+    int32_t E;           /* n <= E <= QMRI_LM_MAX_ECHOES and (n + 3) * E <= 320 (LDS) */
     int32_t maxfev;      /* 100 */
     int64_t N;
     int64_t ld;

@@ -288,7 +288,7 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         L.monoexp_fit_host(x[:1], y[:1])  # fewer samples than parameters
     with pytest.raises(NotImplementedError):
-        L.monoexp_fit_host(np.arange(40.0), np.ones((40, 10), dtype=np.float32))  # > QMRI_MAX_ECHOES
+        L.monoexp_fit_host(np.arange(40.0), np.ones((40, 10), dtype=np.float32))  # > QMRI_MAX_ECHOES of THIS entry (the API routes such fits to qmri_lmfit_*: tests/test_lmfit_gpu.py)
     with pytest.raises(ValueError):
         L.monoexp_fit_host(x, y.astype(np.int32))  # dtype the kernel does not read
     out = L.monoexp_fit_host(x, np.zeros((4, 0), dtype=np.float32))  # empty input

@@ -110,7 +110,10 @@ def test_lmfit_edges():
 
 @pytest.mark.parametrize("model,E", [("biexponential", 5), ("biexponential", 8), ("biexponential", 10),
                                      ("biexponential", 12), ("biexponential", 16),
-                                     ("monoexponential", 3), ("monoexponential", 8), ("monoexponential", 11)])
+                                     ("monoexponential", 3), ("monoexponential", 8), ("monoexponential", 11),
+                                     # beyond the 32 samples of the register-resident kernels: the general-E
+                                     # kernel holds (n + 3) E doubles per lane in LDS -- 64 samples for 2 parameters, 45 for 4
+                                     ("monoexponential", 40), ("monoexponential", 64), ("biexponential", 40)])
 def test_every_echo_count_variant_vs_oracle(relerr, model, E):
     """The pulling kernel is instantiated per echo-count class (E = 8 and E = 12 unrolled exactly, E < 8 and 8 < E < 12
     with guards) and E > 12 runs the general-E kernel: each against the C restatement of lmdif (oracle/minpack_oracle.c),
@@ -138,3 +141,37 @@ def test_every_echo_count_variant_vs_oracle(relerr, model, E):
     assert (d < RTOL).mean() > (0.99 if model == "biexponential" else 0.9999), f"{(d >= RTOL).sum()} of {both.sum()}"
     assert (o["nfev"][both] == nfev[both]).mean() > (0.95 if model == "biexponential" else 0.999)
     assert np.abs(o["r2"][both] - r2[both])[d < RTOL].max() < 1e-6
+
+
+def test_more_than_32_samples_through_the_api(relerr):
+    """The reference has no limit on the samples per voxel (/root/reference/dosma/core/fitting.py:755-870).  Beyond the 32 the
+    mono-exponential kernel keeps in registers, curve_fit / CurveFitter / MonoExponentialFit run on the general lmdif kernel:
+    against the per-voxel scipy loop of the oracle at E = 40 and 64, incl. a mask, the polyfit start and the rounded map."""
+    import dosma_amd as dm
+    import oracle.fit_oracle as fo
+    rng = np.random.default_rng(64)
+    for E in (40, 64):
+        x = np.linspace(2.0, 120.0, E)
+        shape = (6, 5, 4)
+        n = int(np.prod(shape))
+        s0, t2 = rng.uniform(400, 1500, n), rng.uniform(15, 80, n)
+        y = s0 * np.exp(-x[:, None] / t2) + 8.0 * rng.standard_normal((E, n))
+        y[:, :10] = 0
+        y = y.astype(np.float32)
+        popt, r2 = dm.curve_fit(dm.monoexponential, x, y, p0=(1.0, -1 / 30.0))
+        ref_popt, ref_r2 = fo.curve_fit_scipy(x, y, p0=(1.0, -1 / 30.0))
+        ok = ~np.isnan(ref_popt[:, 0])
+        assert np.array_equal(np.isnan(popt[:, 0]), ~ok) and ok.sum() > 100
+        assert relerr(popt[ok], ref_popt[ok]).max() < RTOL and np.abs(r2[ok] - ref_r2[ok]).max() < 1e-6
+        vols = [dm.MedicalVolume(y[e].reshape(shape), np.eye(4)) for e in range(E)]
+        mask = np.zeros(shape, bool)
+        mask[1:5] = True
+        for tc0 in (30.0, "polyfit"):
+            tc, r2v = dm.MonoExponentialFit(tc0=tc0, decimal_precision=3).fit(x, vols, mask=dm.MedicalVolume(mask.astype(np.uint8), np.eye(4)))
+            tc_ref, r2_ref, _ = fo.monoexp_fit_arrays(x, y, mask=mask.reshape(-1), tc0=tc0, decimal_precision=3)
+            bad = np.abs(tc.volume.reshape(-1) - tc_ref) > 1e-3 + 1e-9
+            assert bad.mean() < 0.01, (E, tc0, int(bad.sum()))
+            assert np.abs(r2v.volume.reshape(-1) - r2_ref).max() < 1e-5
+            assert (tc.volume[0] == 0).all() and (tc.volume[5] == 0).all()
+    with pytest.raises(NotImplementedError):
+        dm.curve_fit(dm.monoexponential, np.arange(1.0, 66.0), np.ones((65, 4), np.float32))  # beyond 64: says so

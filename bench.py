@@ -433,7 +433,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     }
 
 
-UNET_SOURCES = ("unet_s3.hip", "unet_enc0.hip", "unet_kernels.hip", "unet_rw.hip", "unet_engine.hip", "qmri_internal.h")
+UNET_SOURCES = ("unet_s3.hip", "unet_c4.hip", "unet_enc0.hip", "unet_kernels.hip", "unet_rw.hip", "unet_engine.hip", "qmri_internal.h")
 
 
 def _source_sha1(files):

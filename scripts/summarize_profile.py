@@ -69,7 +69,7 @@ if os.path.exists(ut):
         "# rocprofv3 --kernel-trace of scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160: last forward\n"
         "# TF = ALGORITHMIC flops of the layer / kernel time (the parity mode issues 3 MFMAs per product)\n" + layers)
     rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "unet_pmc", "*counter_collection.csv"))[0]))
-            if any(k in r["Kernel_Name"] for k in ("conv_s3_kernel", "enc0_kernel", "mid0_kernel", "out0_kernel"))]
+            if any(k in r["Kernel_Name"] for k in ("conv_s3_kernel", "conv_c4_kernel", "enc0_kernel", "mid0_kernel", "out0_kernel"))]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-25:]  # per forward: enc0 + 17 convolutions + 5 transposed + mid0 + out0
     agg = collections.Counter()
     for r in rows:
@@ -77,7 +77,7 @@ if os.path.exists(ut):
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
     cycles = agg["SQ_BUSY_CYCLES"] / 32  # summed over the 32 shader engines
     u = {"tag": tag, "workload": "UNet2D forward, 160 slices of 384x384, parity mode fp16x3: the 25 MFMA-kernel dispatches of one forward "
-                                 "(enc0_kernel, 22 x conv_s3_kernel, mid0_kernel, out0_kernel)",
+                                 "(enc0_kernel, 22 x conv_s3_kernel / conv_c4_kernel, mid0_kernel, out0_kernel)",
          "counters": dict(agg),
          "MfmaUtil": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
          "mfma_instructions": agg["SQ_INSTS_MFMA"],
@@ -106,3 +106,10 @@ if os.path.exists(ut):
     u["kernel_source_sha1"] = open(uh).read().strip() if os.path.exists(uh) else None   # bench.py: traffic_source.stale
     json.dump(u, open(f"profiles/{tag}_unet_counters.json", "w"), indent=1)
     print(json.dumps({k: u[k] for k in ("MfmaUtil", "mfma_gflop_issued", "mfma_gflop_algorithmic_x3", "wave_wait_frac")}))
+
+# ---- round 4: per-kernel-family PMC table and the same-box conv_c4 / conv_s3 A/B ----
+for name in ("unet_pmc_by_kernel.txt", "c4_ab.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        # (the A/B is referenced from the kernel sources as profiles/r04_c4_ab.txt: one per round, the newest collection)
+        shutil.copy(f, f"profiles/{rnd}_{name}" if name == "c4_ab.txt" else f"profiles/{tag}_{name}")

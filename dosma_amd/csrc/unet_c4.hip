@@ -470,6 +470,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int lane = lane_e, khalf = lane_e >> 5;
+        // (and the item's geometry: the output addresses only depend on it, so hipcc computes them BEFORE the chunk loop, spills
+        //  them across it and reloads one per global store -- each reload a vmcnt(0), i.e. every store behind the previous one)
+        int ey0 = t_y0, ex0 = t_x0, eb = t_b, ef0 = t_f0, enb = t_nb;
+        asm volatile("" : "+s"(ey0), "+s"(ex0), "+s"(eb), "+s"(ef0), "+s"(enb));
+        const int t_y0 = ey0, t_x0 = ex0, t_b = eb, t_f0 = ef0, t_nb = enb;
         unsigned char *stage = halo + kHBuf + wave * 4096;
         if (FLAT) {
             for (int i = tid; i < kMTile; i += kThreads) outpix[i] = flat_to_pix(t_f0 + i, P, A.H, A.W, A.B);
@@ -523,19 +528,43 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                 }
                 // (no wait between the window's writes and reads: a wave's LDS instructions execute in issue order; hipcc waits for the
                 //  read RESULTS before the stores, and the next tile's arithmetic overlaps this tile's LDS round trip)
-                // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window swizzle)
+                // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window swizzle).
+                // Addresses are rebuilt per tile from a scalar row pointer + a small per-lane offset of a lane index made opaque HERE:
+                // as loop invariants of the epilogue they were spilled (the register allocator fills the epilogue's ArchVGPRs with
+                // accumulator copies) and every store waited for a scratch reload, i.e. for the store before it.
+                int lane_t = lane;
+                asm volatile("" : "+v"(lane_t));
                 uint4 v[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16);
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane_t >> 3)) * 128 + (lane_t & 7) * 16);
+                if (FLAT) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int pix = out_pixel(i, t);
-                    const int p8 = (lane & 7) ^ (((t * 8 + (lane >> 3)) >> 1) & 7);
-                    if (pix >= 0) {
-                        const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
-                        nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
+                    for (int t = 0; t < 4; ++t) {
+                        const int pix = outpix[(wave * kRT + i) * 32 + t * 8 + (lane_t >> 3)];
+                        const int p8 = (lane_t & 7) ^ (((t * 8 + (lane_t >> 3)) >> 1) & 7);
+                        if (pix >= 0) {
+                            const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
+                            nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
+                        }
+                    }
+                } else {
+                    const int yy = t_y0 + wave * kRT + i;  // (scalar)
+                    if (yy < A.H) {
+                        unsigned char *rowp = static_cast<unsigned char *>(A.y) +
+                                              (((long long)(t_b * A.H + yy) * A.W + t_x0) * A.ldy + A.yoff + cbase) * 4;  // scalar pointer
+                        const unsigned pstep = (unsigned)A.ldy * 4u;  // bytes per output pixel
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const unsigned px = (unsigned)(t * 8 + (lane_t >> 3));
+                            const unsigned p8 = (unsigned)(lane_t & 7) ^ ((px >> 1) & 7u);
+                            nt_store16(rowp + (size_t)(px * pstep + p8 * 16u), v[t]);
+                        }
                     }
                 }
+                // one accumulator tile at a time: left alone, the scheduler moves the AccVGPR reads of many tiles ahead of their use, the
+                // store addresses get spilled, and every global store then sits behind a scratch reload + s_waitcnt vmcnt(0) -- i.e.
+                // behind the previous store's completion (seen on the 16 x 32 tiles: 117 reloads among 80 stores)
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- fused MaxPooling2D(2x2): row pairs (0, 1) and (2, 3) of this wave -> 16 pooled pixels x 32 channels each ----
             if (!FLAT && A.pool_y) {

@@ -901,13 +901,14 @@ bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     // The choice depends on the LAYER only (level geometry and channel counts), never on the batch: the two kernels add the same
     // products in different orders (tap-major against half-chunk-major), and a slice's logits must not depend on how many slices
     // travel with it (tests/test_unet_fullsize_gpu.py::test_forward_is_bitwise_repeatable runs one volume through engines of two
-    // batch sizes).  Per-layer A/B at 160 slices of 384 x 384 (profiles/r04_c4_ab.txt): on the flattened levels conv_c4_kernel ties
-    // at 4 input chunks and wins 6-10 % from 8; on 16 x 32 image tiles it loses up to 8 chunks (its per-item fixed costs -- the
-    // epilogue of 16 tiles on ONE wave per SIMD, halo set-up -- weigh more there) and ties at 8.
+    // batch sizes).  Per-layer A/B at 160 slices of 384 x 384 (profiles/r04_c4_ab.txt; QMRI_C4 = 0 / 2 alternating on one box):
+    // conv_c4_kernel wins 4-10 % wherever an item has at least 4 input chunks on 16 x 32 image tiles (96 x 96 level: 1074 / 1916 /
+    // 1038 us against 1138 / 2074 / 1072) and at least 8 on the flattened levels (4 chunks: 589 against 582 us); with 2 chunks its
+    // per-item costs -- the epilogue of 16 tiles on ONE wave per SIMD, the halo set-up -- tie it with conv_s3_kernel<128>.
     const bool flat = k.W % 32 != 0;
     const int chunks = k.Cin / 32;
     (void)num_cu;
-    return flat ? chunks >= 8 : chunks >= 16;
+    return flat ? chunks >= 8 : chunks >= 4;
 }
 
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {

@@ -276,11 +276,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     int req_k = 0, req_hc = 0;
     const int nhc = 2 * A.chunks;
     auto halo_soff = [&](int hc) -> unsigned { return (unsigned)(A.xoff * 4 + (hc >> 1) * 128 + (hc & 1) * 32); };
-    auto issue_halo = [&](int i, int hc) {
+    auto issue_halo_at = [&](int i, int hc, unsigned voff) {
         int j = wave + kWaves * i;
         if (j >= kNJ) j = wave;
-        dma_buf16(hofft[i * kThreads + tid], xr, halo_soff(hc), halo_lds + (unsigned)((hc & 1) * kHBuf + j * 1024));
+        dma_buf16(voff, xr, halo_soff(hc), halo_lds + (unsigned)((hc & 1) * kHBuf + j * 1024));
     };
+    auto issue_halo = [&](int i, int hc) { issue_halo_at(i, hc, hofft[i * kThreads + tid]); };
 
     // ---- weight requests: this wave's share (kSlot / 4 bytes) of the slot of the step kAhead ahead ----
     // The request pointer crosses into the NEXT item's weights during the last steps of the current one: w_next = scalar offset
@@ -349,6 +350,24 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         }
     };
 
+    // the same in four parts -- part r: the pixel fragments of row-tile r and the weight fragments of column tile r -- so that the
+    // 16 reads of a step can sit four at a time in front of the four 12-MFMA groups instead of in one block at the step's head
+    auto load_part = [&](Frags &f, int tap, int buf_imm, int slot_, auto sub, int r) {
+        constexpr bool kSub = decltype(sub)::value;
+        const int shift = (tap / 3 - 1) * P + (tap % 3 - 1);
+        int ab = abase[r];
+        asm volatile("" : "+v"(ab));
+        const int hp = ab + shift;
+        const unsigned ao = halo_lds + (unsigned)(hp * 64 + ((khalf ^ ((hp >> 2) & 3)) * 16));
+        f.ah[r] = lds16(ao + (unsigned)buf_imm);
+        f.al[r] = lds16((ao ^ 32u) + (unsigned)buf_imm);
+        const unsigned wb = (kSub ? boff_sub : boff) + (unsigned)(slot_ * kSlot);
+        if (r < (kSub ? 1 : kCT)) {
+            f.bh[r] = lds16(wb + (unsigned)(r * 1024));
+            f.bl[r] = lds16(wb + (unsigned)(r * 1024 + kSlot / 2));
+        }
+    };
+
     f32x16 acc[kRT][kCT];
     // the 3 CT MFMAs of row-tile i: lo x hi, hi x lo, hi x hi over the column tiles (same accumulator every CT-th instruction).
     // `first`: the first k-step of a work item starts the accumulators from the MFMA's constant-zero C operand -- 256 registers
@@ -401,19 +420,31 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         constexpr int NH_ = (T) == 8 ? 1 - (H) : (H);                                                              \
         constexpr int NT_ = (T) == 8 ? 0 : (T) + 1;                                                                \
         /* (the last step of a work item reads nothing ahead: the epilogue does not need 64 live operand registers) */ \
-        if (!((H) == 1 && (T) == 8 && chunk + 1 == A.chunks) && !C4_DBG(8)) load_frags(NXT, NT_, NH_ * kHBuf, (slot + 1) & (kRing - 1), SUB{}); \
+        const bool pf_ = !((H) == 1 && (T) == 8 && chunk + 1 == A.chunks) && !C4_DBG(8);                           \
+        const int nslot_ = (slot + 1) & (kRing - 1);                                                               \
+        /* this step's halo offsets leave the LDS table FIRST: read right in front of the request they would put an lgkmcnt wait -- */ \
+        /* which also drains the operand reads queued before it -- in the middle of the MFMA stream */           \
+        unsigned hv_[3] = {0u, 0u, 0u};                                                                            \
+        _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) hv_[hp_] = hofft[(c4_halo_first(T) + hp_) * kThreads + tid]; \
+        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 0);                                               \
         mma_row(CUR, 0, FIRST{}, SUB{});                                                                           \
         if (!C4_DBG(16)) issue_weights();                                                                          \
+        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 1);                                               \
         mma_row(CUR, 1, FIRST{}, SUB{});                                                                           \
         if constexpr (c4_halo_pieces(T) > 0) if (!C4_DBG(16)) {                                                    \
-            _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) issue_halo(c4_halo_first(T) + hp_, req_hc); \
+            _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) issue_halo_at(c4_halo_first(T) + hp_, req_hc, hv_[hp_]); \
         }                                                                                                          \
+        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 2);                                               \
         mma_row(CUR, 2, FIRST{}, SUB{});                                                                           \
+        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 3);                                               \
         mma_row(CUR, 3, FIRST{}, SUB{});                                                                           \
-        /* the step opens with an MFMA; the reads ride two per MFMA behind the first eight */                      \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                     \
+        /* every 12-MFMA group opens with an MFMA; its four reads ride one per MFMA behind it */                   \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                         \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+            }                                                                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                     \
         }                                                                                                          \
         constexpr int kN_ = c4_in_flight((T), kWPieces);                                                           \
         if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) C4_WAIT(kN_); \

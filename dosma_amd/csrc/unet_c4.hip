@@ -91,7 +91,8 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
 // against num_records: beyond it the lane receives zeros) + soffset (scalar, not range-checked).  Inline asm for the same reason
 // as unet_s3.hip's dma16: hipcc neither counts nor drains it; every wait in this file is a hand-counted s_waitcnt vmcnt(N).
 __device__ __forceinline__ void dma_buf16(unsigned voff, const i32x4 &rsrc, unsigned soff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc),
+                 "s"(__builtin_amdgcn_readfirstlane((int)soff)), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst))
                  : "memory");
 }
 
@@ -160,7 +161,7 @@ struct Frags {
 
 }  // namespace
 
-#ifdef QMRI_C4_EXPERIMENTS  // timing experiments (results wrong by construction): QMRI_C4_DBG = 1 no epilogue | 2 halo sources computed once | 4 no MFMAs | 8 no LDS reads | 16 no DMA requests
+#ifdef QMRI_C4_EXPERIMENTS  // timing experiments (results wrong by construction): QMRI_C4_DBG = 1 no epilogue | 2 halo sources computed once | 4 no MFMAs | 8 no LDS reads | 16 no DMA requests | 32 no global stores in the epilogue | 64 odd blocks start half an item late
 #define C4_DBG(bit) (A.dbg & (bit))
 #else
 #define C4_DBG(bit) 0
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                     for (int t = 0; t < 4; ++t) {
                         const int pix = outpix[(wave * kRT + i) * 32 + t * 8 + (lane_t >> 3)];
                         const int p8 = (lane_t & 7) ^ (((t * 8 + (lane_t >> 3)) >> 1) & 7);
-                        if (pix >= 0) {
+                        if (pix >= 0 && !C4_DBG(32)) {
                             const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
                             nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
                         }
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                         for (int t = 0; t < 4; ++t) {
                             const unsigned px = (unsigned)(t * 8 + (lane_t >> 3));
                             const unsigned p8 = (unsigned)(lane_t & 7) ^ ((px >> 1) & 7u);
-                            nt_store16(rowp + (size_t)(px * pstep + p8 * 16u), v[t]);
+                            if (!C4_DBG(32)) nt_store16(rowp + (size_t)(px * pstep + p8 * 16u), v[t]);
                         }
                     }
                 }
@@ -655,6 +656,13 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         return true;
     };
 
+#ifdef QMRI_C4_EXPERIMENTS
+    if (C4_DBG(64) && (blockIdx.x & 8)) {  // (experiment: every other group of 8 blocks -- one per XCD -- starts half an item late)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)A.chunks * 9ull * 2300ull;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     bool more = true;
     if (my_full > 0) {
         load_frags(f0, 0, 0, slot, Full{});  // operands of the very first step

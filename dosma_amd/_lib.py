@@ -149,7 +149,7 @@ MODELS = {"monoexponential": 0, "biexponential": 1}
 MODEL_NPARAMS = {"monoexponential": 2, "biexponential": 4}
 # "fp16x3" is the parity mode (logits within 1e-3 of an fp64 run); "fp16x3-general" forces it onto the general
 # convolution kernel in the operator-level entry (tests); "bf16" is the single-MFMA throughput mode
-PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2, "bf16-s3": 3, "fp16x3-c4": 4, "fp16x3-s3": 5}  # "bf16-s3": plain bf16 forced onto conv_s3_kernel (operator entry, tests)
+PRECISION = {"bf16": 0, "fp16x3": 1, "fp16x3-general": 2, "bf16-s3": 3, "fp16x3-c4": 4, "fp16x3-s3": 5, "fp16x3-c4-nosplit": 6}  # "bf16-s3": plain bf16 forced onto conv_s3_kernel (operator entry, tests)
 
 EXPORTS = (
     "qmri_version", "qmri_device_count", "qmri_last_error", "qmri_monoexp_defaults",

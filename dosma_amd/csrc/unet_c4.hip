@@ -759,7 +759,7 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         const char *e = std::getenv("QMRI_C4_SPLIT");
         return e ? std::atoi(e) : 1;
     }();
-    k.c4_split = split;
+    k.c4_split = k0.c4_split < 0 ? 0 : split;  // (< 0: the caller wants whole items only -- tests compare the two bit for bit)
     static const int dbg = [] {
         const char *e = std::getenv("QMRI_C4_DBG");
         return e ? std::atoi(e) : 0;

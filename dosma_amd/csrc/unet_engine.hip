@@ -1221,7 +1221,7 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         hipDeviceProp_t prop;
         U_TRY(hipGetDeviceProperties(&prop, device));
         // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
-        // 4: conv_c4_kernel or an error; 5: conv_s3_kernel whatever the cost model says (tests compare the two)
+        // 4: conv_c4_kernel or an error; 5: conv_s3_kernel whatever the layer; 6: conv_c4_kernel, whole work items only (tests compare them)
         const bool s3 = !ab && precision != 2 && s3_width_ok(W);
         if (!ab) U_TRY(L.upload_parity(wk, s3));
         if (precision == 3) {
@@ -1246,7 +1246,8 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
             k.deconv = transposed ? 1 : 0;
             k.w = L.w_s3.p; k.winv = L.winv;
             k.w_c4 = L.w_c4.p;
-            k.c4_mode = precision == 4 ? 1 : precision == 5 ? -1 : 0;
+            k.c4_mode = (precision == 4 || precision == 6) ? 1 : precision == 5 ? -1 : 0;
+            k.c4_split = precision == 6 ? -1 : 0;  // 6: conv_c4_kernel without the channel-split last round
             k.bias = L.bias.as<float>();
             k.scale = L.has_affine ? L.scale.as<float>() : nullptr;
             k.shift = L.has_affine ? L.shift.as<float>() : nullptr;

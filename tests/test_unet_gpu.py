@@ -85,6 +85,10 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     (32, 64, (32, 64), 3),      # 64-channel blocks (CT = 2): one chunk
     (128, 64, (16, 32), 4),     # 64-channel block, four chunks
     (64, 192, (30, 46), 2),     # 64-channel blocks x 3, flattened
+    # more work items than CUs, with a short last round: 264 items -> 33 per XCD on 32 blocks = one round + 1 leftover item per
+    # XCD, which runs as four 32-channel sub-items (the channel-split last round); flattened: 285 tiles -> 36 per XCD, 4 leftover
+    (32, 128, (16, 32), 264),
+    (64, 128, (12, 12), 800),
 ])
 def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     """conv_c4_kernel (one wave per SIMD, 128 x 128 register tiles; unet_c4.hip) forced on, against the fp64 convolution
@@ -104,6 +108,9 @@ def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     assert np.abs(y3 - ref).max() < 3e-5
     again = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, precision="fp16x3-c4")
     assert np.array_equal(y4, again)  # no atomics, no timing dependence: same bits every run
+    # the channel-split last round (leftover work items as four 32-channel sub-items) adds the same products in the same order
+    whole = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, precision="fp16x3-c4-nosplit")
+    assert np.array_equal(y4, whole)
 
 
 def test_deconv_matches_the_scatter_definition():

@@ -150,9 +150,9 @@ def test_product_never_imports_the_oracle():
     subprocess.check_call([sys.executable, "-c", code])
 
 
-@pytest.mark.parametrize("source,min_dma", [("unet_s3.hip", 20), ("unet_enc0.hip", 6)])
+@pytest.mark.parametrize("source,min_dma", [("unet_s3.hip", 20), ("unet_enc0.hip", 6), ("unet_c4.hip", 8)])
 def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
-    """unet_s3.hip / unet_enc0.hip issue their LDS-DMA through inline asm that writes M0 (the LDS destination base) and does
+    """unet_s3.hip / unet_enc0.hip / unet_c4.hip issue their LDS-DMA through inline asm that writes M0 (the LDS destination base) and does
     not restore it.  That is only sound if nothing else in those kernels reads M0: check the generated gfx950 assembly --
     every line that mentions m0 must be one of the statement's own `s_mov_b32 m0, ...` writes."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -168,3 +168,41 @@ def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
     others = [ln for ln in m0 if not ln.startswith("s_mov_b32 m0,")]
     assert not others, others[:5]
     assert sum("global_load_lds_dwordx4" in ln or ("buffer_load_dwordx4" in ln and ln.rstrip().endswith("lds")) for ln in lines) >= min_dma
+
+
+def test_conv_c4_main_loop_has_no_scratch_traffic(tmp_path):
+    """conv_c4_kernel keeps DMA requests in flight across steps and waits for them with COUNTED s_waitcnt vmcnt(N).  A register
+    the allocator spills inside the main loop comes back through scratch_load -- a vector-memory load hipcc waits for with
+    vmcnt(0), i.e. for every request in flight (this happened with the tap-offset table, the halo offsets and the store
+    addresses: DESIGN 6.4).  Guard: in the generated gfx950 code of the 128-channel instantiations, no barrier interval that
+    holds a main-loop share of MFMAs (three steps = 144) contains a scratch access, and none but the one with the per-item halo
+    set-up (divisions: exec-masked branches; its reload waits were measured at +-0) a vmcnt(0)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "dosma_amd", "csrc", "unet_c4.hip")
+    out = tmp_path / "unet_c4.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "dosma_amd", "csrc"), src, "-o", str(out)])
+    text = out.read_text()
+    checked = pure = 0
+    for flat in ("Lb1", "Lb0"):
+        name = f"_ZN4qmri14conv_c4_kernelI{flat}ELi4EEEvNS_10ConvS3ArgsE"
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        for interval in body.split("s_barrier"):
+            lines = [ln.strip() for ln in interval.splitlines()]
+            mfma = sum(ln.startswith("v_mfma") for ln in lines)
+            stores = sum(ln.startswith("global_store") for ln in lines)
+            if mfma >= 135 and stores == 0:  # a main-loop interval (144 MFMAs; the last one of an item runs into the epilogue and holds fewer)
+                checked += 1
+                assert not any(ln.startswith("scratch_") for ln in lines), (flat, [ln for ln in lines if ln.startswith("scratch_")][:3])
+                if not any(ln.startswith("s_cbranch_execz") for ln in lines):  # (a pure step interval)
+                    pure += 1
+                    assert not any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in lines), flat
+    assert checked >= 8 and pure >= 6, (checked, pure)  # (two instantiations x >= 4 of the 6 intervals of a chunk)
+
+
+def test_conv_c4_lds_layouts_are_bank_conflict_free():
+    """scripts/lds_bank_check.py: the halo and weight images of conv_c4_kernel against the guide's ds_read_b128 lane groups."""
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "lds_bank_check.py")])

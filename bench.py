@@ -487,7 +487,7 @@ def _unet_traffic():
     base = {"algorithmic_bytes": alg, "algorithmic_bytes_written": alg_w, "algorithmic_bytes_read": alg_r,
             "algorithmic_bytes_note": "layer-by-layer minimum as built (4 B per activation value, first block / pooling / "
                                       "classifier fused): every feature map crossing a kernel boundary written once, read once"}
-    # newest first BY TAG (r04b > r04a > r03g: file times do not survive a checkout); a file whose recorded source hash matches
+    # newest first BY TAG (r04c > r03g: file times do not survive a checkout); a file whose recorded source hash matches
     # the current sources wins over a newer tag that does not
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_unet_counters.json")),
                    key=lambda q: os.path.basename(q), reverse=True)

@@ -115,8 +115,17 @@ def test_edge_cases_golden(golden, relerr):
     assert same_class.mean() > 0.99
     both = same_class & ok
     d = relerr(o["popt"][both], g["popt"][both]).max(axis=1)
-    assert (d > RTOL).mean() < 0.06
-    assert (d > 10 * RTOL).mean() < 0.03
+    assert (d > RTOL).mean() < 0.05          # measured 3.8 % (18 of 473; scripts/edge_noise_check.py)
+    assert (d > 10 * RTOL).mean() < 0.02     # measured 1.3 %
+    # ... and the tail is the ill-conditioning of fitting noise, not a different algorithm: against the C restatement of lmdif run
+    # with the kernel's own difference quotients (jac_mode 2) every column takes the SAME number of evaluations and stops with the
+    # same code -- the decision path is identical, only last-digit arithmetic (the exponential) differs, amplified on flat minima;
+    # the restatement with TRUE differences is itself 0.85 % / 0.63 % away from scipy on these columns
+    popt_c, _, info_c, nfev_c = fo.curve_fit_c(x, y, P0, jac_mode=2, full_output=True)
+    ok_c = (info_c >= 1) & (info_c <= 4)
+    assert ((((o["info"] >= 1) & (o["info"] <= 4)) == ok_c).mean() > 0.995)
+    b2 = ok_c & (o["info"] >= 1) & (o["info"] <= 4)
+    assert (o["nfev"][b2] == nfev_c[b2]).mean() > 0.995
     # p0 = None (ones) and the reference tests' far guess p0 = (1, 50) with x = 1..4
     o = L.monoexp_fit_host(x, y, p0=(1.0, 1.0))
     both = ~np.isnan(g["popt_p0none"][:, 0]) & ~np.isnan(o["popt"][:, 0])

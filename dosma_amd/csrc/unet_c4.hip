@@ -1,5 +1,5 @@
-// unet_c4.hip -- the parity-mode ("fp16x3") 3x3 convolution for layers with >= 128 output channels, round 4:
-// ONE WAVE PER SIMD, 128 x 128 register tiles.
+// unet_c4.hip -- the parity-mode ("fp16x3") 3x3 convolution for layers with >= 64 output channels, round 4:
+// ONE WAVE PER SIMD, 128 x 128 (or 192 x 64) register tiles.
 //
 // Same layer as conv_s3_kernel<128> (unet_s3.hip): Conv2D(3x3, SAME) + bias + ReLU (+ the BatchNormalization affine after
 // the block's second ReLU, + fused MaxPooling2D) of /root/reference/dosma/models/oaiunet2d.py:213-226, 266-279 on SPLIT
@@ -34,11 +34,18 @@
 //     immediate offset; the first k-step of an item starts from the MFMA's constant-zero C operand (no zeroing pass).
 //   * work items are big, so the last, partial round of a launch is split by CHANNELS: each leftover item becomes four
 //     sub-items of one 32-channel column tile, one per block (the 24 x 24 level: 3.3 instead of 4 rounds).
-//   * epilogue as in unet_s3.hip (wave-private 4 KB staging window in the finished half-chunk's halo buffer, 16-byte stores
-//     of whole 128-byte pixel-chunks, fused 2x2 max-pool on row pairs, saturation tracking).
+//   * epilogue: THE ACCUMULATORS LEAVE THE REGISTER FILE RAW -- ds_write_b128 straight from AccVGPRs into two wave-private
+//     4 KB windows in the finished half-chunk's halo buffer -- and come back pixel-major, a lane = 8 channels of one pixel:
+//     bias, ReLU, BatchNormalization affine, split, two 16-byte stores (hi and lo plane) into the pixel's 128-byte record;
+//     fused 2x2 max-pool on the staged row pair; saturation tracking.  (The first version did the arithmetic in the MFMA
+//     layout like unet_s3.hip: VALU instructions cannot read AccVGPRs, the register allocator moved the epilogue's whole live
+//     range into ArchVGPRs at its entry -- 160 v_accvgpr_read in a row and six tiles to scratch, every reload behind
+//     s_waitcnt vmcnt(0), i.e. behind the acknowledgement of all stores so far.  -3.7 % on the layers of this kernel.)
+//   * 64-channel layers (CT = 2) on image tiles take 6 x 2 register tiles per wave: 24 rows x 32 pixels per block, 36 MFMAs
+//     per k-step, halo 1.15 x the tile (C4Geo).  With 4 x 2 tiles (24 MFMAs per k-step; still the flattened form) the kernel
+//     lost to conv_s3_kernel<64>.
 //   * which layers run here is conv_s3_takes_c4's decision (unet_s3.hip): by layer shape only, so that a slice's bits do not
-//     depend on the batch.  64-channel blocks (CT = 2) are built and tested but never picked: 24 MFMAs per barrier lose to
-//     conv_s3_kernel<64>.
+//     depend on the batch.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -61,14 +68,24 @@ typedef __attribute__((address_space(3))) f16x8 lds_f16x8;
 
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
-constexpr int kMTile = 512;              // output positions per tile: 16 MFMA row-tiles of 32
-constexpr int kRT = 4;                   // 32-pixel row-tiles per wave; the column tiles (32 channels each) are the template parameter CT:
-                                         // 4 = 128-channel blocks (256 accumulators), 2 = 64-channel blocks (Cout = 64 layers)
 constexpr int kPitch2D = 34;
-constexpr int kHalo2D = 18 * kPitch2D;   // 612 halo pixels of the 16 x 32 tile
-constexpr int kNJ = 39;                  // DMA instructions (16 pixels x 64 B) per halo buffer: 624 >= 612 (2D), >= 512 + 2 * 50 + 2 (flat)
-constexpr int kHBuf = kNJ * 1024;        // bytes per halo buffer
-constexpr int kHSlots = 10;              // halo pieces per wave (4 * 10 >= 39; the 40th repeats the wave's first)
+// Tile geometry.  A wave's register tile is RT row-tiles (32 pixels each) x CT column tiles (32 channels each; the template parameter):
+//   CT = 4: 128-channel blocks, RT = 4 -> 256 accumulators; block tile 16 rows x 32 pixels (or 512 flattened positions)
+//   CT = 2: 64-channel blocks (the Cout = 64 layers).  With RT = 4 a k-step is 24 MFMAs per wave and the kernel loses to
+//           conv_s3_kernel<64>; on image tiles it therefore takes RT = 6: 24 rows x 32 pixels, 192 accumulators, 36 MFMAs per
+//           k-step, halo 26 x 34 = 1.15 x the tile -- what the LDS holds twice beside the ring (2 x 56 KB + 32 KB).
+template <bool FLAT, int CT>
+struct C4Geo {
+    static constexpr int RT = (CT == 2 && !FLAT) ? 6 : 4;   // 32-pixel row-tiles per wave
+    static constexpr int ROWS = 4 * RT;                      // image rows of a block tile (one per row-tile)
+    static constexpr int MTILE = ROWS * 32;                  // output positions per block tile
+    static constexpr int HALO2D = (ROWS + 2) * kPitch2D;     // 612 / 884 halo pixels
+    // DMA instructions (16 pixels x 64 B) per halo buffer: 39 (624 >= 612 (2D), >= 512 + 2 * 50 + 2 (flat)) / 56 (896 >= 884)
+    static constexpr int NJ = (HALO2D + 15) / 16;
+    static constexpr int HBUF = NJ * 1024;                   // bytes per halo buffer
+    static constexpr int HSLOTS = (NJ + 3) / 4;              // halo pieces per wave: 10 (the 40th repeats the wave's first) / 14
+    static constexpr int STAGE = 8192;                       // epilogue staging per wave: two 4 KB windows (the tiles of a row pair)
+};
 constexpr int kRing = 8;                 // weight ring slots of [2 planes][32 CT rows][32 B] = 2048 CT bytes
 // One s_barrier per kBarEvery steps.  What the ring allows: the operands of step u are read during step u - 1, i.e. after the last
 // barrier at or before step u - 2; a wave's counted wait in front of a barrier covers everything it issued kInFlight or more steps
@@ -112,14 +129,18 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *base) {
     return r;
 }
 
-// requests a wave issues in tap t: the step's weight pieces + the halo pieces of c4_halo_pieces(t); the counted wait at the end of
-// tap t lets the requests of the last kInFlight steps (taps wrap: every half-chunk has the same pattern) stay in flight
-constexpr int c4_halo_pieces(int t) { return kBarEvery == 1 ? (t <= 4 ? 2 : 0) : (t <= 1 ? 3 : t <= 3 ? 2 : 0); }
-constexpr int c4_halo_first(int t) { return kBarEvery == 1 ? 2 * t : (t <= 1 ? 3 * t : 6 + 2 * (t - 2)); }
-constexpr int c4_issued(int t, int w) { return w + c4_halo_pieces(t); }
-constexpr int c4_in_flight(int t, int w) {
-    return c4_issued(t, w) + c4_issued((t + 8) % 9, w) + (kInFlight == 2 ? 0 : c4_issued((t + 7) % 9, w));
+// requests a wave issues in tap t: the step's weight pieces + the halo pieces of c4_halo_pieces(t, n) (n = pieces per wave and
+// half-chunk, spread over the first kHaloTaps taps: 3 3 2 2 for 10, 4 4 3 3 for 14); the counted wait at the end of tap t lets the
+// requests of the last kInFlight steps (taps wrap: every half-chunk has the same pattern) stay in flight
+constexpr int kHaloTaps = kBarEvery == 1 ? 5 : 4;
+constexpr int c4_halo_pieces(int t, int n) { return t >= kHaloTaps ? 0 : n / kHaloTaps + (t < n % kHaloTaps ? 1 : 0); }
+constexpr int c4_halo_first(int t, int n) { return t * (n / kHaloTaps) + (t < n % kHaloTaps ? t : n % kHaloTaps); }
+constexpr int c4_issued(int t, int w, int n) { return w + c4_halo_pieces(t, n); }
+constexpr int c4_in_flight(int t, int w, int n) {
+    return c4_issued(t, w, n) + c4_issued((t + 8) % 9, w, n) + (kInFlight == 2 ? 0 : c4_issued((t + 7) % 9, w, n));
 }
+static_assert(c4_halo_first(kHaloTaps - 1, 10) + c4_halo_pieces(kHaloTaps - 1, 10) == 10 && c4_halo_pieces(0, 10) <= 4, "halo schedule");
+static_assert(c4_halo_first(kHaloTaps - 1, 14) + c4_halo_pieces(kHaloTaps - 1, 14) == 14 && c4_halo_pieces(0, 14) <= 4, "halo schedule");
 
 // decode a flat position of the zero-framed image stack: f = R * P + c, R = b * (H + 1) + y + 1, c = x + 1
 __device__ __forceinline__ int flat_to_pix(int f, int P, int H, int W, int B) {
@@ -154,10 +175,27 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 &hi, uint2 &lo
     lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
-template <int CT>
+template <int RT, int CT>
 struct Frags {
-    f16x8 ah[kRT], al[kRT], bh[CT], bl[CT];
+    f16x8 ah[RT], al[RT], bh[CT], bl[CT];
 };
+
+// scheduling hints of one k-step (sched_group_barrier wants literal counts): group g = the 3 * CT MFMAs of row-tile g with the
+// NR reads of the next step's part g (its two pixel fragments, + two weight fragments while g < CT) one per MFMA behind the first
+template <int G, int RT, int CT>
+__device__ __forceinline__ void c4_sched_step() {
+    if constexpr (G < RT) {
+        constexpr int NM = 3 * CT, NR = G < CT ? 4 : 2, NP = NR < NM ? NR : NM;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (NR > NP) __builtin_amdgcn_sched_group_barrier(0x100, NR - NP, 0);
+        if constexpr (NM > NP) __builtin_amdgcn_sched_group_barrier(0x008, NM - NP, 0);
+        c4_sched_step<G + 1, RT, CT>();
+    }
+}
 
 }  // namespace
 
@@ -166,18 +204,34 @@ struct Frags {
 #else
 #define C4_DBG(bit) 0
 #endif
+#ifdef QMRI_C4_TIMELINE  // (experiment build: block 8 records where its second and third work items spend their time, in 10 ns ticks;
+                         //  read back with qmri_debug_c4_timeline -- scripts/c4_timeline.py)
+__device__ unsigned long long g_c4_tl[256 * 16];
+__device__ unsigned int g_c4_tl_n;
+#define C4_TS(k)                                                                                     \
+    do {                                                                                             \
+        if (blockIdx.x == 8 && tid == 0 && cur >= 1 && cur <= 2) tsbuf[(cur - 1) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define C4_TS(k)
+#endif
 
 template <bool FLAT, int CT>
 __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A) {
+    using G = C4Geo<FLAT, CT>;
+    constexpr int kRT = G::RT, kMTile = G::MTILE, kHalo2D = G::HALO2D, kNJ = G::NJ, kHBuf = G::HBUF, kHSlots = G::HSLOTS;
     constexpr int kCT = CT, kBN = 32 * CT, kSlot = 2048 * CT;
     constexpr int kWPieces = kSlot / (kWaves * 1024);  // weight DMA instructions per wave and step: 2 (CT = 4) or 1 (CT = 2)
-    using Frags = Frags<CT>;
+    using Frags = Frags<kRT, CT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *halo = smem;                                        // [2][kNJ * 16 pixels][64 B swizzled]
     unsigned char *ring = smem + 2 * kHBuf;                            // [kRing][2 planes][128][32 B swizzled]
-    int *outpix = reinterpret_cast<int *>(ring + kRing * kSlot);       // [512] output pixel of a tile position, or -1 (FLAT)
-    float *prm = reinterpret_cast<float *>(outpix + kMTile);           // bias | scale | shift, [128] each
+    int *outpix = reinterpret_cast<int *>(ring + kRing * kSlot);       // [kMTile] output pixel of a tile position, or -1 (FLAT only)
+    float *prm = reinterpret_cast<float *>(outpix + (FLAT ? kMTile : 0));  // bias | scale | shift, [128] each
     unsigned *hofft = reinterpret_cast<unsigned *>(prm + 3 * kBN);     // [kHSlots][256] per-lane halo source offsets (see below)
+#ifdef QMRI_C4_TIMELINE
+    unsigned long long *tsbuf = reinterpret_cast<unsigned long long *>(hofft + kHSlots * kThreads);
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -235,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             b = t / per_img;
             const int r = t - b * per_img;
             const int ty = r / A.tiles_x;
-            y0 = ty * 16;
+            y0 = ty * G::ROWS;
             x0 = (r - ty * A.tiles_x) * 32;
             f0 = 0;
         }
@@ -420,35 +474,30 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     {                                                                                                              \
         constexpr int NH_ = (T) == 8 ? 1 - (H) : (H);                                                              \
         constexpr int NT_ = (T) == 8 ? 0 : (T) + 1;                                                                \
+        constexpr int kHP_ = c4_halo_pieces((T), kHSlots), kHF_ = c4_halo_first((T), kHSlots);                     \
         /* (the last step of a work item reads nothing ahead: the epilogue does not need 64 live operand registers) */ \
         const bool pf_ = !((H) == 1 && (T) == 8 && chunk + 1 == A.chunks) && !C4_DBG(8);                           \
         const int nslot_ = (slot + 1) & (kRing - 1);                                                               \
         /* this step's halo offsets leave the LDS table FIRST: read right in front of the request they would put an lgkmcnt wait -- */ \
         /* which also drains the operand reads queued before it -- in the middle of the MFMA stream */           \
-        unsigned hv_[3] = {0u, 0u, 0u};                                                                            \
-        _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) hv_[hp_] = hofft[(c4_halo_first(T) + hp_) * kThreads + tid]; \
-        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 0);                                               \
-        mma_row(CUR, 0, FIRST{}, SUB{});                                                                           \
-        if (!C4_DBG(16)) issue_weights();                                                                          \
-        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 1);                                               \
-        mma_row(CUR, 1, FIRST{}, SUB{});                                                                           \
-        if constexpr (c4_halo_pieces(T) > 0) if (!C4_DBG(16)) {                                                    \
-            _Pragma("unroll") for (int hp_ = 0; hp_ < c4_halo_pieces(T); ++hp_) issue_halo_at(c4_halo_first(T) + hp_, req_hc, hv_[hp_]); \
-        }                                                                                                          \
-        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 2);                                               \
-        mma_row(CUR, 2, FIRST{}, SUB{});                                                                           \
-        if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, 3);                                               \
-        mma_row(CUR, 3, FIRST{}, SUB{});                                                                           \
-        /* every 12-MFMA group opens with an MFMA; its four reads ride one per MFMA behind it */                   \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                         \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+        unsigned hv_[4] = {0u, 0u, 0u, 0u};                                                                        \
+        _Pragma("unroll") for (int hp_ = 0; hp_ < kHP_; ++hp_) hv_[hp_] = hofft[(kHF_ + hp_) * kThreads + tid];    \
+        /* part r: the reads of the next step's row-tile r (+ column tile r), the MFMAs of this step's row-tile r; the weight */ \
+        /* request rides behind the first group, the halo requests behind the second */                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < kRT; ++r_) {                                                       \
+            if (pf_) load_part(NXT, NT_, NH_ * kHBuf, nslot_, SUB{}, r_);                                          \
+            mma_row(CUR, r_, FIRST{}, SUB{});                                                                      \
+            if (r_ == 0 && !C4_DBG(16)) issue_weights();                                                           \
+            if constexpr (kHP_ > 0) if (r_ == 1 && !C4_DBG(16)) {                                                  \
+                _Pragma("unroll") for (int hp_ = 0; hp_ < kHP_; ++hp_) issue_halo_at(kHF_ + hp_, req_hc, hv_[hp_]); \
             }                                                                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                     \
         }                                                                                                          \
-        constexpr int kN_ = c4_in_flight((T), kWPieces);                                                           \
+        /* every MFMA group opens with an MFMA; its reads (4 while column tiles are left, 2 after) ride one per MFMA behind it */ \
+        c4_sched_step<0, kRT, (SUB::value ? 1 : kCT)>();                                                           \
+        constexpr int kN_ = c4_in_flight((T), kWPieces, kHSlots);                                                  \
+        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS(1); }                                          \
         if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) C4_WAIT(kN_); \
+        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS(2); }                                          \
         slot = (slot + 1) & (kRing - 1);                                                                           \
     }
 #define C4_STEP(H, T, CUR, NXT, SUB) C4_STEP_(H, T, CUR, NXT, std::false_type, SUB)
@@ -507,76 +556,98 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         int ey0 = t_y0, ex0 = t_x0, eb = t_b, ef0 = t_f0, enb = t_nb;
         asm volatile("" : "+s"(ey0), "+s"(ex0), "+s"(eb), "+s"(ef0), "+s"(enb));
         const int t_y0 = ey0, t_x0 = ex0, t_b = eb, t_f0 = ef0, t_nb = enb;
-        unsigned char *stage = halo + kHBuf + wave * 4096;
+        unsigned char *stage = halo + kHBuf + wave * G::STAGE;
         if (FLAT) {
             for (int i = tid; i < kMTile; i += kThreads) outpix[i] = flat_to_pix(t_f0 + i, P, A.H, A.W, A.B);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        auto out_pixel = [&](int i, int t) -> int {  // output pixel of this lane's store t of row-tile i (lane >> 3 = pixel of 8)
-            if (FLAT) return outpix[(wave * kRT + i) * 32 + t * 8 + (lane >> 3)];
-            const int yy = t_y0 + wave * kRT + i, xx = t_x0 + t * 8 + (lane >> 3);
-            if (yy >= A.H) return -1;
-            return (t_b * A.H + yy) * A.W + xx;
-        };
         const float winv = A.winv;
-        struct Prm4 {
-            f32x4 b, s, t;
-        };
-        auto load_prm4 = [&](int jc, int q) -> Prm4 {  // jc = column tile within the channel block
-            Prm4 p;
-            const float *pp = prm + jc * 32 + 8 * q + 4 * khalf;
-            p.b = *reinterpret_cast<const f32x4 *>(pp);
-            p.s = *reinterpret_cast<const f32x4 *>(pp + kBN);
-            p.t = *reinterpret_cast<const f32x4 *>(pp + 2 * kBN);
-            return p;
-        };
         const float floor_ = A.relu ? 0.f : -__builtin_inff();  // ReLU as a lower bound: one v_max, no select on the flag
-        auto affine = [&](float a, const Prm4 &p, int r) -> float {
-            const float v = fmaxf(fmaf(a, winv, p.b[r]), floor_);
-            return fmaf(v, p.s[r], p.t[r]);
-        };
         const int n0 = t_nb * kBN;
         const int px_l = lane & 31;
-        auto stage_piece = [&](int px, int p8) { return px * 128 + ((p8 ^ ((px >> 1) & 7)) * 16); };
+        // THE ACCUMULATORS LEAVE THE REGISTER FILE RAW.  An MFMA tile has this lane's pixel (lane & 31) and 16 channels
+        // (8 q + 4 khalf + r); VALU instructions cannot read AccVGPRs, and an epilogue that starts with arithmetic on them makes the
+        // register allocator move its whole live range into ArchVGPRs at the epilogue's entry (160 v_accvgpr_read in a row, six
+        // tiles to SCRATCH, every reload behind s_waitcnt vmcnt(0) = behind the acknowledgement of all stores issued so far).
+        // ds_write takes AccVGPR data: four 16-byte pieces (4 channels, fp32) per lane go to a wave-private 4 KB window
+        // [32 pixels][128 B], piece g = 2 q + khalf of pixel p at position g ^ ((p >> 1) & 7) (conflict-free both ways), and come
+        // back pixel-major: task t = 0, 1 of a lane = pixel 16 t + (lane >> 2), channel octet lane & 3 -- 8 values -> bias, ReLU,
+        // BatchNormalization affine, split -> one 16-byte piece of the hi plane and one of the lo plane of the pixel's 128-byte
+        // record.  A lane's octet is the same for every tile of a column tile: its 24 parameters are fetched once.
+        // Two windows per wave: the tiles of a row pair are written back to back, so the second write and both read-backs overlap
+        // the first tile's arithmetic, and the fused 2 x 2 max-pool finds both rows staged.
+        const int oc = lane & 3, opx = lane >> 2;
+        auto piece_off = [&](int px, int g) -> int { return px * 128 + ((g ^ ((px >> 1) & 7)) * 16); };
+        struct Prm8 {
+            f32x4 b[2], s[2], t[2];
+        };
+        auto finish8 = [&](const f32x4 &r0, const f32x4 &r1, const Prm8 &p, float (&v)[8]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaf(fmaxf(fmaf(r0[r], winv, p.b[0][r]), floor_), p.s[0][r], p.t[0][r]);
+                v[4 + r] = fmaf(fmaxf(fmaf(r1[r], winv, p.b[1][r]), floor_), p.s[1][r], p.t[1][r]);
+            }
+        };
+        auto split8 = [&](const float (&v)[8], uint4 &hi, uint4 &lo) {
+            uint2 h0, l0, h1, l1;
+            const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+            split4(a, h0, l0);
+            split4(b, h1, l1);
+            hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        };
 #pragma unroll
         for (int j = 0; j < (kSub ? 1 : kCT); ++j) {
             const int jc = kSub ? sub_cq : j;
             const int cbase = n0 + jc * 32;
+            Prm8 p;
+            {
+                const float *pp = prm + jc * 32 + 8 * oc;
 #pragma unroll
-            for (int i = 0; i < kRT; ++i) {
+                for (int h = 0; h < 2; ++h) {
+                    p.b[h] = *reinterpret_cast<const f32x4 *>(pp + 4 * h);
+                    p.s[h] = *reinterpret_cast<const f32x4 *>(pp + kBN + 4 * h);
+                    p.t[h] = *reinterpret_cast<const f32x4 *>(pp + 2 * kBN + 4 * h);
+                }
+            }
+            auto put_tile = [&](int i, int win) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const Prm4 p = load_prm4(jc, q);
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = affine(acc[i][j][4 * q + r], p, r);
-                    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-                    amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
-                    asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps all 256 values alive -- in scratch -- until then)
-                    uint2 hi2, lo2;
-                    split4(v, hi2, lo2);
-                    *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, q) + 8 * khalf) = hi2;
-                    *reinterpret_cast<uint2 *>(stage + stage_piece(px_l, 4 + q) + 8 * khalf) = lo2;
+                    const f32x16 &a = acc[i][j];
+                    const f32x4 piece = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                    *reinterpret_cast<f32x4 *>(stage + win * 4096 + piece_off(px_l, 2 * q + khalf)) = piece;
                 }
-                // (no wait between the window's writes and reads: a wave's LDS instructions execute in issue order; hipcc waits for the
-                //  read RESULTS before the stores, and the next tile's arithmetic overlaps this tile's LDS round trip)
-                // four 16-byte stores per lane: 8 lanes = one 128-byte pixel-chunk (pieces permuted by the window swizzle).
-                // Addresses are rebuilt per tile from a scalar row pointer + a small per-lane offset of a lane index made opaque HERE:
-                // as loop invariants of the epilogue they were spilled (the register allocator fills the epilogue's ArchVGPRs with
-                // accumulator copies) and every store waited for a scratch reload, i.e. for the store before it.
+            };
+            auto get_tile = [&](int i, int win) {
+                // (addresses are rebuilt per tile from a scalar row pointer + a small per-lane offset of a lane index made opaque HERE:
+                //  as loop invariants of the epilogue they get spilled and every store waits for a scratch reload)
                 int lane_t = lane;
                 asm volatile("" : "+v"(lane_t));
-                uint4 v[4];
+                const int oc_t = lane_t & 3, opx_t = lane_t >> 2;
+                f32x4 r[2][2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(stage + (t * 8 + (lane_t >> 3)) * 128 + (lane_t & 7) * 16);
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) r[t][h] = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(t * 16 + opx_t, 2 * oc_t + h));
+                }
+                uint4 hi[2], lo[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v[8];
+                    finish8(r[t][0], r[t][1], p, v);
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) amax = fmaxf(fmaxf(amax, fabsf(v[k])), fabsf(v[k + 1]));
+                    asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps every value alive until then)
+                    split8(v, hi[t], lo[t]);
+                }
                 if (FLAT) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int pix = outpix[(wave * kRT + i) * 32 + t * 8 + (lane_t >> 3)];
-                        const int p8 = (lane_t & 7) ^ (((t * 8 + (lane_t >> 3)) >> 1) & 7);
+                    for (int t = 0; t < 2; ++t) {
+                        const int pix = outpix[(wave * kRT + i) * 32 + t * 16 + opx_t];
                         if (pix >= 0 && !C4_DBG(32)) {
-                            const long long doff = ((long long)pix * A.ldy + A.yoff + cbase) * 4 + p8 * 16;
-                            nt_store16(static_cast<unsigned char *>(A.y) + doff, v[t]);
+                            unsigned char *dst = static_cast<unsigned char *>(A.y) + ((long long)pix * A.ldy + A.yoff + cbase) * 4 + oc_t * 16;
+                            nt_store16(dst, hi[t]);
+                            nt_store16(dst + 64, lo[t]);
                         }
                     }
                 } else {
@@ -586,57 +657,51 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                                               (((long long)(t_b * A.H + yy) * A.W + t_x0) * A.ldy + A.yoff + cbase) * 4;  // scalar pointer
                         const unsigned pstep = (unsigned)A.ldy * 4u;  // bytes per output pixel
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const unsigned px = (unsigned)(t * 8 + (lane_t >> 3));
-                            const unsigned p8 = (unsigned)(lane_t & 7) ^ ((px >> 1) & 7u);
-                            if (!C4_DBG(32)) nt_store16(rowp + (size_t)(px * pstep + p8 * 16u), v[t]);
+                        for (int t = 0; t < 2; ++t) {
+                            const unsigned off = (unsigned)(t * 16 + opx_t) * pstep + (unsigned)oc_t * 16u;
+                            if (!C4_DBG(32)) {
+                                nt_store16(rowp + (size_t)off, hi[t]);
+                                nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                            }
                         }
                     }
                 }
-                // one accumulator tile at a time: left alone, the scheduler moves the AccVGPR reads of many tiles ahead of their use, the
-                // store addresses get spilled, and every global store then sits behind a scratch reload + s_waitcnt vmcnt(0) -- i.e.
-                // behind the previous store's completion (seen on the 16 x 32 tiles: 117 reloads among 80 stores)
+            };
+#pragma unroll
+            for (int pr = 0; pr < kRT / 2; ++pr) {
+                put_tile(2 * pr, 0);
+                put_tile(2 * pr + 1, 1);
+                get_tile(2 * pr, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- fused MaxPooling2D(2x2): row pairs (0, 1) and (2, 3) of this wave -> 16 pooled pixels x 32 channels each ----
-            if (!FLAT && A.pool_y) {
+                get_tile(2 * pr + 1, 1);
+                // ---- fused MaxPooling2D(2x2): rows 2 pr, 2 pr + 1 of this wave -> 16 pooled pixels x 32 channels; a lane = one
+                // pooled pixel's octet: the four source pixels' pieces from the two windows (2-way bank conflicts; pool layers only) ----
+                if (!FLAT && A.pool_y) {
+                    float m[8];
 #pragma unroll
-                for (int pr = 0; pr < kRT / 2; ++pr) {
+                    for (int win = 0; win < 2; ++win) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const Prm4 p = load_prm4(jc, q);
-                        float m[4];
+                        for (int d = 0; d < 2; ++d) {
+                            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(2 * opx + d, 2 * oc));
+                            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(2 * opx + d, 2 * oc + 1));
+                            float v[8];
+                            finish8(r0, r1, p, v);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float vmax = fmaxf(affine(acc[2 * pr][j][4 * q + r], p, r), affine(acc[2 * pr + 1][j][4 * q + r], p, r));
-                            const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vmax), 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
-                            m[r] = fmaxf(vmax, other);
-                        }
-                        uint2 hi2, lo2;
-                        split4(m, hi2, lo2);
-                        if (!(px_l & 1)) {
-                            const int pp = (px_l >> 1) + 16 * pr;  // pooled column 0..15 of pair pr -> window pixel 0..31
-                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, q) + 8 * khalf) = hi2;
-                            *reinterpret_cast<uint2 *>(stage + stage_piece(pp, 4 + q) + 8 * khalf) = lo2;
+                            for (int k = 0; k < 8; ++k) m[k] = (win == 0 && d == 0) ? v[k] : fmaxf(m[k], v[k]);
                         }
                     }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int Hp = A.H >> 1, Wp = A.W >> 1;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {  // 32 window pixels x 8 pieces = 256 stores of 16 bytes: four per lane
-                    const int id = t * 64 + lane, px = id >> 3, pos = id & 7;
-                    const int pr = px >> 4, pc = px & 15;
+                    uint4 hi, lo;
+                    split8(m, hi, lo);
+                    const int Hp = A.H >> 1, Wp = A.W >> 1;
                     const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
                     if (yy < Hp) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(stage + px * 128 + pos * 16);
-                        const int p8 = pos ^ ((px >> 1) & 7);
-                        const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + pc;
-                        unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + p8 * 16;
-                        nt_store16(dst, v);
+                        const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + opx;
+                        unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + oc * 16;
+                        nt_store16(dst, hi);
+                        nt_store16(dst + 64, lo);
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // one row pair at a time (left alone, the scheduler piles up the next pairs' window traffic and the addresses spill)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -663,13 +728,34 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
 #endif
+    // (output-only: the fragment sets are dead across the epilogue -- the next item's first step reads f0 after load_frags and fills
+    //  f1 before its second -- but the fill is conditional (pf_), so to the compiler f1's old contents stay live: 64 registers the
+    //  epilogue does not have, paid for with accumulator tiles in scratch and a vmcnt(0) -- every store acknowledged -- per reload)
+    auto kill_frags = [&](Frags &f) {
+#pragma unroll
+        for (int i = 0; i < kRT; ++i) {
+            asm volatile("" : "=v"(f.ah[i]));
+            asm volatile("" : "=v"(f.al[i]));
+        }
+#pragma unroll
+        for (int j = 0; j < kCT; ++j) {
+            asm volatile("" : "=v"(f.bh[j]));
+            asm volatile("" : "=v"(f.bl[j]));
+        }
+    };
     bool more = true;
     if (my_full > 0) {
         load_frags(f0, 0, 0, slot, Full{});  // operands of the very first step
         while (true) {
+            C4_TS(0);
             C4_CHUNKS(Full)
+            C4_TS(3);
+            kill_frags(f0);
+            kill_frags(f1);
             if (!C4_DBG(1)) epilogue(Full{});
+            C4_TS(4);
             more = next_item();
+            if (more) { --cur; C4_TS(5); ++cur; }
             if (!more || cur >= my_full) break;
             load_frags(f0, 0, 0, slot, Full{});  // operands of the new item's first step (landed: see C4_STEP_)
         }
@@ -677,13 +763,45 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     if (more && has_sub) {  // the block's last item: one 32-channel column tile of a leftover item
         load_frags(f0, 0, 0, slot, Sub{});
         C4_CHUNKS(Sub)
+        kill_frags(f0);
+        kill_frags(f1);
         epilogue(Sub{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
+#ifdef QMRI_C4_TIMELINE
+    if (blockIdx.x == 8 && tid == 0 && my_items >= 4) {
+        const unsigned r = atomicAdd(&g_c4_tl_n, 1u);
+        if (r < 256u) {
+            unsigned long long *o = g_c4_tl + r * 16;
+            o[0] = (unsigned long long)CT;
+            o[1] = (unsigned long long)FLAT;
+            o[2] = (unsigned long long)A.chunks;
+            o[3] = (unsigned long long)my_items;
+            for (int it = 0; it < 2; ++it) {
+                const unsigned long long *t = tsbuf + it * 8;
+                for (int k = 0; k < 5; ++k) o[4 + it * 5 + k] = t[k + 1] - t[k];
+            }
+        }
+    }
+#endif
     if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
-static size_t c4_lds_bytes(int ct) { return (size_t)2 * kHBuf + (size_t)kRing * 2048 * ct + kMTile * 4 + (size_t)3 * 32 * ct * 4 + (size_t)kHSlots * kThreads * 4; }
+template <bool FLAT, int CT>
+static constexpr size_t c4_lds_bytes() {
+    using G = C4Geo<FLAT, CT>;
+    size_t n = (size_t)2 * G::HBUF + (size_t)kRing * 2048 * CT + (FLAT ? G::MTILE * 4 : 0) + (size_t)3 * 32 * CT * 4 + (size_t)G::HSLOTS * kThreads * 4;
+#ifdef QMRI_C4_TIMELINE
+    n += 128;
+#endif
+    return n;
+}
+static_assert(c4_lds_bytes<false, 2>() <= 160 * 1024 && c4_lds_bytes<true, 2>() <= 160 * 1024 && c4_lds_bytes<false, 4>() <= 160 * 1024 &&
+                  c4_lds_bytes<true, 4>() <= 160 * 1024,
+              "LDS");
+// tile geometry of a layer on this kernel (host side of C4Geo)
+static int c4_tile_rows(int Cout) { return conv_c4_block_channels(Cout) == 128 ? C4Geo<false, 4>::ROWS : C4Geo<false, 2>::ROWS; }
+static int c4_flat_tile(int Cout) { return conv_c4_block_channels(Cout) == 128 ? C4Geo<true, 4>::MTILE : C4Geo<true, 2>::MTILE; }
 
 // which layers the kernel takes: >= 128 output channels in blocks of 128, 32-channel input chunks, a level it tiles
 int conv_c4_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
@@ -700,10 +818,11 @@ bool conv_c4_supported(const ConvS3Args &k) {
 // number of work items (channel blocks x tiles) of a layer on this kernel: the dispatcher's cost model wants it
 int conv_c4_work_items(const ConvS3Args &k) {
     const int nb = k.Cout / conv_c4_block_channels(k.Cout);
-    if (k.W % 32 == 0) return nb * k.B * (k.W / 32) * ((k.H + 15) / 16);
+    const int rows = c4_tile_rows(k.Cout), mtile = c4_flat_tile(k.Cout);
+    if (k.W % 32 == 0) return nb * k.B * (k.W / 32) * ((k.H + rows - 1) / rows);
     const int P = k.W + 2;
     const long long span = (long long)k.B * (k.H + 1) * P - P;
-    return nb * (int)((span + kMTile - 1) / kMTile);
+    return nb * (int)((span + mtile - 1) / mtile);
 }
 
 // Rounds a layer takes on this kernel with one persistent block per CU, in units of one whole item: the per-XCD ranges of
@@ -726,7 +845,7 @@ double conv_c4_rounds(const ConvS3Args &k, int num_cu) {
 template <bool FLAT, int CT>
 static hipError_t c4_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
     auto fn = conv_c4_kernel<FLAT, CT>;
-    const size_t lds = c4_lds_bytes(CT);
+    constexpr size_t lds = c4_lds_bytes<FLAT, CT>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int grid = k.nwork < num_cu ? k.nwork : num_cu;
@@ -745,15 +864,17 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     if (flat) {
         k.P = k.W + 2;
         const long long span = (long long)k.B * (k.H + 1) * k.P - k.P;
-        k.ntiles = (int)((span + kMTile - 1) / kMTile);
+        const int mtile = c4_flat_tile(k.Cout);
+        k.ntiles = (int)((span + mtile - 1) / mtile);
         k.tiles_x = k.tiles_y = 0;
     } else {
         k.P = kPitch2D;
         k.tiles_x = k.W / 32;
-        k.tiles_y = (k.H + 15) / 16;
+        const int rows = c4_tile_rows(k.Cout);
+        k.tiles_y = (k.H + rows - 1) / rows;
         k.ntiles = k.B * k.tiles_x * k.tiles_y;
     }
-    k.nj = kNJ;
+    k.nj = 0;  // (conv_s3_kernel's field: the halo geometry is C4Geo's here)
     k.nwork = k.nb * k.ntiles;
     static const int split = [] {
         const char *e = std::getenv("QMRI_C4_SPLIT");
@@ -771,3 +892,17 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
 }
 
 }  // namespace qmri
+
+#ifdef QMRI_C4_TIMELINE
+extern "C" int qmri_debug_c4_timeline(unsigned long long *out, int max_records) {
+    unsigned int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(qmri::g_c4_tl_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > 256u) n = 256u;
+    if ((int)n > max_records) n = (unsigned)max_records;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::g_c4_tl), (size_t)n * 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(qmri::g_c4_tl_n), &zero, sizeof(zero));
+    return (int)n;
+}
+#endif

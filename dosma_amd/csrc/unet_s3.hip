@@ -883,10 +883,9 @@ int conv_s3_block_channels(int Cout, int deconv) {
     return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
 }
 
-// Which kernel for a >= 128-channel-block layer?  conv_c4_kernel (unet_c4.hip) issues MFMAs faster but works in items of
-// 512 positions x 128 channels, twice conv_s3_kernel<128>'s: with one persistent block per CU the layer takes
-// ceil(items / CUs) rounds, and a level whose item count leaves the last round mostly empty can lose more to that than the
-// faster kernel gains.  QMRI_C4 = 0 never / 1 by this model (default) / 2 wherever it is supported.
+// Which kernel for a layer both support?  conv_c4_kernel (unet_c4.hip: one wave per SIMD, 4 x 4 or 6 x 2 register tiles) issues
+// MFMAs faster but works in bigger items (512 positions x 128 channels / 768 x 64); QMRI_C4 = 0 never / 1 by the rule below
+// (default) / 2 wherever it is supported.
 bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     static const int mode = [] {
         const char *e = std::getenv("QMRI_C4");
@@ -895,20 +894,18 @@ bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     if (!k.w_c4 || k.c4_mode < 0 || !conv_c4_supported(k)) return false;
     if (k.c4_mode > 0 || mode >= 2) return true;
     if (mode <= 0) return false;
-    // 64-channel blocks: a step is only 24 MFMAs per wave between barriers -- measured 5-10 % SLOWER than conv_s3_kernel<64> on every
-    // 192 x 192 layer of the network (824 / 1407 / 2240 / 1310 us against 742 / 1286 / 2195 / 1221): kept for tests, never picked
-    if (conv_c4_block_channels(k.Cout) != 128) return false;
     // The choice depends on the LAYER only (level geometry and channel counts), never on the batch: the two kernels add the same
     // products in different orders (tap-major against half-chunk-major), and a slice's logits must not depend on how many slices
     // travel with it (tests/test_unet_fullsize_gpu.py::test_forward_is_bitwise_repeatable runs one volume through engines of two
-    // batch sizes).  Per-layer A/B at 160 slices of 384 x 384 (profiles/r04_c4_ab.txt; QMRI_C4 = 0 / 2 alternating on one box):
-    // conv_c4_kernel wins 4-10 % wherever an item has at least 4 input chunks on 16 x 32 image tiles (96 x 96 level: 1074 / 1916 /
-    // 1038 us against 1138 / 2074 / 1072) and at least 8 on the flattened levels (4 chunks: 589 against 582 us); with 2 chunks its
-    // per-item costs -- the epilogue of 16 tiles on ONE wave per SIMD, the halo set-up -- tie it with conv_s3_kernel<128>.
-    const bool flat = k.W % 32 != 0;
-    const int chunks = k.Cin / 32;
+    // batch sizes).  Since conv_c4_kernel's epilogue writes the accumulators to LDS as they are (round 4, profiles/r04_c4_ab.txt)
+    // it wins on every layer it supports -- 128-channel blocks at any depth (2 chunks: 567 against 620 us; flattened, 4 chunks: 533
+    // against 584) and, on 24-row image tiles, the 64-channel layers of the 192 x 192 level (701 / 1165 / 2015 / 1153 us against
+    // 709 / 1234 / 2127 / 1248 for conv_s3_kernel<64>); 16 / 48 slices per forward and the 512 x 512 network: +-0 / +1.3 % / +1.4 %.
+    // Before that its per-item costs tied or lost wherever an item had fewer than 4 (flattened: 8) input chunks.
+    // (64-channel blocks on the FLATTENED levels -- 4 x 2 tiles, 24 MFMAs per k-step -- were 5-10 % slower than conv_s3_kernel<64>
+    //  when last measured and appear in no network of the bench: kept for tests, not picked)
     (void)num_cu;
-    return flat ? chunks >= 8 : chunks >= 4;
+    return !(conv_c4_block_channels(k.Cout) == 64 && k.W % 32 != 0);
 }
 
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {

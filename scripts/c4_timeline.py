@@ -1,0 +1,28 @@
+"""Where conv_c4_kernel's work items spend their time (experiment build: python -m dosma_amd.build --variant tl -DQMRI_C4_TIMELINE;
+run with DOSMA_AMD_LIB=.../libqmri_hip_tl.so): block 8 of every launch timestamps its second and third item (s_memrealtime, 10 ns)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from dosma_amd import _lib as L
+from dosma_amd.models import weights as W
+
+slices = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), 384, 384, max_batch=slices, precision="fp16x3")
+dev = torch.device("cuda", 0)
+x = torch.randn((slices, 384, 384), device=dev)
+logits = torch.empty((slices, 384, 384, 4), device=dev)
+mask = torch.empty((slices, 384, 384, 4), device=dev, dtype=torch.uint8)
+st = torch.cuda.current_stream().cuda_stream
+lib = ctypes.CDLL(os.environ["DOSMA_AMD_LIB"])
+buf = (ctypes.c_ulonglong * (256 * 16))()
+for rep in range(2):
+    eng.forward_device(x.data_ptr(), slices, logits.data_ptr(), mask.data_ptr(), whiten=True, stream=st)
+    torch.cuda.synchronize()
+    n = lib.qmri_debug_c4_timeline(buf, 256)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16)[:n].astype(np.int64)
+print("per launch (the forward's c4 layers in order), 10 ns ticks; item 2 | item 3: steps 0-2, first wait, rest of K, epilogue, next_item")
+for r in a:
+    ct, flat, chunks, items = r[:4]
+    print(f"CT {ct} flat {flat} chunks {chunks:2d} items {items:3d} | " + " ".join(f"{v:6d}" for v in r[4:9]) + " | " + " ".join(f"{v:6d}" for v in r[9:14])
+          + f"   per step {r[6] / (18 * chunks - 3) / 100:.3f} us")

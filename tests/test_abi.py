@@ -170,13 +170,15 @@ def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
     assert sum("global_load_lds_dwordx4" in ln or ("buffer_load_dwordx4" in ln and ln.rstrip().endswith("lds")) for ln in lines) >= min_dma
 
 
-def test_conv_c4_main_loop_has_no_scratch_traffic(tmp_path):
+def test_conv_c4_kernel_has_no_scratch_traffic(tmp_path):
     """conv_c4_kernel keeps DMA requests in flight across steps and waits for them with COUNTED s_waitcnt vmcnt(N).  A register
-    the allocator spills inside the main loop comes back through scratch_load -- a vector-memory load hipcc waits for with
-    vmcnt(0), i.e. for every request in flight (this happened with the tap-offset table, the halo offsets and the store
-    addresses: DESIGN 6.4).  Guard: in the generated gfx950 code of the 128-channel instantiations, no barrier interval that
-    holds a main-loop share of MFMAs (three steps = 144) contains a scratch access, and none but the one with the per-item halo
-    set-up (divisions: exec-masked branches; its reload waits were measured at +-0) a vmcnt(0)."""
+    the allocator spills comes back through scratch_load -- a vector-memory load hipcc waits for with vmcnt(0), i.e. for every
+    request in flight and every global store not yet acknowledged (this happened with the tap-offset table, the halo offsets, the
+    store addresses, and -- until the accumulators left the register file raw, through ds_write from AccVGPRs -- with six
+    accumulator tiles per epilogue: DESIGN 6.4).  Guard on the generated gfx950 code of all four instantiations: no scratch
+    access anywhere, no v_accvgpr_read (the epilogue must not pull accumulators through ArchVGPRs), and in the barrier
+    intervals that hold a main-loop share of MFMAs (three steps) no vmcnt(0) except in the one with the per-item halo set-up
+    (divisions: exec-masked branches; its waits were measured at +-0)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
@@ -185,22 +187,26 @@ def test_conv_c4_main_loop_has_no_scratch_traffic(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
                            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "dosma_amd", "csrc"), src, "-o", str(out)])
     text = out.read_text()
-    checked = pure = 0
-    for flat in ("Lb1", "Lb0"):
-        name = f"_ZN4qmri14conv_c4_kernelI{flat}ELi4EEEvNS_10ConvS3ArgsE"
+    # (instantiation, MFMAs of three steps): 4 x 4 tiles x 3 products x 3 steps = 144; 4 x 2 -> 72; 6 x 2 (image tiles, 64 channels) -> 108
+    for flat, ct, per_interval in (("Lb1", 4, 144), ("Lb0", 4, 144), ("Lb1", 2, 72), ("Lb0", 2, 108)):
+        name = f"_ZN4qmri14conv_c4_kernelI{flat}ELi{ct}EEEvNS_10ConvS3ArgsE"
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
+        all_lines = [ln.strip() for ln in body.splitlines()]
+        assert not any(ln.startswith("scratch_") for ln in all_lines), (name, [ln for ln in all_lines if ln.startswith("scratch_")][:3])
+        assert not any(ln.startswith("v_accvgpr_read") for ln in all_lines), name
+        assert any(ln.startswith("ds_write_b128") and ", a[" in ln for ln in all_lines) or ct == 2, name  # accumulators go to LDS as they are
+        checked = pure = 0
         for interval in body.split("s_barrier"):
             lines = [ln.strip() for ln in interval.splitlines()]
             mfma = sum(ln.startswith("v_mfma") for ln in lines)
             stores = sum(ln.startswith("global_store") for ln in lines)
-            if mfma >= 135 and stores == 0:  # a main-loop interval (144 MFMAs; the last one of an item runs into the epilogue and holds fewer)
+            if mfma >= per_interval - 9 and stores == 0:  # a main-loop interval (the last one of an item runs into the epilogue)
                 checked += 1
-                assert not any(ln.startswith("scratch_") for ln in lines), (flat, [ln for ln in lines if ln.startswith("scratch_")][:3])
                 if not any(ln.startswith("s_cbranch_execz") for ln in lines):  # (a pure step interval)
                     pure += 1
-                    assert not any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in lines), flat
-    assert checked >= 8 and pure >= 6, (checked, pure)  # (two instantiations x >= 4 of the 6 intervals of a chunk)
+                    assert not any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in lines), name
+        assert checked >= 4 and pure >= 3, (name, checked, pure)  # (>= 4 of the 6 intervals of a chunk)
 
 
 def test_conv_c4_lds_layouts_are_bank_conflict_free():

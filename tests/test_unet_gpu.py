@@ -82,8 +82,11 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     (64, 256, (24, 24), 3),     # flattened, tiles straddle images
     (256, 128, (12, 12), 7),    # flattened 12 x 12 (the 384-pixel network's deepest level), 8 chunks
     (128, 384, (5, 6), 2),      # flattened, less than one tile, three channel blocks
-    (32, 64, (32, 64), 3),      # 64-channel blocks (CT = 2): one chunk
-    (128, 64, (16, 32), 4),     # 64-channel block, four chunks
+    (32, 64, (32, 64), 3),      # 64-channel blocks (CT = 2; image tiles of 24 rows): one chunk, second tile row partial
+    (128, 64, (16, 32), 4),     # 64-channel block, four chunks, less than one tile row
+    (64, 64, (48, 32), 2),      # 64-channel block, two whole tile rows
+    (64, 64, (50, 96), 2),      # three tile rows, the last with 2 of 24 rows inside the image
+    (32, 64, (24, 32), 264),    # 64-channel blocks with a channel-split last round (two 32-channel sub-items per leftover item)
     (64, 192, (30, 46), 2),     # 64-channel blocks x 3, flattened
     # more work items than CUs, with a short last round: 264 items -> 33 per XCD on 32 blocks = one round + 1 leftover item per
     # XCD, which runs as four 32-channel sub-items (the channel-split last round); flattened: 285 tiles -> 36 per XCD, 4 leftover

@@ -212,8 +212,14 @@ __device__ unsigned int g_c4_tl_n;
     do {                                                                                             \
         if (blockIdx.x == 8 && tid == 0 && cur >= 1 && cur <= 2) tsbuf[(cur - 1) * 8 + (k)] = wall_clock64(); \
     } while (0)
+#if QMRI_C4_TIMELINE >= 2  // (timestamps inside the first barrier interval too: they disturb the steps they sit in)
+#define C4_TS_STEP(k) C4_TS(k)
+#else
+#define C4_TS_STEP(k)
+#endif
 #else
 #define C4_TS(k)
+#define C4_TS_STEP(k)
 #endif
 
 template <bool FLAT, int CT>
@@ -495,9 +501,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         /* every MFMA group opens with an MFMA; its reads (4 while column tiles are left, 2 after) ride one per MFMA behind it */ \
         c4_sched_step<0, kRT, (SUB::value ? 1 : kCT)>();                                                           \
         constexpr int kN_ = c4_in_flight((T), kWPieces, kHSlots);                                                  \
-        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS(1); }                                          \
+        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS_STEP(1); }                                     \
         if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) C4_WAIT(kN_); \
-        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS(2); }                                          \
+        if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS_STEP(2); }                                     \
         slot = (slot + 1) & (kRing - 1);                                                                           \
     }
 #define C4_STEP(H, T, CUR, NXT, SUB) C4_STEP_(H, T, CUR, NXT, std::false_type, SUB)
@@ -570,14 +576,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         // register allocator move its whole live range into ArchVGPRs at the epilogue's entry (160 v_accvgpr_read in a row, six
         // tiles to SCRATCH, every reload behind s_waitcnt vmcnt(0) = behind the acknowledgement of all stores issued so far).
         // ds_write takes AccVGPR data: four 16-byte pieces (4 channels, fp32) per lane go to a wave-private 4 KB window
-        // [32 pixels][128 B], piece g = 2 q + khalf of pixel p at position g ^ ((p >> 1) & 7) (conflict-free both ways), and come
+        // [32 pixels][128 B], piece g = 2 q + khalf of pixel p at a swizzled position (conflict-free both ways), and come
         // back pixel-major: task t = 0, 1 of a lane = pixel 16 t + (lane >> 2), channel octet lane & 3 -- 8 values -> bias, ReLU,
         // BatchNormalization affine, split -> one 16-byte piece of the hi plane and one of the lo plane of the pixel's 128-byte
         // record.  A lane's octet is the same for every tile of a column tile: its 24 parameters are fetched once.
         // Two windows per wave: the tiles of a row pair are written back to back, so the second write and both read-backs overlap
         // the first tile's arithmetic, and the fused 2 x 2 max-pool finds both rows staged.
         const int oc = lane & 3, opx = lane >> 2;
-        auto piece_off = [&](int px, int g) -> int { return px * 128 + ((g ^ ((px >> 1) & 7)) * 16); };
+        // (ds_write_b128 is served in groups of 8 contiguous lanes over 8 slots of 16 B, ds_read_b128 in the guide's groups of 16 over
+        //  16 slots: this swizzle is conflict-free for the writes, the read-back and -- with the pixel parity swapped in every other
+        //  group of 16 lanes -- the pooling reads; scripts/lds_bank_check.py)
+        auto piece_off = [&](int px, int g) -> int { return px * 128 + ((g ^ (((px & 1) << 2) | ((px >> 1) & 3))) * 16); };
         struct Prm8 {
             f32x4 b[2], s[2], t[2];
         };
@@ -596,12 +605,30 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
             lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
         };
+        // The row pairs of all column tiles form ONE software pipeline: pair u + 1 is written to the windows right after pair u's
+        // read-back has been issued (LDS instructions of a wave execute in order), so its write and the read-back's latency run
+        // under pair u's arithmetic and stores instead of in front of every pair.
+        constexpr int kJ = kSub ? 1 : kCT, kNP = kRT / 2, kU = kJ * kNP;
+        auto put_tile = [&](int i, int j, int win) {
 #pragma unroll
-        for (int j = 0; j < (kSub ? 1 : kCT); ++j) {
+            for (int q = 0; q < 4; ++q) {
+                const f32x16 &a = acc[i][j];
+                const f32x4 piece = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                *reinterpret_cast<f32x4 *>(stage + win * 4096 + piece_off(px_l, 2 * q + khalf)) = piece;
+            }
+        };
+        auto put_pair = [&](int u) {
+            put_tile(2 * (u % kNP), u / kNP, 0);
+            put_tile(2 * (u % kNP) + 1, u / kNP, 1);
+        };
+        put_pair(0);
+        Prm8 p;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int j = u / kNP, pr = u % kNP;
             const int jc = kSub ? sub_cq : j;
             const int cbase = n0 + jc * 32;
-            Prm8 p;
-            {
+            if (pr == 0) {
                 const float *pp = prm + jc * 32 + 8 * oc;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -610,31 +637,43 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                     p.t[h] = *reinterpret_cast<const f32x4 *>(pp + 2 * kBN + 4 * h);
                 }
             }
-            auto put_tile = [&](int i, int win) {
+            // (addresses are rebuilt per pair from a scalar row pointer + a small per-lane offset of a lane index made opaque HERE:
+            //  as loop invariants of the epilogue they get spilled and every store waits for a scratch reload)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int oc_t = lane_t & 3, opx_t = lane_t >> 2;
+            const bool pool = !FLAT && A.pool_y;
+            // ---- read-back of the pair (+ the pooling reads: a lane = one pooled pixel's octet, the four source pixels' pieces) ----
+            f32x4 r[2][2][2], rp[2][2][2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x16 &a = acc[i][j];
-                    const f32x4 piece = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-                    *reinterpret_cast<f32x4 *>(stage + win * 4096 + piece_off(px_l, 2 * q + khalf)) = piece;
-                }
-            };
-            auto get_tile = [&](int i, int win) {
-                // (addresses are rebuilt per tile from a scalar row pointer + a small per-lane offset of a lane index made opaque HERE:
-                //  as loop invariants of the epilogue they get spilled and every store waits for a scratch reload)
-                int lane_t = lane;
-                asm volatile("" : "+v"(lane_t));
-                const int oc_t = lane_t & 3, opx_t = lane_t >> 2;
-                f32x4 r[2][2];
+            for (int win = 0; win < 2; ++win) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) r[t][h] = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(t * 16 + opx_t, 2 * oc_t + h));
+                    for (int h = 0; h < 2; ++h) r[win][t][h] = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(t * 16 + opx_t, 2 * oc_t + h));
                 }
+            }
+            if (pool) {
+                const int dsw = (lane_t >> 4) & 1;  // (which of the two columns a lane reads first: see piece_off)
+#pragma unroll
+                for (int win = 0; win < 2; ++win) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) rp[win][d][h] = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(2 * opx_t + (d ^ dsw), 2 * oc_t + h));
+                    }
+                }
+            }
+            if (u + 1 < kU) put_pair(u + 1);
+            // ---- the pair's two tiles: bias, ReLU, affine, saturation tracking, split, stores ----
+#pragma unroll
+            for (int win = 0; win < 2; ++win) {
+                const int i = 2 * pr + win;
                 uint4 hi[2], lo[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float v[8];
-                    finish8(r[t][0], r[t][1], p, v);
+                    finish8(r[win][t][0], r[win][t][1], p, v);
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) amax = fmaxf(fmaxf(amax, fabsf(v[k])), fabsf(v[k + 1]));
                     asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps every value alive until then)
@@ -666,44 +705,33 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                         }
                     }
                 }
-            };
+            }
+            // ---- fused MaxPooling2D(2x2): rows 2 pr, 2 pr + 1 of this wave -> 16 pooled pixels x 32 channels ----
+            if (pool) {
+                float m[8];
 #pragma unroll
-            for (int pr = 0; pr < kRT / 2; ++pr) {
-                put_tile(2 * pr, 0);
-                put_tile(2 * pr + 1, 1);
-                get_tile(2 * pr, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                get_tile(2 * pr + 1, 1);
-                // ---- fused MaxPooling2D(2x2): rows 2 pr, 2 pr + 1 of this wave -> 16 pooled pixels x 32 channels; a lane = one
-                // pooled pixel's octet: the four source pixels' pieces from the two windows (2-way bank conflicts; pool layers only) ----
-                if (!FLAT && A.pool_y) {
-                    float m[8];
+                for (int win = 0; win < 2; ++win) {
 #pragma unroll
-                    for (int win = 0; win < 2; ++win) {
+                    for (int d = 0; d < 2; ++d) {
+                        float v[8];
+                        finish8(rp[win][d][0], rp[win][d][1], p, v);
 #pragma unroll
-                        for (int d = 0; d < 2; ++d) {
-                            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(2 * opx + d, 2 * oc));
-                            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(stage + win * 4096 + piece_off(2 * opx + d, 2 * oc + 1));
-                            float v[8];
-                            finish8(r0, r1, p, v);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) m[k] = (win == 0 && d == 0) ? v[k] : fmaxf(m[k], v[k]);
-                        }
-                    }
-                    uint4 hi, lo;
-                    split8(m, hi, lo);
-                    const int Hp = A.H >> 1, Wp = A.W >> 1;
-                    const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
-                    if (yy < Hp) {
-                        const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + opx;
-                        unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + oc * 16;
-                        nt_store16(dst, hi);
-                        nt_store16(dst + 64, lo);
+                        for (int k = 0; k < 8; ++k) m[k] = (win == 0 && d == 0) ? v[k] : fmaxf(m[k], v[k]);
                     }
                 }
-                // one row pair at a time (left alone, the scheduler piles up the next pairs' window traffic and the addresses spill)
-                __builtin_amdgcn_sched_barrier(0);
+                uint4 hi, lo;
+                split8(m, hi, lo);
+                const int Hp = A.H >> 1, Wp = A.W >> 1;
+                const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
+                if (yy < Hp) {
+                    const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + opx_t;
+                    unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + oc_t * 16;
+                    nt_store16(dst, hi);
+                    nt_store16(dst + 64, lo);
+                }
             }
+            // one row pair at a time (left alone, the scheduler piles up the next pairs' window traffic and the addresses spill)
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // between two items: geometry and epilogue parameters of the next one, and everyone done with the staging windows (the next
@@ -779,7 +807,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             o[3] = (unsigned long long)my_items;
             for (int it = 0; it < 2; ++it) {
                 const unsigned long long *t = tsbuf + it * 8;
-                for (int k = 0; k < 5; ++k) o[4 + it * 5 + k] = t[k + 1] - t[k];
+                o[4 + it * 5 + 0] = t[3] - t[0];  // the item's k loop
+                o[4 + it * 5 + 1] = t[4] - t[3];  // epilogue
+                o[4 + it * 5 + 2] = t[5] - t[4];  // next_item
+                o[4 + it * 5 + 3] = t[1] - t[0];  // (QMRI_C4_TIMELINE >= 2: the first three steps, and their counted wait + barrier)
+                o[4 + it * 5 + 4] = t[2] - t[1];
             }
         }
     }

@@ -21,8 +21,8 @@ for rep in range(2):
     torch.cuda.synchronize()
     n = lib.qmri_debug_c4_timeline(buf, 256)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16)[:n].astype(np.int64)
-print("per launch (the forward's c4 layers in order), 10 ns ticks; item 2 | item 3: steps 0-2, first wait, rest of K, epilogue, next_item")
+print("per launch (the forward's c4 layers in order), microseconds; item 2 | item 3: k loop, epilogue, next_item")
 for r in a:
     ct, flat, chunks, items = r[:4]
-    print(f"CT {ct} flat {flat} chunks {chunks:2d} items {items:3d} | " + " ".join(f"{v:6d}" for v in r[4:9]) + " | " + " ".join(f"{v:6d}" for v in r[9:14])
-          + f"   per step {r[6] / (18 * chunks - 3) / 100:.3f} us")
+    print(f"CT {ct} flat {flat} chunks {chunks:2d} items {items:3d} | " + " ".join(f"{v / 100:7.2f}" for v in r[4:7]) + " | " + " ".join(f"{v / 100:7.2f}" for v in r[9:12])
+          + f"   per step {(r[4] + r[9]) / 2 / (18 * chunks) / 100:.3f} us, epilogue + next_item = {(r[5] + r[6] + r[10] + r[11]) / 2 / 100:.2f} us = {(r[5] + r[6] + r[10] + r[11]) / (r[4] + r[9] + r[5] + r[6] + r[10] + r[11]) * 100:.1f} % of the item")

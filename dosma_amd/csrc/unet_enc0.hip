@@ -9,8 +9,10 @@
 // as the halo image of the second convolution in LDS and the pooled map is made from the staged output tile: 0.1 GB in
 // (the image), 3.75 GB out.
 //
-// One persistent block of 8 waves per CU; a tile is 8 rows x 32 columns of one slice.  (Two 4-wave blocks per CU with 4 x 32 tiles
-// -- one block's MFMA loop beside the other's VALU phases -- measured 1.79 instead of 1.63 ms: 1.59 x halo instead of 1.33 x.)
+// One persistent block of 8 waves per CU = TWO GROUPS of 4 waves (one per SIMD each), each working on its own tile of 8 rows x 32
+// columns (a wave: two rows), half a tile period apart: while one group multiplies (conv 2), the other does the vector work of
+// its tile on the same SIMDs (enc0_kernel's main loop has the details and what was measured).  (Two 4-wave blocks per CU with
+// 4 x 32 tiles measured 1.79 instead of 1.63 ms: 1.59 x halo instead of 1.33 x; with 8 x 32 tiles they need 2 x 82.1 KB of LDS.)
 // Per tile:
 //   patch   12 x 36 input pixels (prefetched into registers during the previous tile's MFMA loop)           -> LDS
 //   conv 1  on the 10 x 34 halo, as MFMA too: K = 16 = nine taps + a constant-one tap that carries the bias, operands
@@ -20,8 +22,9 @@
 //           request stream, no counted waits); A = weights, B = pixels, so that a lane of the accumulator tile holds
 //           ONE pixel and a register one channel
 //   out     bias, ReLU, BatchNorm affine, split; [pixel][hi 64 B | lo 64 B] image through a wave window in LDS (eight 8-byte
-//           writes per lane instead of thirty-two 2-byte ones); 128-byte pixel-chunk stores of the skip tensor; waves 4-7
-//           (which had one halo group of conv 1, not two) pool the staged tile 2 x 2 and store the next level's input
+//           writes per lane instead of thirty-two 2-byte ones) -- the windows lie IN the group's halo image, dead by then;
+//           128-byte pixel-chunk stores of the skip tensor; each wave pools its two staged rows 2 x 2 and stores a row of the
+//           next level's input
 //
 // The same file holds the two other 32-channel layers of the top level: mid0_kernel (Conv2D 64 -> 32) and out0_kernel (last
 // convolution + classifier).
@@ -37,15 +40,20 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) __fp16 h16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kWaves = 8;               // = rows of a tile
+constexpr int kRows = 8;                // rows of a tile (x 32 columns)
+constexpr int kGW = 4;                  // waves of a GROUP (one per SIMD): a wave owns two rows of its group's tile
+constexpr int kWaves = 2 * kGW;         // two groups per block, half a tile period apart (see enc0_kernel)
 constexpr int kThreads = kWaves * 64;
-constexpr int kPitch = 34;              // halo row pitch of the kWaves x 32 tile
-constexpr int kHalo = (kWaves + 2) * kPitch;       // halo pixels
+constexpr int kGThreads = kGW * 64;
+constexpr int kPitch = 34;              // halo row pitch of the kRows x 32 tile
+constexpr int kHalo = (kRows + 2) * kPitch;        // halo pixels
 constexpr int kGroups = (kHalo + 31) / 32;         // 32-pixel groups of the first convolution (the last one is partly empty)
 constexpr int kHaloBytes = kHalo * 128;
-constexpr int kPatchW = 36, kPatchH = kWaves + 4;
+constexpr int kPatchW = 36, kPatchH = kRows + 4;
+constexpr int kPatchFloats = kPatchW * (kPatchH + 1);  // (+ a row: the discarded pixels of the last conv 1 group read past the patch)
 constexpr int kWBytes = 9 * 4096;       // conv 2 weights: [tap][plane][32 channels][64 B], conv_s3_kernel's slot image
-constexpr int kStageBytes = kWaves * 4096;
+constexpr int kSplitM = 8;              // conv 2's 18 half-steps run as [0, kSplitM) | barrier | [kSplitM, 18): see enc0_kernel
+static_assert(kGW * 8192 <= kHaloBytes, "a group's staging windows (two rows per wave) live in its halo image");
 
 // LDS position of the 16-byte piece (plane, q = channels 8 q .. 8 q + 7) of halo pixel hp
 __device__ __forceinline__ int halo_off(int hp, int plane, int q) {
@@ -56,9 +64,12 @@ __device__ __forceinline__ int stage_off(int px, int p8) { return px * 128 + ((p
 
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
     const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
     hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    // a - float(hi part), one v_fma_mix_f32 each (a * 1.0 - hi: a single rounding like the subtraction; hipcc emits v_cvt_f32_f16 + v_sub_f32)
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(a), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(b), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
 }
 // the same, tracking max |value| for the saturation flag of the split layout (qmri_internal.h: ConvS3Args::sat)
 __device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo, float &amax) {
@@ -85,14 +96,16 @@ __device__ unsigned long long enc0_tstat[8];  // cycles of wave 0: [0] MFMA loop
 
 __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *wlds = smem;                         // conv 2 weights
-    unsigned char *halo = wlds + kWBytes;               // conv 1 output on the halo
-    unsigned char *stage = halo + kHaloBytes;           // output tile, one 4 KB window per wave
-    float *patch = reinterpret_cast<float *>(stage + kStageBytes);  // [12][36] input pixels
+    unsigned char *wlds = smem;                         // conv 2 weights (both groups)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / kGW, wg = wave % kGW;        // group, wave of the group (a workgroup's waves 0-3 and 4-7 each cover the four SIMDs)
+    const int gtid = tid & (kGThreads - 1);
+    unsigned char *halo = wlds + kWBytes + grp * kHaloBytes;                                              // this group's conv 1 output on the halo
+    float *patch = reinterpret_cast<float *>(wlds + kWBytes + 2 * kHaloBytes) + grp * kPatchFloats;      // its [12][36] input pixels
+    unsigned char *win0 = halo + wg * 8192;             // this wave's two staging windows (rows 2 wg, 2 wg + 1): IN the halo image, dead by then
     const int l31 = lane & 31, kgrp = lane >> 5;
     float amax = 0.f;  // max |v| of everything this lane split (input pixels, both feature maps): Enc0Args::sat
 
@@ -113,25 +126,40 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     }
     // conv 2, A operand (weights): byte offset of this lane's piece inside a tap image, k-step 0 (k-step 1: ^ 32; lo: + 2048)
     const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
-    // conv 2, B operand (pixels): halo pixel of this lane's output pixel for tap (0, 0): row wave, column l31
-    const int hp0 = (wave + 1) * kPitch + l31 + 1;
-    int boff[9];
+    // conv 2, B operand (pixels): halo pixel of this lane's output pixel for tap (0, 0): rows 2 wg + r, column l31
+    int boff[2][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) boff[t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
+    for (int r = 0; r < 2; ++r) {
+        const int hp0 = (2 * wg + r + 1) * kPitch + l31 + 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) boff[r][t] = halo_off(hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1), 0, kgrp);
+    }
 
-    const int tiles_x = A.W / 32, tiles_y = A.H / kWaves;
+    const int tiles_x = A.W / 32, tiles_y = A.H / kRows;
     const int per_img = tiles_x * tiles_y;
     const int ntiles = A.B * per_img;
     auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
         b = t / per_img;
         const int r = t - b * per_img;
         const int ty = r / tiles_x;
-        y0 = ty * kWaves;
+        y0 = ty * kRows;
         x0 = (r - ty * tiles_x) * 32;
     };
-    // pixel i of the (kWaves + 4) x 36 input patch of a tile, zero outside the slice (a thread owns pixels tid and tid + kThreads)
+    // XCD x (= blockIdx % 8: its own L2) walks a CONTIGUOUS eighth of the tiles, its CUs side by side in it: neighbouring tiles share
+    // halo rows / columns through that L2 instead of fetching them from HBM once per XCD
+    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * per + (blockIdx.x >> 3);
+        t_stride = gridDim.x >> 3;
+        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    }
+    if (t_first >= t_end) return;
+    const int n_blk = (t_end - t_first + t_stride - 1) / t_stride;  // tiles of this block: the groups take them alternately
+    const int gstride = 2 * t_stride;
+    // pixel i of the (kRows + 4) x 36 input patch of a tile, zero outside the slice (a thread owns pixels gtid and gtid + kGThreads)
     auto load_patch = [&](int t, int i) -> float {
-        if (t >= ntiles || i >= kPatchW * kPatchH) return 0.f;
+        if (t >= t_end || i >= kPatchW * kPatchH) return 0.f;
         int b, y0, x0;
         tile_origin(t, b, y0, x0);
         const int r = i / kPatchW, c = i - r * kPatchW;
@@ -139,15 +167,15 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         if ((unsigned)yy >= (unsigned)A.H || (unsigned)xx >= (unsigned)A.W) return 0.f;
         return A.x[((long long)b * A.H + yy) * A.W + xx];
     };
-    static_assert(kPatchW * kPatchH <= 2 * kThreads, "two patch pixels per thread");
+    static_assert(kPatchW * kPatchH <= 2 * kGThreads, "two patch pixels per thread");
     auto store_patch = [&](float v0, float v1) {
-        patch[tid] = v0;
-        if (tid + kThreads < kPatchW * kPatchH) patch[tid + kThreads] = v1;
+        patch[gtid] = v0;
+        if (gtid + kGThreads < kPatchW * kPatchH) patch[gtid + kGThreads] = v1;
     };
     // conv 1 on one group of 32 consecutive halo pixels -> halo image
     auto conv1_group = [&](int g, int y0, int x0) {
         const int hp = g * 32 + l31;
-        const int r = hp / kPitch, c = hp - r * kPitch;  // halo row / column (pixels beyond the halo: r = kWaves + 2, discarded)
+        const int r = hp / kPitch, c = hp - r * kPitch;  // halo row / column (pixels beyond the halo: r = kRows + 2, discarded)
         float tp[8];
         if (kgrp == 0) {  // taps 0..7: (r + dy, c + dx) of the patch, whose origin is (y0 - 2, x0 - 2)
             const float *p = patch + r * kPatchW + c;
@@ -155,7 +183,7 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
             tp[3] = p[kPatchW]; tp[4] = p[kPatchW + 1]; tp[5] = p[kPatchW + 2];
             tp[6] = p[2 * kPatchW]; tp[7] = p[2 * kPatchW + 1];
         } else {          // tap 8, the constant-one tap of the bias, six zeros
-            tp[0] = r < kWaves + 2 ? patch[(r + 2) * kPatchW + c + 2] : 0.f;
+            tp[0] = r < kRows + 2 ? patch[(r + 2) * kPatchW + c + 2] : 0.f;
             tp[1] = 1.f;
 #pragma unroll
             for (int i = 2; i < 8; ++i) tp[i] = 0.f;
@@ -184,162 +212,173 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
         }
     };
 
-    // XCD x (= blockIdx % 8: its own L2) walks a CONTIGUOUS eighth of the tiles, its CUs side by side in it: neighbouring tiles share
-    // halo rows / columns through that L2 instead of fetching them from HBM once per XCD
-    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
-    if ((gridDim.x & 7) == 0) {
-        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
-        t_first = xcd * per + (blockIdx.x >> 3);
-        t_stride = gridDim.x >> 3;
-        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    // (the discarded pixels of the last conv 1 group read one row past the patch: their products go nowhere, but their operands
+    //  enter the saturation tracking -- that row is zero, not whatever the previous kernel left in LDS)
+    if (gtid < kPatchW) patch[kPatchW * kPatchH + gtid] = 0.f;
+    // ---- prologue: patch and conv 1 of each group's first tile ----
+    int cur = t_first + grp * t_stride;  // the tile whose halo image this group holds
+    int t_b = 0, t_y0 = 0, t_x0 = 0;
+    if (cur < t_end) {
+        tile_origin(cur, t_b, t_y0, t_x0);
+        store_patch(load_patch(cur, gtid), load_patch(cur, gtid + kGThreads));
     }
-    int tile = t_first;
-    if (tile >= t_end) return;
-    int t_b, t_y0, t_x0;
-    tile_origin(tile, t_b, t_y0, t_x0);
-    // prologue: patch and conv 1 of the first tile
-    store_patch(load_patch(tile, tid), load_patch(tile, tid + kThreads));
     __syncthreads();
-    for (int g = wave; g < kGroups; g += kWaves) conv1_group(g, t_y0, t_x0);
+    if (cur < t_end)
+        for (int g = wg; g < kGroups; g += kGW) conv1_group(g, t_y0, t_x0);
     __syncthreads();
 
-#ifdef QMRI_S3_EXPERIMENTS
-    unsigned long long tmark = __builtin_amdgcn_s_memtime();
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (registers: one atomic per block at the very end)
-#endif
-    while (true) {
-        const int next = tile + t_stride;
-        const float pn0 = load_patch(next, tid), pn1 = load_patch(next, tid + kThreads);  // in flight during the MFMA loop
-
-        // ---------------- conv 2: kWaves x 32 pixels x 32 channels, K = 9 taps x 32 ----------------
-        // Software pipeline, spelled out for the scheduler (hipcc's own order is read, wait for it, multiply): the four
-        // operands of half-step h + 2 are read while the three MFMAs of half-step h run, two reads per MFMA gap.
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        struct Frag {
-            f16x8 wh, wl, xh, xl;
-        };
-        auto load_frag = [&](Frag &f, int t, int kk) {
-            const unsigned char *wt = wlds + t * 4096 + (woff ^ (kk * 32));
-            const int o = boff[t] ^ (kk * 32);
-            f.wh = *reinterpret_cast<const f16x8 *>(wt);
-            f.xh = *reinterpret_cast<const f16x8 *>(halo + o);
-            f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
-            f.xl = *reinterpret_cast<const f16x8 *>(halo + (o ^ 64));
-        };
-        auto mma = [&](const Frag &f) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl, f.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xl, acc, 0, 0, 0);
-        };
-#define ENC0_PIPE()                                     \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        Frag f[3];  // half-step h (tap h / 2, k-step h % 2) lives in f[h % 3]; its operands are read two half-steps ahead
-        load_frag(f[0], 0, 0);
-        load_frag(f[1], 0, 1);
-        __builtin_amdgcn_sched_barrier(0);  // the head start stays a head start: the groups below count from here
+    // ---- THE TWO GROUPS TAKE TURNS ON THE MATRIX PIPES ----
+    // Time runs in half-periods h = 0, 1, ...; in half-period h group h & 1 multiplies its tile (conv 2: 108 MFMAs per wave, a
+    // wave alone on its SIMD's matrix pipe) while the OTHER group, on the same four SIMDs, does everything that is not conv 2 for
+    // the tile it multiplied in the half-period before: output arithmetic, staging, skip stores, pooling, then conv 1 of its next
+    // tile.  Both branches hold two s_barriers -- the block's waves arrive at the same barriers from different code: group-local
+    // hand-overs (halo image complete / staging windows read) ride on them, the groups share nothing but the weights.
+    // Measured (160 slices of 384 x 384, same box, alternating): 1.64-1.70 ms against 1.71-1.79 for the block of eight waves in
+    // ONE phase at a time (MfmaUtil 0.42) -- 4.5 %, not the 40 % the MFMA share promises: the vector work of a tile (~930
+    // instructions per wave, LDS round trips between them) takes a lone wave per SIMD 2.4 x its multiply phase, and LDS time --
+    // operand reads at 1.0 per MFMA + staging + halo image, ~3.8 k cycles per tile -- is not far below the period.  Also tried:
+    // three slots (M | O | C: two vector phases on one SIMD just add, 1.72-1.77 ms); two groups of EIGHT waves (16 per block, 112
+    // registers, parameters and conv 1 operands from LDS: 1.33 reads per MFMA, no faster).  The outputs are bit-identical to the
+    // one-phase kernel's (scripts/unet_bits.py).
+    f32x16 acc[2];
+    float pn0 = 0.f, pn1 = 0.f;
+    bool pending = false;  // an output tile waits in acc
+    for (int h = 0; h <= n_blk; ++h) {
+        if ((h & 1) == grp) {
+            // ================= conv 2 of tile `cur`: 2 rows x 32 pixels x 32 channels per wave, K = 9 taps x 32 =================
+            if (cur < t_end) {
+                const int next = cur + gstride;
+                pn0 = load_patch(next, gtid), pn1 = load_patch(next, gtid + kGThreads);  // in flight during the MFMA loop
+                // Software pipeline, spelled out for the scheduler (hipcc's own order is read, wait for it, multiply): the six
+                // operands of half-step s + 2 are read while the six MFMAs of half-step s run, one read per MFMA gap.
+                struct Frag {
+                    f16x8 wh, wl, xh[2], xl[2];
+                };
+                auto load_frag = [&](Frag &f, int t, int kk) {
+                    const unsigned char *wt = wlds + t * 4096 + (woff ^ (kk * 32));
+                    f.wh = *reinterpret_cast<const f16x8 *>(wt);
+                    f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
 #pragma unroll
-        for (int h = 0; h < 18; ++h) {
-            if (h + 2 < 18) load_frag(f[(h + 2) % 3], (h + 2) / 2, (h + 2) % 2);
-            mma(f[h % 3]);
-            ENC0_PIPE()
-        }
-#undef ENC0_PIPE
-        ENC0_T(0)
-        S_BARRIER();  // A: every wave is done with the halo image (and with the staging windows of the previous tile)
-
-        ENC0_T(1)
-        // ---------------- output: bias, ReLU, BatchNorm, split, staged image ----------------
-        store_patch(pn0, pn1);
-        unsigned char *win = stage + wave * 4096;
+                    for (int r = 0; r < 2; ++r) {
+                        const int o = boff[r][t] ^ (kk * 32);
+                        f.xh[r] = *reinterpret_cast<const f16x8 *>(halo + o);
+                        f.xl[r] = *reinterpret_cast<const f16x8 *>(halo + (o ^ 64));
+                    }
+                };
+                auto mma = [&](const Frag &f) {  // (per accumulator the same order as ever: hi hi, lo hi, hi lo)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[4];
+                    for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xh[r], acc[r], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = 4 * q + i;
-                v[i] = fmaf(fmaxf(fmaf(acc[e], A.winv2, pb[e]), 0.f), ps[e], pt[e]);
+                    for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl, f.xh[r], acc[r], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh, f.xl[r], acc[r], 0, 0, 0);
+                };
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                Frag f[3];  // half-step s (tap s / 2, k-step s % 2) lives in f[s % 3]; its operands are read two half-steps ahead
+                load_frag(f[0], 0, 0);
+                load_frag(f[1], 0, 1);
+                __builtin_amdgcn_sched_barrier(0);  // the head start stays a head start: the groups below count from here
+#pragma unroll
+                for (int s = 0; s < 18; ++s) {
+                    if (s + 2 < 18) load_frag(f[(s + 2) % 3], (s + 2) / 2, (s + 2) % 2);
+                    mma(f[s % 3]);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    if (s == kSplitM - 1) S_BARRIER();  // (the other group: staging windows read, its conv 1 may overwrite them)
+                }
+                pending = true;
+            } else {
+                S_BARRIER();
             }
-            unsigned h0, l0, h1, l1;
-            split2m(v[0], v[1], h0, l0, amax);
-            split2m(v[2], v[3], h1, l1, amax);
-            *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
-        }
-        ENC0_T(2)
-        S_BARRIER();  // B: patch of the next tile and all staging windows visible
-
-        ENC0_T(3)
-        // ---------------- conv 1 of the next tile; skip stores and pooling of this one ----------------
-        int n_b = 0, n_y0 = 0, n_x0 = 0;
-        if (next < t_end) {
-            tile_origin(next, n_b, n_y0, n_x0);
-            for (int g = wave; g < kGroups; g += kWaves) conv1_group(g, n_y0, n_x0);
-        }
-        {
-            // skip tensor: row t_y0 + wave, 32 pixels x 128 B; 8 lanes = one pixel-chunk (pieces permuted by the window swizzle)
-            const long long row = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0;
-            unsigned char *ybase = static_cast<unsigned char *>(A.y) + (row * A.ldy + A.yoff) * 4;
-            uint4 v[4];
+            S_BARRIER();  // (the other group: its next halo image is complete)
+        } else {
+            // ================= everything else, for the tile multiplied in the previous half-period =================
+            const int next = cur + gstride;
+            if (pending) {
+                // ---- output: bias, ReLU, BatchNorm, split, staged image ([pixel][hi 64 B | lo 64 B], a 4 KB window per row) ----
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int px = t * 8 + (lane >> 3);
-                v[t] = *reinterpret_cast<const uint4 *>(win + px * 128 + (lane & 7) * 16);
-            }
+                for (int r = 0; r < 2; ++r) {
+                    unsigned char *win = win0 + r * 4096;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int px = t * 8 + (lane >> 3);
-                const int p8 = (lane & 7) ^ ((px >> 1) & 7);
-                *reinterpret_cast<uint4 *>(ybase + (long long)px * A.ldy * 4 + p8 * 16) = v[t];
-            }
-        }
-        if (wave >= kWaves / 2) {
-            // MaxPooling2D(2 x 2) by the waves that had ONE halo group of the first convolution above (waves 0-2 had two):
-            // pooled row prow_w <- staged rows 2 prow_w, 2 prow_w + 1; lane = (pooled pixel, 8-channel group)
-            const int prow_w = wave - kWaves / 2;
-            const int pp = lane >> 2, g = lane & 3;
-            float m[8];
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const unsigned char *w2 = stage + (2 * prow_w + (s >> 1)) * 4096;
-                const int px = 2 * pp + (s & 1);
-                const uint4 hi = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, g));
-                const uint4 lo = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, 4 + g));
-                const unsigned hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = 4 * q + i;
+                            v[i] = fmaf(fmaxf(fmaf(acc[r][e], A.winv2, pb[e]), 0.f), ps[e], pt[e]);
+                        }
+                        unsigned h0, l0, h1, l1;
+                        split2m(v[0], v[1], h0, l0, amax);
+                        split2m(v[2], v[3], h1, l1, amax);
+                        *reinterpret_cast<uint2 *>(win + stage_off(l31, q) + 8 * kgrp) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2 *>(win + stage_off(l31, 4 + q) + 8 * kgrp) = make_uint2(l0, l1);
+                    }
+                }
+                store_patch(pn0, pn1);
+                // ---- skip tensor: rows t_y0 + 2 wg + r, 32 pixels x 128 B; 8 lanes = one pixel-chunk (pieces permuted by the window
+                // swizzle).  The windows are this wave's own: no barrier between their writes and these reads ----
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const h16x2 a = __builtin_bit_cast(h16x2, hh[i]), b = __builtin_bit_cast(h16x2, ll[i]);
-                    const float v0 = (float)a[0] + (float)b[0], v1 = (float)a[1] + (float)b[1];
-                    m[2 * i] = s == 0 ? v0 : fmaxf(m[2 * i], v0);
-                    m[2 * i + 1] = s == 0 ? v1 : fmaxf(m[2 * i + 1], v1);
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned char *win = win0 + r * 4096;
+                    const long long row = ((long long)t_b * A.H + t_y0 + 2 * wg + r) * A.W + t_x0;
+                    unsigned char *ybase = static_cast<unsigned char *>(A.y) + (row * A.ldy + A.yoff) * 4;
+                    auto rd = [&](int t) -> uint4 { return *reinterpret_cast<const uint4 *>(win + (t * 8 + (lane >> 3)) * 128 + (lane & 7) * 16); };
+                    auto wr = [&](int t, const uint4 &v) {
+                        const int px = t * 8 + (lane >> 3);
+                        const int p8 = (lane & 7) ^ ((px >> 1) & 7);
+                        *reinterpret_cast<uint4 *>(ybase + (long long)px * A.ldy * 4 + p8 * 16) = v;
+                    };
+                    const uint4 v0 = rd(0), v1 = rd(1), v2 = rd(2), v3 = rd(3);
+                    wr(0, v0);
+                    wr(1, v1);
+                    wr(2, v2);
+                    wr(3, v3);
+                }
+                {
+                    // ---- MaxPooling2D(2 x 2): pooled row wg <- this wave's two staged rows; lane = (pooled pixel, 8-channel group) ----
+                    const int pp = lane >> 2, g = lane & 3;
+                    float m[8];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const unsigned char *w2 = win0 + (s >> 1) * 4096;
+                        const int px = 2 * pp + (s & 1);
+                        const uint4 hi = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, g));
+                        const uint4 lo = *reinterpret_cast<const uint4 *>(w2 + stage_off(px, 4 + g));
+                        const unsigned hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const h16x2 a = __builtin_bit_cast(h16x2, hh[i]), b = __builtin_bit_cast(h16x2, ll[i]);
+                            const float v0 = (float)a[0] + (float)b[0], v1 = (float)a[1] + (float)b[1];
+                            m[2 * i] = s == 0 ? v0 : fmaxf(m[2 * i], v0);
+                            m[2 * i + 1] = s == 0 ? v1 : fmaxf(m[2 * i + 1], v1);
+                        }
+                    }
+                    unsigned hq[4], lq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split2(m[2 * i], m[2 * i + 1], hq[i], lq[i]);
+                    const long long prow = ((long long)t_b * (A.H / 2) + (t_y0 / 2) + wg) * (A.W / 2) + (t_x0 / 2) + pp;
+                    unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + prow * A.pool_ld * 4 + g * 16;
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+                    *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
                 }
             }
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) split2(m[2 * i], m[2 * i + 1], h[i], l[i]);
-            const long long prow = ((long long)t_b * (A.H / 2) + (t_y0 / 2) + prow_w) * (A.W / 2) + (t_x0 / 2) + pp;
-            unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + prow * A.pool_ld * 4 + g * 16;
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+            S_BARRIER();  // this group: every wave has read its staging windows, the next patch is visible
+            if (pending) {
+                // ---- conv 1 of this group's next tile -> its halo image (over the staging windows) ----
+                cur = next;
+                if (cur < t_end) {
+                    tile_origin(cur, t_b, t_y0, t_x0);
+                    for (int g = wg; g < kGroups; g += kGW) conv1_group(g, t_y0, t_x0);
+                }
+                pending = false;
+            }
+            S_BARRIER();  // this group: halo image complete
         }
-        ENC0_T(4)
-        if (next >= t_end) break;
-        tile = next;
-        t_b = n_b;
-        t_y0 = n_y0;
-        t_x0 = n_x0;
-        S_BARRIER();  // C: halo image of the next tile complete
-        ENC0_T(5)
-#ifdef QMRI_S3_EXPERIMENTS
-        tacc[6] += 1;
-#endif
     }
-#ifdef QMRI_S3_EXPERIMENTS
-    if (tid == 0)
-        for (int i = 0; i < 7; ++i) atomicAdd(&enc0_tstat[i], tacc[i]);
-#endif
     if (A.sat && amax > 65504.f) *A.sat = 1;
 }
 
@@ -794,16 +833,16 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
 
 // (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
 // 36864 + 26112 + 16384 + 1296 = 80656 B: two blocks fit the 160 KB of a CU
-size_t enc0_lds_bytes() { return (size_t)kWBytes + kHaloBytes + kStageBytes + (size_t)kPatchW * (kPatchH + 1) * 4; }
+size_t enc0_lds_bytes() { return (size_t)kWBytes + 2 * (size_t)kHaloBytes + 2 * (size_t)kPatchFloats * 4; }
 
-bool enc0_supported(const Enc0Args &k) { return k.H % kWaves == 0 && k.W % 32 == 0 && k.B > 0; }
+bool enc0_supported(const Enc0Args &k) { return k.H % kRows == 0 && k.W % 32 == 0 && k.B > 0; }
 
 hipError_t enc0_launch(const Enc0Args &k, int num_cu, hipStream_t stream) {
     if (!enc0_supported(k)) return hipErrorInvalidValue;
     const size_t lds = enc0_lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(enc0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const long long ntiles = (long long)k.B * (k.H / kWaves) * (k.W / 32);
+    const long long ntiles = (long long)k.B * (k.H / kRows) * (k.W / 32);
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
     hipLaunchKernelGGL(enc0_kernel, dim3((unsigned)grid), dim3(kThreads), lds, stream, k);

@@ -260,8 +260,6 @@ bool conv_s3_supported(const ConvS3Args &k);
 bool conv_c4_supported(const ConvS3Args &k);
 int conv_c4_block_channels(int Cout);  // 128, or 64 for Cout = 64 (mod 128): the packing of w_c4 depends on it
 bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu);  // will conv_s3_launch run this layer on conv_c4_kernel
-int conv_c4_work_items(const ConvS3Args &k);
-double conv_c4_rounds(const ConvS3Args &k, int num_cu);
 hipError_t conv_c4_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 int conv_s3_block_channels(int Cout, int deconv);  // channel-block size the kernel uses for a layer: the weight packing depends on it
 hipError_t conv_s3_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);

@@ -94,6 +94,17 @@ __device__ unsigned long long enc0_tstat[8];  // cycles of wave 0: [0] MFMA loop
 // LDS traffic only: the skip / pooled stores of a tile stay in flight across the barriers (__syncthreads would drain them)
 #define S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+#ifdef QMRI_ENC0_TIMELINE  // (experiment build: block 8 records when its two groups reach the marks of half-periods 20 .. 23, 10 ns ticks;
+                           //  read back with qmri_debug_enc0_timeline -- scripts/enc0_timeline.py)
+__device__ unsigned long long g_enc0_tl[4 * 2 * 8];
+#define ENC0_TS(k)                                                                                                   \
+    do {                                                                                                             \
+        if (blockIdx.x == 8 && (tid & 255) == 0 && h >= 20 && h < 24) g_enc0_tl[((h - 20) * 2 + grp) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define ENC0_TS(k)
+#endif
+
 __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wlds = smem;                         // conv 2 weights (both groups)
@@ -238,12 +249,18 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
     // instructions per wave, LDS round trips between them) takes a lone wave per SIMD 2.4 x its multiply phase, and LDS time --
     // operand reads at 1.0 per MFMA + staging + halo image, ~3.8 k cycles per tile -- is not far below the period.  Also tried:
     // three slots (M | O | C: two vector phases on one SIMD just add, 1.72-1.77 ms); two groups of EIGHT waves (16 per block, 112
-    // registers, parameters and conv 1 operands from LDS: 1.33 reads per MFMA, no faster).  The outputs are bit-identical to the
-    // one-phase kernel's (scripts/unet_bits.py).
+    // registers, parameters and conv 1 operands from LDS: 1.33 reads per MFMA, no faster); the multiplying group taking three of the
+    // other group's eleven conv 1 groups after its loop (+-0); s_setprio 3 on the multiply phase (+-1 %).  The timeline
+    // (QMRI_ENC0_TIMELINE, scripts/enc0_timeline.py, profiles/r04_enc0_timeline.txt) says why: beside a vector partner the multiply
+    // phase runs at 55-65 % of the matrix pipe's rate (3.0-3.8 us for the 108 MFMAs of a wave = 1.97 us of pipe time), the vector
+    // phase takes 1.7 us when its group is the older one and 3.4 us when it is the younger (VALU issue goes by priority, then age):
+    // on one SIMD the two streams add more than they overlap (MI355X_MICROARCH.md, "Two waves per SIMD").  The outputs are
+    // bit-identical to the one-phase kernel's (scripts/unet_bits.py).
     f32x16 acc[2];
     float pn0 = 0.f, pn1 = 0.f;
     bool pending = false;  // an output tile waits in acc
     for (int h = 0; h <= n_blk; ++h) {
+        ENC0_TS(0);
         if ((h & 1) == grp) {
             // ================= conv 2 of tile `cur`: 2 rows x 32 pixels x 32 channels per wave, K = 9 taps x 32 =================
             if (cur < t_end) {
@@ -288,13 +305,19 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
-                    if (s == kSplitM - 1) S_BARRIER();  // (the other group: staging windows read, its conv 1 may overwrite them)
+                    if (s == kSplitM - 1) {
+                        ENC0_TS(1);
+                        S_BARRIER();  // (the other group: staging windows read, its conv 1 may overwrite them)
+                        ENC0_TS(2);
+                    }
                 }
                 pending = true;
             } else {
                 S_BARRIER();
             }
+            ENC0_TS(3);
             S_BARRIER();  // (the other group: its next halo image is complete)
+            ENC0_TS(4);
         } else {
             // ================= everything else, for the tile multiplied in the previous half-period =================
             const int next = cur + gstride;
@@ -366,7 +389,9 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                     *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
                 }
             }
+            ENC0_TS(1);
             S_BARRIER();  // this group: every wave has read its staging windows, the next patch is visible
+            ENC0_TS(2);
             if (pending) {
                 // ---- conv 1 of this group's next tile -> its halo image (over the staging windows) ----
                 cur = next;
@@ -376,7 +401,9 @@ __global__ __launch_bounds__(kThreads, 1) void enc0_kernel(const Enc0Args A) {
                 }
                 pending = false;
             }
+            ENC0_TS(3);
             S_BARRIER();  // this group: halo image complete
+            ENC0_TS(4);
         }
     }
     if (A.sat && amax > 65504.f) *A.sat = 1;
@@ -885,6 +912,13 @@ hipError_t mid0_launch(const Mid0Args &k, int num_cu, hipStream_t stream) {
 }
 
 }  // namespace qmri
+
+#ifdef QMRI_ENC0_TIMELINE
+extern "C" int qmri_debug_enc0_timeline(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(qmri::g_enc0_tl), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef QMRI_S3_EXPERIMENTS
 extern "C" int qmri_enc0_debug_stats(unsigned long long *out, int reset) {

@@ -7,6 +7,8 @@ moving statistics spread like a trained network's (variance 5e-3 .. 1.5e2, means
 -- and the north_star tolerance on the logits (1e-3 abs) in the parity mode, for both activation-buffer sizes the bench
 uses (max_batch 16 and 160), plus an assertion on WHICH kernels ran every layer (so that the 384-only dispatch -- 8 x 32
 tiles at 384 / 192 / 96, the flattened tiling at 48 / 24 / 12, fused pool and head -- is what is tested)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -72,9 +74,16 @@ def test_384_logits_parity_mode(net, ref384, max_batch):
     tr = eng.trace()
     _expect_families(tr, 384, 384)
     fams = {t.split(":", 1)[1].split("+")[0] for t in tr if t.startswith(("down", "up")) and "conv" in t and "deconv" not in t}
-    # the >= 128-channel layers run on conv_s3_kernel<128> ("bn128") or conv_c4_kernel ("c4"), per layer by the launcher's cost model
+    # the plain 3 x 3 convolutions run on conv_s3_kernel ("bn64" / "bn128") or conv_c4_kernel ("c4x64" / "c4x128")
     assert {"mid0", "out0"} <= fams and fams & {"s3/2d/bn64", "s3/2d/c4x64"} and fams & {"s3/2d/bn128", "s3/2d/c4x128"} \
         and fams & {"s3/flat/bn128", "s3/flat/c4x128"}, fams
+    if os.environ.get("QMRI_C4", "1") == "1":
+        # the product's dispatch (conv_s3_takes_c4, by layer shape only): every plain 3 x 3 convolution below the top level is
+        # conv_c4_kernel's -- 64-channel blocks on 24-row image tiles, 128-channel blocks on image tiles and flattened levels --
+        # and conv_s3_kernel is left with the transposed convolutions
+        assert {"s3/2d/c4x64", "s3/2d/c4x128", "s3/flat/c4x128"} <= fams, fams
+        assert not fams & {"s3/2d/bn64", "s3/2d/bn128", "s3/flat/bn128"}, fams
+        assert all(t.split(":", 1)[1].endswith("bn32") for t in tr if "deconv" in t), tr
     eng.close()
 
 

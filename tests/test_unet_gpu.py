@@ -376,6 +376,40 @@ np.save(sys.argv[1], logits)
     assert np.abs(out["dedicated"][2] - out["general"][2]).max() < 2e-4
 
 
+@pytest.mark.parametrize("slices", [32, 33, 48])
+def test_enc0_two_group_schedule_at_several_tiles_per_block(slices):
+    """enc0_kernel's two groups of waves take a block's tiles alternately and hand over at shared barriers: 64 x 64 slices are
+    16 tiles each, so 32 / 33 / 48 slices give every block 2 / 2 or 3 (the groups end in different half-periods) / 3 tiles on
+    the 256 CUs of an MI355X.  Against the general route (QMRI_ENC0=0, read once per process: first-layer kernel +
+    conv_s3_kernel + pooling kernel) on the same volume (/root/reference/dosma/models/oaiunet2d.py:213-243)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dosma_amd import _lib as L
+from dosma_amd.models import weights as W
+S = int(sys.argv[2])
+eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), 64, 64, max_batch=S, precision="fp16x3")
+vol = (np.random.default_rng(3).standard_normal((S, 64, 64)) * 2 + 0.5).astype(np.float32)
+logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+print("TRACE", ",".join(eng.trace()))
+np.save(sys.argv[1], logits)
+''' % root
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("enc0", {}), ("general", {"QMRI_ENC0": "0"})):
+            path = os.path.join(d, tag + ".npy")
+            txt = subprocess.check_output([sys.executable, "-c", code, path, str(slices)], env=dict(os.environ, **env), cwd=root).decode()
+            out[tag] = ([ln for ln in txt.splitlines() if ln.startswith("TRACE")][-1], np.load(path))
+    assert "down0:enc0" in out["enc0"][0] and "down0.conv1:c1/split" in out["general"][0]
+    assert np.abs(out["enc0"][1] - out["general"][1]).max() < 1e-4, np.abs(out["enc0"][1] - out["general"][1]).max()
+
+
 @pytest.mark.parametrize("hw", [(32, 32), (160, 64), (224, 32), (96, 32)])
 def test_dedicated_top_level_kernels_on_small_and_ragged_sizes(small_net, hw):
     """enc0 / mid0 / out0 (unet_enc0.hip) where their tiling is at its edges: one tile per slice (32 x 32), a single tile

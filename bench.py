@@ -643,6 +643,24 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
     return out
 
 
+def _launch_ranks(n: int) -> int:
+    """Re-run this command as n ranks under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (what the
+    driver's own multi-GPU command line is) and return the launcher's exit code.  stdout / stderr are inherited: the
+    single JSON line rank 0 prints is this process's output."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def _kernel_source_sha1():
     return _source_sha1(("monoexp_lm.hip", "fp64_fast.h", "qmri_internal.h"))
 
@@ -686,8 +704,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: become the launcher -- N ranks of this very command under
+            # torch.distributed.run (one per GPU, rendezvous on 127.0.0.1 at a free port); rank 0's JSON line is the
+            # children's stdout, the exit code is the launcher's
+            raise SystemExit(_launch_ranks(args.gpus))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N launches them itself)")
     # QMRI_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices); the real runs use nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("QMRI_BENCH_BACKEND", "nccl")

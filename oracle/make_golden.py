@@ -6,7 +6,7 @@ golden vectors are produced here from seeded inputs by calling the reference's p
 ``dosma.curve_fit``, ``dosma.CurveFitter``, ``dosma.MonoExponentialFit`` (dosma/core/fitting.py).
 A fixture is data only: inputs + the reference's outputs (+ scipy's ier/nfev for the same call).
 
-    python oracle/make_golden.py            # writes tests/golden/g*.npz  (~1-2 min, 8 workers)
+    python oracle/make_golden.py [g1 ... g9]   # writes tests/golden/g*.npz  (~30 s, 8 workers)
 """
 import os
 import sys
@@ -18,7 +18,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "tests", "golden")
+# QMRI_GOLDEN_OUT: write somewhere else (tests/test_oracle.py::test_fixture_recipes_reproduce_the_committed_fixtures
+# regenerates every fixture into a temp dir and compares it with the committed one)
+OUT = os.environ.get("QMRI_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")
 
 from oracle.ref_harness import load_reference  # noqa: E402
 

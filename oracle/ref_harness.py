@@ -196,6 +196,10 @@ _LOADED = {}
 # the reference is imported (its own modules keep their reference to the stub; dosma/utils/io_utils.py:7 imports h5py
 # unconditionally, so the import itself needs one)
 _DROP_AFTER_IMPORT = ("h5py",)
+_SUBMODULES = ("dosma.scan_sequences", "dosma.scan_sequences.mri.qdess", "dosma.scan_sequences.mri.cube_quant",
+               "dosma.scan_sequences.mri.cones", "dosma.scan_sequences.mri.mapss", "dosma.tissues", "dosma.models",
+               "dosma.models.oaiunet2d", "dosma.models.seg_model", "dosma.models.stanford_qdess", "dosma.models.util",
+               "dosma.core.quant_vals")
 
 
 def load_reference():
@@ -231,6 +235,11 @@ def load_reference():
     matplotlib.use("Agg")
     try:
         dosma = importlib.import_module("dosma")
+        # the sub-packages `import dosma` does not pull in but the fixture generators import later
+        # (oracle/make_golden.py g6: dosma.scan_sequences.mri.qdess -> dosma.tissues -> dosma.utils.img_utils ->
+        # seaborn; g9: dosma.models.*): imported HERE, while the stand-ins are still resolvable
+        for sub in _SUBMODULES:
+            importlib.import_module(sub)
     finally:
         # the stand-ins are only for the reference's own import: leaving the finder on sys.meta_path would hand
         # an inert stub to any later `import h5py` / `import skimage` in the same process (e.g. the product's

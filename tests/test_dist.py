@@ -152,6 +152,38 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher (how the driver's N = 1 command line is recorded: plain python):
+    bench.py re-runs itself under torch.distributed.run, one process per rank, and this process's stdout carries rank
+    0's single JSON line.  QMRI_BENCH_BACKEND=gloo lets the two ranks share the box's one GPU."""
+    import json
+
+    env = dict(os.environ, QMRI_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cfg5-volumes-per-gpu", "1", "--no-cpu-baseline", "--no-unet"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2
+    assert out["process_group"]["world_size"] == 2 and out["process_group"]["backend"] == "gloo"
+    assert out["cfg5"]["per_rank"] == [1, 1]
+    assert abs(out["value"] - 2 * 512 * 512 * 160 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_launcher_forwards_the_exit_code(tmp_path):
+    """The self-launch path without a GPU: the ranks fail (no device), and the failure -- not a usage error, not a
+    hang -- is what the caller sees; with WORLD_SIZE set and different from --gpus the old refusal stays."""
+    env = dict(os.environ, QMRI_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_knee_batch_example(ranks):
     """examples/knee_batch.py (BASELINE configs[4] through the drop-in API: fit + generate_mask per volume, batch axis

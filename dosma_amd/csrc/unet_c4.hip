@@ -248,8 +248,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     const int ntiles = A.ntiles;
     const int wsteps = A.steps;  // chunks * 18 steps per work item
 
-    const i32x4 xr = make_rsrc(A.x);
+    // the activation descriptor's base is the first IMAGE the requested tile's halo touches (set_halo_sources): per-lane offsets
+    // are 32 bits and stay inside a few images' bytes, so which layers this kernel can address does not depend on the batch
+    i32x4 xr = make_rsrc(A.x);
     const i32x4 wr = make_rsrc(A.w_c4);
+    const long long img_bytes = (long long)A.H * A.W * A.ldx * 4;
     const unsigned halo_lds = lds_off(halo), ring_lds = lds_off(ring);
 
     // ---- work distribution ----
@@ -313,6 +316,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         int lane_h = lane;
         asm volatile("" : "+v"(lane_h));  // (opaque: the per-piece pixel coordinates are otherwise computed before the main loop and spilled)
         const int lane = lane_h;
+        // first image of the halo: the tile's own (image tiles) / the one holding the first halo position of the stack (flattened)
+        int b0 = b;
+        if (FLAT) {
+            const int r1 = (f0 - P - 1) / P - 1;
+            b0 = r1 > 0 ? r1 / (A.H + 1) : 0;
+            if (b0 > A.B - 1) b0 = A.B - 1;
+        }
+        xr = make_rsrc(static_cast<const unsigned char *>(A.x) + (long long)b0 * img_bytes);
+        const int pix0 = b0 * A.H * A.W;
 #pragma unroll
         for (int i = 0; i < kHSlots; ++i) {
             int j = wave + kWaves * i;
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                     if ((unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W) pix = (b * A.H + yy) * A.W + xx;
                 }
             }
-            hofft[i * kThreads + tid] = pix >= 0 ? (unsigned)pix * (unsigned)A.ldx * 4u + srcb : kPadOff;
+            hofft[i * kThreads + tid] = pix >= 0 ? (unsigned)(pix - pix0) * (unsigned)A.ldx * 4u + srcb : kPadOff;
         }
     };
     // the half-chunk being requested: item ordinal, half-chunk index hc = 2 chunk + half, destination buffer = hc & 1
@@ -671,19 +683,25 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             for (int win = 0; win < 2; ++win) {
                 const int i = 2 * pr + win;
                 uint4 hi[2], lo[2];
+                float tmax[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float v[8];
                     finish8(r[win][t][0], r[win][t][1], p, v);
+                    // saturation tracking over the values that are STORED: a discarded position (a frame position of the flattened
+                    // stack, a row below the image in a partial tile) above 65504 would re-run the whole forward scaled
+                    float tm = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 8; k += 2) amax = fmaxf(fmaxf(amax, fabsf(v[k])), fabsf(v[k + 1]));
-                    asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps every value alive until then)
+                    for (int k = 0; k < 8; k += 2) tm = fmaxf(fmaxf(tm, fabsf(v[k])), fabsf(v[k + 1]));
+                    tmax[t] = tm;
                     split8(v, hi[t], lo[t]);
                 }
                 if (FLAT) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int pix = outpix[(wave * kRT + i) * 32 + t * 16 + opx_t];
+                        amax = fmaxf(amax, pix >= 0 ? tmax[t] : 0.f);
+                        asm volatile("" : "+v"(amax));  // (pinned here: hipcc otherwise sinks the whole max chain behind the epilogue and keeps every value alive until then)
                         if (pix >= 0 && !C4_DBG(32)) {
                             unsigned char *dst = static_cast<unsigned char *>(A.y) + ((long long)pix * A.ldy + A.yoff + cbase) * 4 + oc_t * 16;
                             nt_store16(dst, hi[t]);
@@ -693,6 +711,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                 } else {
                     const int yy = t_y0 + wave * kRT + i;  // (scalar)
                     if (yy < A.H) {
+                        amax = fmaxf(fmaxf(amax, tmax[0]), tmax[1]);
+                        asm volatile("" : "+v"(amax));  // (pinned: see the flattened branch)
                         unsigned char *rowp = static_cast<unsigned char *>(A.y) +
                                               (((long long)(t_b * A.H + yy) * A.W + t_x0) * A.ldy + A.yoff + cbase) * 4;  // scalar pointer
                         const unsigned pstep = (unsigned)A.ldy * 4u;  // bytes per output pixel
@@ -842,10 +862,17 @@ int conv_c4_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : 64; }
 bool conv_c4_supported(const ConvS3Args &k) {
     if (k.deconv || k.one || k.head_w) return false;
     if (k.Cin % 32 || k.Cout % 64) return false;
-    // 32-bit source offsets: pixel * ldx * 4 (+ the chunk's 128 bytes) must stay below the descriptor's num_records
-    if ((unsigned long long)k.B * k.H * k.W * (unsigned long long)k.ldx * 4ull >= (unsigned long long)kPadOff) return false;
-    if (k.W % 32 == 0) return !k.pool_y || (!(k.H & 1) && !(k.W & 1));
-    return k.W + 2 <= 50 && !k.pool_y;  // flattened zero-framed stack (halo: 512 + 2 (W + 2) + 2 <= 624 pixels)
+    // 32-bit source offsets relative to the first image a halo touches (the descriptor base moves per work item): the bytes of
+    // the images ONE halo can span (+ the chunk's 128) must stay below the descriptor's num_records.  A property of the layer's
+    // shape, not of the batch: a slice's bits must not depend on the pass it travels in.
+    const unsigned long long img = (unsigned long long)k.H * k.W * (unsigned long long)k.ldx * 4ull;
+    if (k.W % 32 == 0) {
+        if (img >= (unsigned long long)kPadOff) return false;
+        return !k.pool_y || (!(k.H & 1) && !(k.W & 1));
+    }
+    if (!(k.W + 2 <= 50 && !k.pool_y)) return false;  // flattened zero-framed stack (halo: 512 + 2 (W + 2) + 2 <= 624 pixels)
+    const unsigned long long span = (624ull + (unsigned long long)(k.H + 1) * (k.W + 2) - 1) / ((unsigned long long)(k.H + 1) * (k.W + 2)) + 1;
+    return span * img < (unsigned long long)kPadOff;
 }
 
 template <bool FLAT, int CT>

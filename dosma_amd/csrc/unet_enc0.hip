@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
 }  // namespace
 
 // (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
-// 36864 + 26112 + 16384 + 1296 = 80656 B: two blocks fit the 160 KB of a CU
+// 36864 (weights) + 2 x 43520 (one halo image per group) + 2 x 1872 (one input patch per group) = 127648 B: ONE 8-wave block per CU
 size_t enc0_lds_bytes() { return (size_t)kWBytes + 2 * (size_t)kHaloBytes + 2 * (size_t)kPatchFloats * 4; }
 
 bool enc0_supported(const Enc0Args &k) { return k.H % kRows == 0 && k.W % 32 == 0 && k.B > 0; }

@@ -16,12 +16,15 @@ for t in x:
     v[:150] = 0
     vols.append(dm.MedicalVolume(v, np.eye(4)))
 n = np.prod(shape)
-for tc0 in (30.0, "polyfit"):
-    f = dm.MonoExponentialFit(tc0=tc0, decimal_precision=3)
-    for rep in range(3):
-        t0 = time.perf_counter()
-        tc, r2 = f.fit(x, vols)
-        dt = time.perf_counter() - t0
-    print(f"MonoExponentialFit(tc0={tc0!r}).fit: {dt*1e3:.1f} ms -> {n/dt:.3e} voxel-fits/s end to end")
+# the same volumes as int16 (what DICOM pixel data is; the reference keeps the volumes' dtype, fitting.py:194-196)
+vols16 = [dm.MedicalVolume(np.rint(v.volume).astype(np.int16), np.eye(4)) for v in vols]
+for name, vv in (("float32", vols), ("int16", vols16)):
+    for tc0 in (30.0, "polyfit"):
+        f = dm.MonoExponentialFit(tc0=tc0, decimal_precision=3)
+        for rep in range(3):
+            t0 = time.perf_counter()
+            tc, r2 = f.fit(x, vv)
+            dt = time.perf_counter() - t0
+        print(f"{name}: MonoExponentialFit(tc0={tc0!r}).fit: {dt*1e3:.1f} ms -> {n/dt:.3e} voxel-fits/s end to end")
 pr = cProfile.Profile(); pr.enable(); f.fit(x, vols); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(12)

@@ -2,7 +2,7 @@
 FETCH_SIZE (KB, doubled per the gfx950 correction of MI355X_MICROARCH.md) of the last forward in a rocprofv3 --pmc FETCH_SIZE
 collection of scripts/prof_unet.py (scripts/collect_profile.sh writes it to gpurun_out/<tag>/unet_fetch).
 
-    python scripts/unet_read_traffic.py gpurun_out/r04f/unet_fetch [gpurun_out/r04f/unet_write] > profiles/r04f_unet_reads_by_layer.txt
+    python scripts/unet_read_traffic.py gpurun_out/<tag>/unet_fetch [gpurun_out/<tag>/unet_write] > profiles/<tag>_unet_reads_by_layer.txt   (committed: r04g_…)
 
 With the WRITE_SIZE pass as second argument: also bytes written and the layer's HBM-side bandwidth (kernel time of the FETCH pass).
 """

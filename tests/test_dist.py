@@ -146,6 +146,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert c5["voxel_fits_per_s"] > 1e7 and c5["slices_per_s"] > 10
     hf = c5["host_feed"]
     assert len(hf["seconds_per_rank"]) == 2 and hf["voxel_fits_per_s"] > 1e7
+    assert len(hf["int16"]["seconds_per_rank"]) == 2 and hf["int16"]["voxel_fits_per_s"] > 1e7
     for d in ("h2d", "d2h"):
         assert len(hf["copy_bandwidth"][d]["gb_per_s_per_rank"]) == 2 and hf["copy_bandwidth"][d]["gb_per_s_all_ranks"] > 1
     assert out["unet2d"]["value"] > 100 and "cpu_baseline" not in out

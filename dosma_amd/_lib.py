@@ -25,6 +25,8 @@ QMRI_ERR_NOMEM = -5
 QMRI_F32, QMRI_F64, QMRI_I16, QMRI_U16 = 0, 1, 2, 3
 INIT_SCALAR, INIT_PER_VOXEL, INIT_LOGLIN = 0, 1, 2
 MAX_ECHOES = 32
+# samples per voxel the general lmdif kernel keeps (include/qmri.h: E <= QMRI_LM_MAX_ECHOES and (n + 3) * E <= 320)
+LM_MAX_SAMPLES = {"monoexponential": 64, "biexponential": 45}
 
 _NP2Q = {np.dtype(np.float32): QMRI_F32, np.dtype(np.float64): QMRI_F64,
          np.dtype(np.int16): QMRI_I16, np.dtype(np.uint16): QMRI_U16}

@@ -12,8 +12,11 @@ BASELINE.json -- same names, arguments and error behaviour:
 What runs where: everything per-voxel runs in ``libqmri_hip.so`` (include/qmri.h).  Python only does
 what the reference's Python does *around* the loop: argument checking, reorientation, flattening to
 the (E, N) echo-major array, p0 formatting, wrapping results in MedicalVolumes.  There is no CPU
-solver in this package: an unsupported request raises ``NotImplementedError``; a missing library
-or GPU raises ``dosma_amd._lib.QmriError``.
+solver for the models the kernels implement: a missing library or GPU raises ``dosma_amd._lib.QmriError``.
+A request the kernels do NOT implement -- a generic Python ``func``, scipy ``**kwargs`` that select another
+solver (``bounds=``, ``sigma=``, ``jac=``, ``method=``), more samples per voxel than the kernels keep -- is
+served the way the reference serves every request: one ``scipy.optimize.curve_fit`` per voxel
+(``dosma_amd/_scipy_loop.py``; SURVEY 8(b)'s dispatch rule, reference :827-870, :1026-1073).
 
 Like the reference (:403-406, 745-746, 809-810) inputs must live on the CPU; the library stages
 them to the GPU itself.
@@ -64,7 +67,8 @@ _inv_abs.__qmri_ufunc__ = "inv_abs"
 
 
 def _model_of(func) -> str:
-    """Which built-in kernel model ``func`` is.  Raises NotImplementedError for anything else.
+    """Which built-in kernel model ``func`` is.  Raises NotImplementedError for anything else (the callers then take the
+    reference's per-voxel scipy route: :func:`_kernel_route`).
 
     ``func`` is recognised by identity, by a ``__qmri_model__`` attribute, or -- for a user's own
     2-parameter callable such as ``lambda x, a, b: a * np.exp(b * x)`` -- by evaluating it on a few
@@ -93,8 +97,7 @@ def _model_of(func) -> str:
             return "monoexponential"
     name = getattr(func, "__name__", type(func).__name__)
     raise NotImplementedError(
-        f"dosma_amd fits the mono-exponential (a*exp(b*x)) and bi-exponential models on the GPU; "
-        f"func={name!r} is neither and there is no CPU fallback.")
+        f"func={name!r} is neither the mono-exponential (a*exp(b*x)) nor the bi-exponential model the kernels implement")
 
 
 def _func_param_names(func):
@@ -190,11 +193,10 @@ def curve_fit(
     ``y_bounds``, or whose fit does not converge (MINPACK info not in 1..4) is ``(nan, nan), 0``.
     ``show_pbar`` / ``num_workers`` / ``chunksize`` are accepted for compatibility and ignored (there
     is no per-voxel Python loop to parallelise).  Of the extra scipy ``**kwargs`` the MINPACK options
-    ``xtol`` / ``gtol`` / ``factor`` (and ``method="lm"``) are honoured; ``bounds=``, ``sigma=``, ``jac=``,
-    another ``method`` ... select solvers this library does not implement -> NotImplementedError.
+    ``xtol`` / ``gtol`` / ``factor`` (and ``method="lm"``) go to the kernels; a generic ``func``, ``bounds=``,
+    ``sigma=``, ``jac=``, another ``method`` ... take the reference's own route: one ``scipy.optimize.curve_fit``
+    per voxel on the CPU (``_scipy_loop.py``; there ``num_workers`` / ``chunksize`` mean what they mean in the reference).
     """
-    model = _model_of(func)
-    solver = _solver_options(kwargs, "curve_fit")
     if isinstance(x, MedicalVolume) or isinstance(y, MedicalVolume):
         raise TypeError("`x` and `y` must be array-like (use CurveFitter for MedicalVolumes)")
     x = np.asarray(x)
@@ -205,10 +207,16 @@ def curve_fit(
         raise ValueError("`y` must have shape (M,) or (M, N)")
     N = y.shape[-1]
     param_args = _func_param_names(func)
+    given_p0 = p0 is not None
     p0 = _format_p0(p0, param_args, N)
 
     if y_bounds is not None and ((y < y_bounds[0]).any() or (y > y_bounds[1]).any()):
         warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+
+    model, solver = _kernel_route(func, kwargs, x.reshape(-1).shape[0], "curve_fit")
+    if model is None:
+        return _scipy_loop(func, x, y, p0, given_p0=given_p0, y_bounds=y_bounds, maxfev=maxfev, ftol=ftol, eps=eps,
+                           num_workers=num_workers, chunksize=chunksize, scipy_kwargs=kwargs, why=solver)
 
     # general lmdif kernel (lm_generic.hip): the bi-exponential, and the mono-exponential beyond the 32 samples per voxel its own
     # kernel keeps in registers (the reference has no limit: fitting.py:755-870)
@@ -407,7 +415,8 @@ _KERNEL_SOLVER_OPTIONS = ("xtol", "gtol", "factor")
 def _solver_options(kwargs, who):
     """Split the reference's ``**kwargs`` (forwarded to scipy.optimize.curve_fit, fitting.py:827-830) into the
     MINPACK options the kernels take.  ``method="lm"`` is the default solver and accepted; anything else
-    (``bounds=``, ``sigma=``, ``jac=``, ``method="trf"`` ...) is a different algorithm -> NotImplementedError."""
+    (``bounds=``, ``sigma=``, ``jac=``, ``method="trf"`` ...) is a different algorithm -> NotImplementedError (caught by
+    :func:`_kernel_route`: such requests run the reference's per-voxel scipy loop)."""
     opts = {}
     rest = {}
     for k, v in kwargs.items():
@@ -419,9 +428,34 @@ def _solver_options(kwargs, who):
             rest[k] = v
     if rest:
         raise NotImplementedError(
-            f"{who}(**{sorted(rest)}): only scipy's default unbounded Levenberg-Marquardt "
-            "('lm') configuration is implemented on the GPU; there is no CPU fallback.")
+            f"{who}(**{sorted(rest)}) selects a scipy solver other than the default unbounded Levenberg-Marquardt ('lm') "
+            "configuration the kernels implement")
     return opts
+
+
+def _kernel_route(func, kwargs, n_samples, who):
+    """``(model, solver options)`` when libqmri_hip.so implements the request, else ``(None, reason)``: the caller then
+    runs the reference's per-voxel scipy loop ("otherwise the scipy fallback (reference behaviour)")."""
+    try:
+        model = _model_of(func)
+        solver = _solver_options(kwargs, who)
+    except NotImplementedError as e:
+        return None, str(e)
+    limit = _lib.LM_MAX_SAMPLES.get(model)
+    if limit is not None and n_samples > limit:
+        return None, f"{n_samples} samples per voxel (the {model} kernels keep up to {limit})"
+    return model, solver
+
+
+def _scipy_loop(func, x, y, p0, *, given_p0, y_bounds, maxfev, ftol, eps, num_workers, chunksize, scipy_kwargs, why):
+    """One scipy.optimize.curve_fit per column of ``y`` (E, N) under the reference's rules (dosma_amd/_scipy_loop.py)."""
+    from . import _scipy_loop as loop
+
+    warnings.warn(f"dosma_amd: {why} -> the reference's per-voxel scipy.optimize.curve_fit loop on the CPU "
+                  f"({y.shape[1]} voxels)", RuntimeWarning, stacklevel=3)
+    return loop.loop_fit(func, x, y, p0 if given_p0 else None, nparams=len(_func_param_names(func)), y_bounds=y_bounds,
+                         maxfev=maxfev, ftol=ftol, eps=eps, num_workers=num_workers, chunksize=chunksize,
+                         scipy_kwargs=scipy_kwargs)
 
 
 class _Fitter:
@@ -498,10 +532,11 @@ class _Fitter:
 class CurveFitter(_Fitter):
     """Non-linear least squares fit of ``func`` per voxel of co-registered MedicalVolumes.
 
-    Same constructor and ``fit`` contract as the reference's ``CurveFitter`` (:238-458).  ``func`` must
-    be the mono-exponential or the bi-exponential model (see :func:`curve_fit`).  ``num_workers`` / ``chunksize`` / ``verbose``
-    are accepted and ignored; ``**kwargs`` are forwarded like the reference does (``maxfev``, ``ftol``, ``eps``, and the
-    MINPACK options ``xtol`` / ``gtol`` / ``factor``), anything that selects another scipy solver raises at ``fit``.
+    Same constructor and ``fit`` contract as the reference's ``CurveFitter`` (:238-458).  The mono-exponential and the
+    bi-exponential model run on the GPU (see :func:`curve_fit`; ``num_workers`` / ``chunksize`` / ``verbose`` are then
+    ignored); ``**kwargs`` are forwarded like the reference does (``maxfev``, ``ftol``, ``eps``, and the MINPACK options
+    ``xtol`` / ``gtol`` / ``factor``).  Any other ``func``, or kwargs that select another scipy solver, run the reference's
+    per-voxel scipy loop on the CPU (``_scipy_loop.py``).
     """
 
     def __init__(
@@ -579,12 +614,14 @@ class CurveFitter(_Fitter):
             _decimals=None, _tc_only=False):
         """Fit every voxel; returns ``(popt, r2)`` MedicalVolumes (``popt`` has a trailing parameter
         axis).  Voxels outside ``mask`` hold NaN (or ``nan_to_num``) like the reference (:205-215)."""
-        model = _model_of(self._func)
         # the reference forwards **kwargs to its module-level curve_fit (:422-435): maxfev / ftol / eps are that
         # function's own arguments, the rest go to scipy
         fit_kw = dict(self.kwargs)
         named = {k: fit_kw.pop(k) for k in ("maxfev", "ftol", "eps") if k in fit_kw}
-        solver = _solver_options(fit_kw, "CurveFitter")
+        model, solver = _kernel_route(self._func, fit_kw, np.asarray(x).shape[-1] if not isinstance(x, MedicalVolume) else 0,
+                                      "CurveFitter")
+        if model is None:
+            return self._fit_scipy_loop(x, y, mask, p0, copy_headers, named, fit_kw, solver)
         if "maxfev" in named:
             solver["maxfev"] = int(named["maxfev"])
         if "ftol" in named:
@@ -646,6 +683,38 @@ class CurveFitter(_Fitter):
         if "tc" in out:
             self._last_tc = out["tc"]
         return popt_mv, r2_mv
+
+    def _fit_scipy_loop(self, x, y, mask, p0, copy_headers, named, scipy_kwargs, why):
+        """A request the kernels do not implement, as the reference runs it (:157-235, :422-435): gather the masked columns,
+        one scipy.optimize.curve_fit per voxel, post-process, scatter back."""
+        if isinstance(x, MedicalVolume):
+            raise RuntimeError("`x` must be on the CPU")
+        x, y, svs, mask_flat = self._prepare(x, y, mask)
+        N = svs.shape[1]
+        if p0 is np._NoValue:
+            p0 = self.p0
+        given_p0 = p0 is not None
+        p0 = self._format_p0(p0, ref=y[0], flatten=True)
+        p0 = _format_p0(p0, _func_param_names(self._func), N)
+        sel = None if mask_flat is None else np.flatnonzero(mask_flat)
+        cols = svs if sel is None else svs[:, sel]
+        p0 = [v[sel] if (sel is not None and isinstance(v, np.ndarray)) else v for v in p0]
+        if self.y_bounds is not None and ((cols < self.y_bounds[0]).any() or (cols > self.y_bounds[1]).any()):
+            warnings.warn("Out of bounds values found. Failure in fit will result in np.nan")
+        popt_s, r2_s = _scipy_loop(self._func, x, cols, p0, given_p0=given_p0, y_bounds=self.y_bounds,
+                                   maxfev=int(named.get("maxfev", 100)), ftol=float(named.get("ftol", 1e-5)),
+                                   eps=float(named.get("eps", 1e-8)), num_workers=self.num_workers,
+                                   chunksize=self.chunksize, scipy_kwargs=scipy_kwargs, why=why)
+        popt_s = self._process_params(popt_s, r2_s)
+        if sel is None:
+            popt, r2 = popt_s, r2_s
+        else:
+            fill = np.nan if self.nan_to_num is None else self.nan_to_num
+            popt = np.full((N, popt_s.shape[-1]), fill, dtype=np.float64)
+            r2 = np.full(N, fill, dtype=np.float64)
+            popt[sel] = popt_s
+            r2[sel] = r2_s
+        return self._wrap(y[0], popt, r2, copy_headers)
 
     def _fit_many_samples(self, x, y, rows, mask, mask_flat, p0, copy_headers, solver, decimals, tc_only):
         if getattr(self, "_loglin_init", False):

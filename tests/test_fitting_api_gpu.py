@@ -89,13 +89,17 @@ class TestCurveFit:
         popt, _ = curve_fit(lambda t, a, b: a * np.exp(b * t), x, y)  # user's own lambda
         assert np.allclose(popt[0], (0.7, 0.3))
 
-    def test_unsupported_requests_fail_loudly(self):
+    def test_requests_outside_the_kernels_take_the_reference_route(self):
+        """A generic func / bounds= is the reference's per-voxel scipy loop (dosma_amd/_scipy_loop.py; compared with the live
+        reference in tests/test_host_logic.py); a non-finite sample is scipy's ValueError on either route."""
         x = np.asarray([1.0, 2.0, 3.0, 4.0])
         y = np.ones((4, 3))
-        with pytest.raises(NotImplementedError):
-            curve_fit(lambda t, a: a * t, x, y)
-        with pytest.raises(NotImplementedError):
-            curve_fit(monoexponential, x, y, bounds=(0, 1))
+        with pytest.warns(RuntimeWarning, match="per-voxel scipy"):
+            popt, r2 = curve_fit(lambda t, a: a * t, x, np.outer(x, [1.0, 2.0, 0.0]))
+        assert np.allclose(popt[:2, 0], (1.0, 2.0)) and np.isnan(popt[2, 0]) and r2[2] == 0
+        with pytest.warns(RuntimeWarning, match="per-voxel scipy"):
+            popt, _ = curve_fit(monoexponential, x, 0.5 * np.exp(-0.2 * x), p0=(0.4, -0.1), bounds=([0, -1], [1, 0]))
+        assert np.allclose(popt[0], (0.5, -0.2), rtol=1e-5)
         with pytest.raises(ValueError):
             curve_fit(monoexponential, x, np.full((4, 3), np.nan))
 
@@ -328,8 +332,9 @@ class TestCurveFitter:
             CurveFitter(monoexponential).fit(x[:3], y)
         with pytest.raises(ValueError):
             CurveFitter(monoexponential, r2_threshold="bogus")
-        with pytest.raises(NotImplementedError):
-            CurveFitter(lambda t, a: a * t).fit(x, y)
+        with pytest.warns(RuntimeWarning, match="per-voxel scipy"):  # a generic func: the reference's own loop
+            p1, _ = CurveFitter(lambda t, a: a * t, r2_threshold=None).fit(x, y)
+        assert p1.shape == y[0].shape + (1,)
 
     def test_str(self):
         s = str(CurveFitter(monoexponential, p0=(1.0, -1 / 30),
@@ -522,5 +527,10 @@ def test_solver_kwargs_are_forwarded():
     ref_tight, _ = fo.curve_fit_c(x, y, p0, xtol=1e-3, factor=10.0)
     good = ~np.isnan(ref_tight[:, 0])
     assert np.array_equal(np.isnan(tight[:, 0]), ~good) and np.abs(tight[good] / ref_tight[good] - 1).max() < 1e-4
-    with pytest.raises(NotImplementedError):
-        CurveFitter(monoexponential, sigma=np.ones(8)).fit(x, vols)
+    # sigma= selects scipy's weighted problem: the reference's per-voxel loop (uniform weights: the same minimiser)
+    small = [v[:4, :4, :1] for v in vols]
+    with pytest.warns(RuntimeWarning, match="per-voxel scipy"):
+        ps, _ = CurveFitter(monoexponential, p0=p0, r2_threshold=None, sigma=np.ones(8)).fit(x, small)
+    pg, _ = CurveFitter(monoexponential, p0=p0, r2_threshold=None).fit(x, small)
+    ok = ~np.isnan(pg.volume[..., 0]) & ~np.isnan(ps.volume[..., 0])
+    assert ok.sum() > 8 and np.abs(ps.volume[ok] / pg.volume[ok] - 1).max() < 1e-4

@@ -119,6 +119,75 @@ def test_constructor_validation_matches_reference():
         MonoExponentialFit().fit([1, 2, 3], y)
 
 
+def _gauss(t, a, mu, sig):
+    return a * np.exp(-0.5 * ((t - mu) / sig) ** 2)
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference absent (GPU box)")
+def test_requests_the_kernels_do_not_implement_follow_the_reference():
+    """SURVEY 8(b)'s dispatch rule, second half: a generic `func`, or scipy kwargs that select another solver, run the
+    reference's behaviour -- one scipy.optimize.curve_fit per voxel under its skip / failure / r2 rules
+    (fitting.py:318-321, 827-870, 1026-1073).  Compared with the live reference on the same inputs: equal, not close
+    (it is the same scipy call on the same numbers).  No GPU involved."""
+    import warnings
+
+    import dosma_amd as dm
+
+    dosma = ref_harness.load_reference()
+    rng = np.random.default_rng(11)
+    x = np.linspace(-2.0, 3.0, 12)
+    N = 40
+    truth = np.stack([rng.uniform(1, 5, N), rng.uniform(-0.5, 1.0, N), rng.uniform(0.6, 1.5, N)], axis=1)
+    y = np.stack([_gauss(x, *p) for p in truth], axis=1) + 0.02 * rng.standard_normal((12, N))
+    y[:, 3] = 0                       # skip rule
+    y[:, 5] = 1e3                     # flat far-away column: the solver hits maxfev or converges badly -- whatever scipy does
+    p0 = (2.0, 0.0, 1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # (a) a 3-parameter user model, scalar p0, y_bounds
+        ref_p, ref_r = dosma.curve_fit(_gauss, x, y, p0=p0, y_bounds=(-10, 100))
+        got_p, got_r = dm.curve_fit(_gauss, x, y, p0=p0, y_bounds=(-10, 100))
+        assert np.array_equal(got_p, ref_p, equal_nan=True) and np.array_equal(got_r, ref_r)
+        assert np.isnan(got_p[3]).all() and got_r[3] == 0 and np.isnan(got_p[5]).all()  # all-zero / out of y_bounds
+        assert np.abs(got_p[6:] - truth[6:]).max() < 0.2
+        # (b) per-voxel p0 for one parameter, maxfev small enough that some voxels fail -> (nan, ...), 0
+        p0v = {"a": truth[:, 0] * 1.3, "mu": 0.0, "sig": 1.0}
+        ref_p, ref_r = dosma.curve_fit(_gauss, x, y, p0=p0v, maxfev=25)
+        got_p, got_r = dm.curve_fit(_gauss, x, y, p0=p0v, maxfev=25)
+        assert np.array_equal(got_p, ref_p, equal_nan=True) and np.array_equal(got_r, ref_r)
+        assert np.isnan(got_p[:, 0]).sum() > 1 and np.isfinite(got_p[:, 0]).sum() > 10
+        # (c) the kernels' own model with bounds= : scipy switches to trf and counts max_nfev (fitting.py:827-830)
+        te = np.arange(1, 9) * 10.0
+        ym = np.stack([s0 * np.exp(-te / t2) for s0, t2 in zip(rng.uniform(300, 1500, N), rng.uniform(15, 80, N))], axis=1)
+        ym += 10 * rng.standard_normal(ym.shape)
+        kw = dict(p0=(1000.0, -0.03), bounds=([0.0, -1.0], [5000.0, 0.0]))
+        ref_p, ref_r = dosma.curve_fit(dosma.monoexponential, te, ym, **kw)
+        got_p, got_r = dm.curve_fit(dm.monoexponential, te, ym, **kw)
+        assert np.array_equal(got_p, ref_p, equal_nan=True) and np.array_equal(got_r, ref_r)
+        # (d) sigma= through CurveFitter on MedicalVolumes with a mask, out_bounds, r2 threshold, nan_to_num
+        shape = (5, 4, 2)
+        vols = [dm.MedicalVolume(ym[e].reshape(shape), np.eye(4)) for e in range(8)]
+        rvols = [dosma.MedicalVolume(ym[e].reshape(shape), np.eye(4)) for e in range(8)]
+        mask = (np.arange(N).reshape(shape) % 3 != 0)
+        opts = dict(p0=(1000.0, -0.03), out_bounds=((0, 1400), (-1, 0)), r2_threshold=0.5, nan_to_num=-1.0,
+                    sigma=np.linspace(1.0, 2.0, 8))
+        ref_pv, ref_rv = dosma.CurveFitter(dosma.monoexponential, **opts).fit(te, rvols, mask=dosma.MedicalVolume(mask, np.eye(4)))
+        got_pv, got_rv = dm.CurveFitter(dm.monoexponential, **opts).fit(te, vols, mask=dm.MedicalVolume(mask, np.eye(4)))
+        assert np.array_equal(got_pv.volume, ref_pv.volume) and np.array_equal(got_rv.volume, ref_rv.volume)
+        assert (got_pv.volume[~mask] == -1.0).all() and (got_pv.volume == -1.0).sum() > (~mask).sum() * 2  # some out of bounds
+        # (e) a generic 1-parameter func through CurveFitter, default p0 (scipy: ones), process pool like the reference's
+        lin = lambda t, a: a * t  # noqa: E731
+        ref_pv, ref_rv = dosma.CurveFitter(lin, r2_threshold=None).fit(te, rvols)
+        got_pv, got_rv = dm.CurveFitter(lin, r2_threshold=None).fit(te, vols)
+        assert np.array_equal(got_pv.volume, ref_pv.volume) and np.array_equal(got_rv.volume, ref_rv.volume)
+        got_p, got_r = dm.curve_fit(_gauss, x, y, p0=p0, num_workers=2, chunksize=7)
+        ref_p, ref_r = dosma.curve_fit(_gauss, x, y, p0=p0)
+        assert np.array_equal(got_p, ref_p, equal_nan=True) and np.array_equal(got_r, ref_r)
+    # the route announces itself (a per-voxel CPU loop is not what a caller of this package expects silently)
+    with pytest.warns(RuntimeWarning, match="per-voxel scipy"):
+        dm.curve_fit(lin, te, ym[:, :2])
+
+
 @pytest.mark.skipif(not ref_harness.reference_available(), reason="/root/reference absent (GPU box)")
 def test_medical_volume_shim_vs_reference():
     dosma = ref_harness.load_reference()

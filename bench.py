@@ -433,7 +433,7 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     }
 
 
-UNET_SOURCES = ("unet_s3.hip", "unet_c4.hip", "unet_enc0.hip", "unet_kernels.hip", "unet_rw.hip", "unet_engine.hip", "qmri_internal.h")
+UNET_SOURCES = ("unet_s3.hip", "unet_c4.hip", "unet_d4.hip", "unet_c4_common.h", "unet_enc0.hip", "unet_kernels.hip", "unet_rw.hip", "unet_engine.hip", "qmri_internal.h")
 
 
 def _source_sha1(files):
@@ -572,11 +572,57 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
         return {"fit_s": t_fit, "seg_s": t_seg, "voxels": float(n), "slices": float(S), "t2_nonzero": fitted,
                 "mask_voxels": float(mask[..., 0].sum().item())}
 
+    # The same batch with the two pipes overlapped: the fit is fp64 VALU at three waves per SIMD, the network
+    # MFMA at one -- independent calls in the reference (qdess.py:64-103 segmentation, cube_quant.py:139-185 fit).  Volume v + 1's fit
+    # is launched on a second stream (its own result buffers) before volume v's segmentation is; no collective, per rank.
+    side = torch.cuda.Stream(device)
+    popt2 = torch.empty((n, 2), dtype=torch.float32, device=device)
+    r22 = torch.empty(n, dtype=torch.float32, device=device)
+
+    def overlapped(mine):
+        res = {}
+        bufs = [(popt, r2), (popt2, r22)]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def launch_fit(i):
+            a = make_args(L, vols[mine[i]], bufs[i & 1][0], bufs[i & 1][1], side.cuda_stream, "A")
+            a.device = local_rank
+            L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
+            done[i & 1].record(side)
+
+        if mine:
+            launch_fit(0)
+        for i, v in enumerate(mine):
+            t = time.perf_counter()
+            if i + 1 < len(mine):
+                launch_fit(i + 1)  # (its buffers: read two volumes ago, by the .item() below)
+            eng.forward_device(vols[v][0].data_ptr(), S, None, mask.data_ptr(), whiten=True, stream=stream.cuda_stream)
+            done[i & 1].synchronize()
+            torch.cuda.synchronize(device) if i + 1 == len(mine) else None
+            res[v] = {"fit_s": float("nan"), "seg_s": float("nan"), "voxels": float(n), "slices": float(S),
+                      "t2_nonzero": float((bufs[i & 1][0][:, 1] > 0).sum().item()),
+                      "mask_voxels": float(mask[..., 0].sum().item()), "wall_s": time.perf_counter() - t}
+        return res
+
     # warm-up (kernel module load, workspace allocation) on this rank's own volume, then the batch
     setup([rank])
     per_volume(rank)
     out = qd.run_batch(n_vol, per_volume, setup=setup)
     summ = out.pop("summary")
+    ovl = qd.run_batch(n_vol, per_volume, setup=setup, pipelined=overlapped)
+    osumm = ovl.pop("summary")
+    same = bool(np.array_equal(osumm["t2_nonzero"], summ["t2_nonzero"]) and np.array_equal(osumm["mask_voxels"], summ["mask_voxels"]))
+    out["two_streams"] = {
+        "what": "the same batch with volume v + 1's fit launched on a second HIP stream before volume v's segmentation "
+                "(fp64 VALU kernel beside the MFMA kernels); cfg5's wall_s / rates are this schedule's iff `adopted`",
+        "wall_s": ovl["wall_s"], "volumes_per_s": ovl["volumes_per_s"], "speedup_vs_back_to_back": out["wall_s"] / ovl["wall_s"],
+        "same_results": same, "back_to_back_wall_s": out["wall_s"], "back_to_back_volumes_per_s": out["volumes_per_s"],
+    }
+    # adopted as cfg5's schedule only when it is worth it (>= 5 %: the MFMA clock is power-limited, a second kernel costs clock)
+    adopt = same and ovl["wall_s"] * 1.05 <= out["wall_s"]
+    out["two_streams"]["adopted"] = bool(adopt)
+    if adopt:
+        out["wall_s"], out["volumes_per_s"], out["rank_busy_s"] = ovl["wall_s"], ovl["volumes_per_s"], ovl["rank_busy_s"]
     out.update({
         "config": f"{n_vol} volumes of 512x512x160 x 8 echoes: mono-exponential fit (MonoExponentialFit defaults) + UNet2D "
                   f"segmentation at 512x512 ({UNET_PARITY_MODE}) per volume, {per_gpu} volumes per GPU (BASELINE configs[4])",

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libqmri_hip.so")
-SOURCES = ["qmri_capi.hip", "monoexp_lm.hip", "linfit.hip", "lm_generic.hip", "unet_kernels.hip", "unet_rw.hip", "unet_s3.hip", "unet_c4.hip", "unet_enc0.hip", "unet_engine.hip", "dess.hip", "region_stats.hip"]
+SOURCES = ["qmri_capi.hip", "monoexp_lm.hip", "linfit.hip", "lm_generic.hip", "unet_kernels.hip", "unet_rw.hip", "unet_s3.hip", "unet_c4.hip", "unet_d4.hip", "unet_enc0.hip", "unet_engine.hip", "dess.hip", "region_stats.hip"]
 ARCH = "gfx950"
 
 

@@ -258,6 +258,12 @@ struct ConvS3Args {
 };
 bool conv_s3_supported(const ConvS3Args &k);
 bool conv_c4_supported(const ConvS3Args &k);
+// deconv_d4_kernel (unet_d4.hip): the transposed convolution on one wave per SIMD (4 row-tiles x 4 phases x 32 channels).  w_c4 then
+// holds ITS weight image: per (32-channel block, k-step = chunk * 2 + half) nine taps of [plane][32 rows][2 x 16 B] in shift-group
+// order (ConvLayer::upload_parity).  c4_mode as for conv_c4_kernel.
+bool conv_d4_supported(const ConvS3Args &k);
+bool conv_s3_takes_d4(const ConvS3Args &k);  // will conv_s3_launch run this transposed convolution on deconv_d4_kernel
+hipError_t conv_d4_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);
 int conv_c4_block_channels(int Cout);  // 128, or 64 for Cout = 64 (mod 128): the packing of w_c4 depends on it
 bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu);  // will conv_s3_launch run this layer on conv_c4_kernel
 hipError_t conv_c4_launch(const ConvS3Args &k, int num_cu, hipStream_t stream);

@@ -143,7 +143,37 @@ struct ConvLayer {
                         }
         e = w_s3.alloc(img.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
-        if (e != hipSuccess || deconv || Cout % 64 || ntaps != 9) return e;
+        if (e != hipSuccess || ntaps != 9) return e;
+        if (deconv) {
+            // deconv_d4_kernel: [nb = Cout / 32][k-step = chunk * 2 + half] slots of nine taps in SHIFT-GROUP order -- A: shift (0, 0),
+            // B: (0, -1), C: (-1, 0), D: (-1, -1) -- each [plane][32 rows][2 positions x 8 halfs], piece g of row r at position
+            // g ^ ((r >> 3) & 1).  pack_deconv_fused's tap order is by phase: t = 0..3 phase (0,0) with shifts (0,0) (0,-1) (-1,0)
+            // (-1,-1); 4, 5 phase (0,1) with (0,0) (-1,0); 6, 7 phase (1,0) with (0,0) (0,-1); 8 phase (1,1).
+            static const int kGroupOrder[9] = {0, 4, 6, 8, 1, 7, 2, 5, 3};  // slot s holds tap kGroupOrder[s]: phases 0 1 2 3 | 0 2 | 0 1 | 0
+            if (Cout % 32) return e;
+            const int chunks_d = Cin / 32;
+            std::vector<unsigned short> imd((size_t)Cout * K * 2);
+            for (int nb = 0; nb < Cout / 32; ++nb)
+                for (int ch = 0; ch < chunks_d; ++ch)
+                    for (int half = 0; half < 2; ++half)
+                        for (int sl = 0; sl < 9; ++sl) {
+                            const int tap = kGroupOrder[sl];
+                            const size_t slot = ((((size_t)nb * chunks_d + ch) * 2 + half) * 9 + sl) * (size_t)(32 * 32);
+                            for (int plane = 0; plane < 2; ++plane)
+                                for (int r = 0; r < 32; ++r)
+                                    for (int g = 0; g < 2; ++g) {
+                                        const int pos = g ^ ((r >> 3) & 1);
+                                        const size_t src = (size_t)(nb * 32 + r) * K + ((size_t)ch * 9 + tap) * 32 + half * 16 + g * 8;
+                                        const size_t dst = slot + (size_t)plane * (32 * 16) + (size_t)r * 16 + pos * 8;
+                                        const unsigned short *from = (plane ? lo.data() : hi.data()) + src;
+                                        for (int k = 0; k < 8; ++k) imd[dst + k] = from[k];
+                                    }
+                        }
+            e = w_c4.alloc(imd.size() * 2);
+            if (e == hipSuccess) e = hipMemcpy(w_c4.p, imd.data(), imd.size() * 2, hipMemcpyHostToDevice);
+            return e;
+        }
+        if (Cout % 64) return e;
         // conv_c4_kernel: [nb][chunk][half][tap] slots of [plane][B4 rows][2 positions x 8 halfs], B4 = 128 or 64 channels per block
         const int chunks = Cin / 32;
         const int B4 = qmri::conv_c4_block_channels(Cout);
@@ -824,11 +854,13 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
                 k.x = src; k.ldx = Cup; k.B = Bt; k.H = U->Hl[l + 1]; k.W = U->Wl[l + 1];
                 k.Cin = L.Cin; k.Cout = L.Cout; k.deconv = 1;
                 k.w = L.w_s3.p; k.winv = L.winv;
+                k.w_c4 = L.w_c4.p;  // (a transposed convolution's w_c4 is deconv_d4_kernel's image)
                 k.bias = L.bias.as<float>();
                 k.y = cat; k.ldy = 2 * C; k.yoff = 0;
                 k.sat = U->sat_ptr();
+                const bool d4 = qmri::conv_s3_takes_d4(k);
                 U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
-                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/bn%d;", l, U->Wl[l + 1] % 32 ? "flat" : "2d", qmri::conv_s3_block_channels(L.Cout, 1));
+                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/%s32;", l, U->Wl[l + 1] % 32 ? "flat" : "2d", d4 ? "d4x" : "bn");
             } else {
                 auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
                 k.w_hi = L.h_hi.as<__bf16>();

@@ -908,8 +908,20 @@ bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     return !(conv_c4_block_channels(k.Cout) == 64 && k.W % 32 != 0);
 }
 
+// The transposed convolutions: deconv_d4_kernel (unet_d4.hip) wherever it supports the layer -- by layer shape only, like
+// conv_s3_takes_c4.  QMRI_D4 = 0: conv_s3_kernel<32, *, DECONV> (round 2's kernel; the A/B switch of profiles/r05_d4_ab.txt).
+bool conv_s3_takes_d4(const ConvS3Args &k) {
+    static const int mode = [] {
+        const char *e = std::getenv("QMRI_D4");
+        return e ? std::atoi(e) : 1;
+    }();
+    if (!k.deconv || !k.w_c4 || k.c4_mode < 0 || !conv_d4_supported(k)) return false;
+    return k.c4_mode > 0 || mode > 0;
+}
+
 hipError_t conv_s3_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
     ConvS3Args k = k0;
+    if (conv_s3_takes_d4(k)) return conv_d4_launch(k, num_cu, stream);
     if (conv_s3_takes_c4(k, num_cu)) return conv_c4_launch(k, num_cu, stream);
     if (k.c4_mode > 0) return hipErrorInvalidValue;
     if (!conv_s3_supported(k)) return hipErrorInvalidValue;

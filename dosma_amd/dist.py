@@ -180,13 +180,16 @@ def broadcast_weights(weights: Dict[str, np.ndarray], src: int = 0) -> Dict[str,
     return out
 
 
-def run_batch(n_volumes: int, per_volume: Callable[[int], Dict[str, float]], *, setup: Callable[[List[int]], None] = None):
+def run_batch(n_volumes: int, per_volume: Callable[[int], Dict[str, float]], *, setup: Callable[[List[int]], None] = None,
+              pipelined: Callable[[List[int]], Dict[int, Dict[str, float]]] = None):
     """BASELINE.json configs[4] as a driver: a batch of ``n_volumes`` independent volumes over the ranks of one node.
 
     Volume v -> rank v mod world (:func:`partition`); ``setup(my_volumes)`` (optional) runs before the clock starts
     (e.g. making the rank's inputs resident in HBM); then, between two barriers, every rank runs
     ``per_volume(v)`` for its volumes -- the hot path on its own GPU, no collective inside -- and the wall time is the
-    MAX over ranks.  The per-volume scalars are all-gathered once at the end (control plane).
+    MAX over ranks.  The per-volume scalars are all-gathered once at the end (control plane).  ``pipelined(my_volumes)``
+    (optional) replaces the per-volume loop by the caller's own schedule over the rank's volumes (e.g. the fit of volume
+    v + 1 on a second stream under the segmentation of volume v) and returns the same per-volume scalars.
 
     Returns dict(wall_s, volumes, volumes_per_s, per_rank=[n volumes], summary={key: ndarray[n_volumes]}).
     """
@@ -198,7 +201,7 @@ def run_batch(n_volumes: int, per_volume: Callable[[int], Dict[str, float]], *, 
         setup(mine)
     barrier()
     t0 = time.perf_counter()
-    local = {v: per_volume(v) for v in mine}
+    local = pipelined(mine) if pipelined is not None else {v: per_volume(v) for v in mine}
     mine_s = time.perf_counter() - t0
     barrier()
     wall = allreduce_max(time.perf_counter() - t0)

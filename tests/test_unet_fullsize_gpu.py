@@ -80,10 +80,12 @@ def test_384_logits_parity_mode(net, ref384, max_batch):
     if os.environ.get("QMRI_C4", "1") == "1":
         # the product's dispatch (conv_s3_takes_c4, by layer shape only): every plain 3 x 3 convolution below the top level is
         # conv_c4_kernel's -- 64-channel blocks on 24-row image tiles, 128-channel blocks on image tiles and flattened levels --
-        # and conv_s3_kernel is left with the transposed convolutions
+        # and conv_s3_kernel was left with the transposed convolutions (round 4)
         assert {"s3/2d/c4x64", "s3/2d/c4x128", "s3/flat/c4x128"} <= fams, fams
         assert not fams & {"s3/2d/bn64", "s3/2d/bn128", "s3/flat/bn128"}, fams
-        assert all(t.split(":", 1)[1].endswith("bn32") for t in tr if "deconv" in t), tr
+        # ... and, since round 5, only where QMRI_D4 = 0 asks for it: the transposed convolutions are deconv_d4_kernel's
+        want = "bn32" if os.environ.get("QMRI_D4", "1") == "0" else "d4x32"
+        assert all(t.split(":", 1)[1].endswith(want) for t in tr if "deconv" in t), tr
     eng.close()
 
 

@@ -116,6 +116,47 @@ def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     assert np.array_equal(y4, whole)
 
 
+@pytest.mark.parametrize("cin,cout,hw,B", [
+    (64, 32, (16, 32), 3),      # image tiles, exactly one tile row, two chunks (four k-steps), one channel block
+    (128, 64, (20, 64), 2),     # image tiles, partial second tile row, two channel blocks
+    (32, 32, (8, 32), 3),       # one chunk = two k-steps: the shortest item (the weight request pointer wraps in the prologue)
+    (256, 128, (48, 96), 2),    # the 96 x 96 -> 192 x 192 shape family: three tile rows / columns, eight chunks, four channel blocks
+    (64, 64, (48, 48), 3),      # flattened, several 512-position tiles
+    (128, 96, (24, 24), 3),     # flattened, tiles straddle images, three channel blocks
+    (512, 64, (12, 12), 7),     # flattened 12 x 12 (the deepest level's transposed convolution), 16 chunks
+    (512, 128, (12, 12), 3),    # four channel blocks, 2.4 MB of weights: channel-major item order (the smaller layers above run tile-major)
+    (64, 32, (5, 6), 2),        # flattened, less than one tile
+    (32, 32, (16, 32), 300),    # more work items than CUs (300 tiles): several items per block, the K stream crosses item boundaries
+    (64, 64, (12, 12), 500),    # the same flattened: 56 tiles x 2 channel blocks per ... > 256 items
+])
+def test_deconv_d4_kernel_vs_torch(cin, cout, hw, B):
+    """deconv_d4_kernel (the transposed convolution on one wave per SIMD: 4 row-tiles x 4 phases x 32 channels; unet_d4.hip)
+    forced on, against the fp64 transposed convolution and against conv_s3_kernel<32, *, DECONV> on the same layer
+    (/root/reference/dosma/models/oaiunet2d.py:259-261: Conv2DTranspose(3x3, strides 2, SAME))."""
+    rng = np.random.default_rng(cin * 13 + cout + hw[0])
+    H, W = hw
+    x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, cout, cin)) / np.sqrt(2.25 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = torch_conv(x, k, b, False, True)
+    y4 = L.conv2d_nhwc_host(x, k, b, relu=False, transposed=True, precision="fp16x3-c4")
+    assert y4.shape == ref.shape == (B, 2 * H, 2 * W, cout)
+    assert np.abs(y4 - ref).max() < 3e-5, np.abs(y4 - ref).max()
+    y3 = L.conv2d_nhwc_host(x, k, b, relu=False, transposed=True, precision="fp16x3-s3")
+    assert np.abs(y3 - ref).max() < 3e-5
+    again = L.conv2d_nhwc_host(x, k, b, relu=False, transposed=True, precision="fp16x3-c4")
+    assert np.array_equal(y4, again)  # no atomics, no timing dependence: same bits every run
+    # the same bits whatever the batch a slice travels in (tiles of the flattened stack straddle images: slice 1 alone)
+    if B <= 8:
+        alone = L.conv2d_nhwc_host(x[1:2], k, b, relu=False, transposed=True, precision="fp16x3-c4")
+        assert np.array_equal(alone[0], y4[1])
+    # the epilogue's optional ReLU + affine (the network's transposed convolutions use neither; the operator entry offers both)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    ya = L.conv2d_nhwc_host(x, k, b, scale=sc, shift=sh, relu=True, transposed=True, precision="fp16x3-c4")
+    assert np.abs(ya - (np.maximum(ref, 0) * sc + sh)).max() < 3e-5
+
+
 def test_deconv_matches_the_scatter_definition():
     rng = np.random.default_rng(1)
     x = rng.standard_normal((1, 3, 4, 32)).astype(np.float32)

@@ -19,6 +19,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/unet_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/unet_write -o u -- python $R/scripts/prof_unet.py --precision fp16x3 --slices 160 --batch 160 --reps 2 > $OUT/unet_write.log 2>&1
 python $R/bench.py --print-kernel-hash > $OUT/kernel_hash.txt
 python $R/bench.py --print-unet-hash > $OUT/unet_hash.txt
-# ---- per-kernel-family PMC of the parity mode (MfmaUtil, waits, LDS, clock, MFMAs per us) and the conv_c4 / conv_s3 A/B on this box ----
+# ---- per-kernel-family PMC of the parity mode (MfmaUtil, waits, LDS, clock, MFMAs per us) and the deconv_d4 / conv_s3 A/B of the transposed convolutions on this box ----
 bash $R/scripts/pmc_unet_mode.sh fp16x3 > $OUT/unet_pmc_by_kernel.txt 2>&1
-bash $R/scripts/c4_ab.sh 0 1 0 1 > $OUT/c4_ab.txt 2>&1
+bash $R/scripts/env_ab.sh QMRI_D4 0 1 0 1 > $OUT/d4_ab.txt 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC of the conv_s3 / conv_c4 kernels in one precision mode (QMRI_C4=0|1|2 in the environment picks the kernel) (run on the GPU box): matrix-pipe busy, waits, LDS activity, clock.
+# PMC of the MFMA kernels of the network (conv_s3 / conv_c4 / deconv_d4 / enc0 / mid0 / out0) in one precision mode (QMRI_C4=0|1|2 in the environment picks the kernel) (run on the GPU box): matrix-pipe busy, waits, LDS activity, clock.
 #   scripts/pmc_unet_mode.sh bf16|fp16x3
 MODE=${1:-bf16}
 R=$GRAFT_REPO_ROOT
@@ -9,13 +9,15 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT -o u -- python $R/scripts/prof_unet.py --precision $MODE --slices 160 --batch 160 --reps 2 > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob, collections
-rows = [r for r in csv.DictReader(open(glob.glob("$OUT/*counter_collection.csv")[0])) if "conv_s3_kernel" in r["Kernel_Name"] or "conv_c4_kernel" in r["Kernel_Name"]]
+KERNELS = ("conv_s3_kernel", "conv_c4_kernel", "deconv_d4_kernel", "enc0_kernel", "mid0_kernel", "out0_kernel")
+rows = [r for r in csv.DictReader(open(glob.glob("$OUT/*counter_collection.csv")[0])) if any(k in r["Kernel_Name"] for k in KERNELS)]
 tr = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(glob.glob("$OUT/*kernel_trace.csv")[0]))}
 by = collections.defaultdict(collections.Counter)
 ids = collections.defaultdict(set)
 for r in rows:
     kn = r["Kernel_Name"]
-    k = ("c4" + kn.split("conv_c4_kernel")[1][:7]) if "conv_c4_kernel" in kn else kn.split("conv_s3_kernel")[1][:24]
+    k = (("c4" + kn.split("conv_c4_kernel")[1][:7]) if "conv_c4_kernel" in kn else ("d4" + kn.split("deconv_d4_kernel")[1][:7]) if "deconv_d4_kernel" in kn
+         else kn.split("conv_s3_kernel")[1][:24] if "conv_s3_kernel" in kn else [q for q in KERNELS if q in kn][0])
     by[k][r["Counter_Name"]] += float(r["Counter_Value"]); ids[k].add(r["Dispatch_Id"])
 for k, a in by.items():
     cyc = a["SQ_BUSY_CYCLES"] / 32

@@ -108,8 +108,8 @@ if os.path.exists(ut):
     print(json.dumps({k: u[k] for k in ("MfmaUtil", "mfma_gflop_issued", "mfma_gflop_algorithmic_x3", "wave_wait_frac")}))
 
 # ---- round 4: per-kernel-family PMC table and the same-box conv_c4 / conv_s3 A/B ----
-for name in ("unet_pmc_by_kernel.txt", "c4_ab.txt"):
+for name in ("unet_pmc_by_kernel.txt", "c4_ab.txt", "d4_ab.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         # (the A/B is referenced from the kernel sources as profiles/r04_c4_ab.txt: one per round, the newest collection)
-        shutil.copy(f, f"profiles/{rnd}_{name}" if name == "c4_ab.txt" else f"profiles/{tag}_{name}")
+        shutil.copy(f, f"profiles/{rnd}_{name}" if name in ("c4_ab.txt", "d4_ab.txt") else f"profiles/{tag}_{name}")

@@ -32,7 +32,11 @@ __device__ __forceinline__ void dma_buf16(unsigned voff, const i32x4 &rsrc, unsi
 
 __device__ __forceinline__ void nt_store16(void *dst, const uint4 &v) {
     u32x4 t = {v.x, v.y, v.z, v.w};
+#ifdef QMRI_PLAIN_STORES  // (A/B build: default-policy stores)
+    *reinterpret_cast<u32x4 *>(dst) = t;
+#else
     __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(dst));
+#endif
 }
 
 // raw buffer descriptor (gfx9 V#): base, stride 0, num_records = kPadOff bytes, DATA_FORMAT = 32 (0x00020000)

@@ -165,7 +165,7 @@ def test_product_never_imports_the_oracle():
     subprocess.check_call([sys.executable, "-c", code])
 
 
-@pytest.mark.parametrize("source,min_dma", [("unet_s3.hip", 20), ("unet_enc0.hip", 6), ("unet_c4.hip", 8)])
+@pytest.mark.parametrize("source,min_dma", [("unet_s3.hip", 20), ("unet_enc0.hip", 6), ("unet_c4.hip", 8), ("unet_d4.hip", 8)])
 def test_lds_dma_statements_own_m0(tmp_path, source, min_dma):
     """unet_s3.hip / unet_enc0.hip / unet_c4.hip issue their LDS-DMA through inline asm that writes M0 (the LDS destination base) and does
     not restore it.  That is only sound if nothing else in those kernels reads M0: check the generated gfx950 assembly --
@@ -222,6 +222,38 @@ def test_conv_c4_kernel_has_no_scratch_traffic(tmp_path):
                     pure += 1
                     assert not any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in lines), name
         assert checked >= 4 and pure >= 3, (name, checked, pure)  # (>= 4 of the 6 intervals of a chunk)
+
+
+def test_deconv_d4_kernel_has_no_scratch_traffic(tmp_path):
+    """deconv_d4_kernel (unet_d4.hip) keeps its LDS-DMA requests in flight across k-steps like conv_c4_kernel: the same guard on its
+    generated gfx950 code -- no scratch access, no v_accvgpr_read, accumulators written to LDS from AccVGPRs, 108 MFMAs per k-step,
+    and no vmcnt(0) inside a k-step that does not carry the per-item halo set-up."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "dosma_amd", "csrc", "unet_d4.hip")
+    out = tmp_path / "unet_d4.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "dosma_amd", "csrc"), src, "-o", str(out)])
+    text = out.read_text()
+    for flat, reads in (("Lb1", 50), ("Lb0", 38)):  # operand reads per k-step: 50, or 38 with the row reuse of image tiles
+        name = f"_ZN4qmri16deconv_d4_kernelI{flat}EEEvNS_10ConvS3ArgsE"
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        all_lines = [ln.strip() for ln in body.splitlines()]
+        assert not any(ln.startswith("scratch_") for ln in all_lines), (name, [ln for ln in all_lines if ln.startswith("scratch_")][:3])
+        assert not any(ln.startswith("v_accvgpr_read") for ln in all_lines), name
+        assert any(ln.startswith("ds_write_b128") and ", a[" in ln for ln in all_lines), name
+        mfma = sum(ln.startswith("v_mfma") for ln in all_lines)
+        assert mfma == 4 * 108, (name, mfma)                      # four k-step bodies (first / odd / even / odd of the loop)
+        b128 = sum(ln.startswith("ds_read_b128") for ln in all_lines)
+        assert 4 * reads + 16 <= b128 <= 4 * reads + 16 + 96, (name, b128)  # + the item's first operand set + the epilogue's read-backs
+        # every k-step interval carries the (exec-masked) halo set-up of an item change, so the intervals cannot be told apart like
+        # conv_c4_kernel's: the kernel's ONLY vmcnt(0) waits are the prologue's, the two behind a channel block's parameter loads
+        # (prologue / item change) and the one in front of s_endpgm
+        zero_waits = [ln for ln in all_lines if ln.startswith("s_waitcnt") and "vmcnt(0)" in ln]
+        assert len(zero_waits) <= 4, (name, len(zero_waits))
+        assert sum(1 for iv in body.split("s_barrier") if sum(ln.strip().startswith("v_mfma") for ln in iv.splitlines()) >= 100) >= 3, name
 
 
 def test_conv_c4_lds_layouts_are_bank_conflict_free():

@@ -253,7 +253,7 @@ def test_deconv_d4_kernel_has_no_scratch_traffic(tmp_path):
         # (prologue / item change) and the one in front of s_endpgm
         zero_waits = [ln for ln in all_lines if ln.startswith("s_waitcnt") and "vmcnt(0)" in ln]
         assert len(zero_waits) <= 4, (name, len(zero_waits))
-        assert sum(1 for iv in body.split("s_barrier") if sum(ln.strip().startswith("v_mfma") for ln in iv.splitlines()) >= 100) >= 3, name
+        assert sum(1 for iv in body.split("s_barrier") if sum(ln.strip().startswith("v_mfma") for ln in iv.splitlines()) >= 100) >= 2, name
 
 
 def test_conv_c4_lds_layouts_are_bank_conflict_free():

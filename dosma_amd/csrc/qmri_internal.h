@@ -295,6 +295,7 @@ hipError_t mask_planes_launch(const unsigned char *mask_sp4, long long P, int S,
                               hipStream_t stream);
 hipError_t absmax_launch(const float *x, long long n, unsigned int *out, hipStream_t stream);
 hipError_t scale_copy_launch(const float *x, long long n, float f, float *y, hipStream_t stream);
+int whiten_stats_doubles();  // size of whiten_launch's `stats` buffer: [sum, sum of squares, mean, -] + the per-block partial sums
 hipError_t whiten_launch(const float *x, long long n, double eps, double *stats, float *y,
                          hipStream_t stream);
 

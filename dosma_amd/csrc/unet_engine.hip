@@ -653,7 +653,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         const int l = d->depth - 1;
         U_TRY(U->bottom.alloc((size_t)B * U->Hl[l] * U->Wl[l] * U->nf[l] * 4));
     }
-    U_TRY(U->stats.alloc(4 * sizeof(double)));
+    U_TRY(U->stats.alloc((size_t)qmri::whiten_stats_doubles() * sizeof(double)));
     *handle = U.release();
     return QMRI_OK;
 }

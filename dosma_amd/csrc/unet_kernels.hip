@@ -951,8 +951,14 @@ hipError_t cast_launch(const void *x, long long n, void *y, int to_bf16, hipStre
 }
 
 // ---- whiten_volume (seg_model.py:114-127): two-pass mean / std in fp64, then (x - mean)/(std + eps) ---
-__global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, long long n, double center,
-                                                  int square, double *__restrict__ out) {
+// The reductions are DETERMINISTIC: every block writes its partial sum to its own slot, one block adds the slots in a fixed order.
+// (Rounds 1-4 let the blocks atomicAdd their partial sums: the order of 2048 double additions -- hence the last bits of mean and
+//  standard deviation, hence the rounding of a handful of whitened voxels -- changed from run to run; two of 160 slices of a 512 x 512
+//  volume then came out with logits 6e-5 apart in one run of ten.  Found by round 5's bitwise test across pass sizes.)
+constexpr int kWhitenBlocks = 2048;  // slots of the partial-sum table behind the three statistics (qmri_internal.h: whiten_stats_doubles)
+__global__ __launch_bounds__(256) void whiten_partial_kernel(const float *__restrict__ x, long long n, const double *__restrict__ stats,
+                                                             int square, double *__restrict__ part) {
+    const double center = square ? stats[2] : 0.0;
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
@@ -960,10 +966,28 @@ __global__ __launch_bounds__(256) void sum_kernel(const float *__restrict__ x, l
         acc += square ? d * d : d;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __shared__ double w4[4];
+    if ((threadIdx.x & 63) == 0) w4[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+}
+// stats[slot] = sum of part[0 .. nblocks) in a fixed order (thread t adds slots t, t + 256, ...; then a fixed tree); slot 0 also
+// leaves the mean in stats[2]
+__global__ __launch_bounds__(256) void whiten_final_kernel(const double *__restrict__ part, int nblocks, double *__restrict__ stats,
+                                                           int slot, long long n) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[i];
+    __shared__ double tree[256];
+    tree[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) tree[threadIdx.x] += tree[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[slot] = tree[0];
+        if (slot == 0) stats[2] = tree[0] / (double)n;
+    }
 }
 
 __global__ __launch_bounds__(256) void whiten_apply_kernel(const float *__restrict__ x, long long n,
@@ -976,24 +1000,6 @@ __global__ __launch_bounds__(256) void whiten_apply_kernel(const float *__restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
         y[i] = (float)(((double)x[i] - mean) * inv);
-}
-
-__global__ void mean_from_sum_kernel(double *stats, long long n) { stats[2] = stats[0] / (double)n; }
-
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x, long long n,
-                                                    double *__restrict__ stats) {
-    const double mean = stats[2];
-    double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const double d = (double)x[i] - mean;
-        acc += d * d;
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(stats + 1, part[0] + part[1] + part[2] + part[3]);
 }
 
 // ---- activation exponent of the parity mode (unet_engine.hip: Unet::sat): max |x| of the input, and y = x * 2^-S ----
@@ -1032,16 +1038,19 @@ hipError_t scale_copy_launch(const float *x, long long n, float f, float *y, hip
     return hipGetLastError();
 }
 
-hipError_t whiten_launch(const float *x, long long n, double eps, double *stats /*[3] device*/, float *y,
+int whiten_stats_doubles() { return 4 + kWhitenBlocks; }
+
+hipError_t whiten_launch(const float *x, long long n, double eps, double *stats /*[whiten_stats_doubles()] device*/, float *y,
                          hipStream_t stream) {
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, 0.0, 0, stats);
-    hipLaunchKernelGGL(mean_from_sum_kernel, dim3(1), dim3(1), 0, stream, stats, n);
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, stats);
+    static_assert(kWhitenBlocks == 2048, "the grid cap above");
+    double *part = stats + 4;  // [kWhitenBlocks] partial sums (the caller's buffer holds whiten_stats_doubles() doubles)
+    hipLaunchKernelGGL(whiten_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, stats, 0, part);
+    hipLaunchKernelGGL(whiten_final_kernel, dim3(1), dim3(256), 0, stream, part, (int)blocks, stats, 0, n);
+    hipLaunchKernelGGL(whiten_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, stats, 1, part);
+    hipLaunchKernelGGL(whiten_final_kernel, dim3(1), dim3(256), 0, stream, part, (int)blocks, stats, 1, n);
     hipLaunchKernelGGL(whiten_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, stats, eps, y);
     return hipGetLastError();
 }

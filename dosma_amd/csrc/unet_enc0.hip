@@ -671,262 +671,6 @@ __global__ __launch_bounds__(NW * 64) void out0_kernel(const Out0Args A) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// out0r_kernel (round 5) -- the same layer as out0_kernel with the WEIGHTS IN REGISTERS and the taps grouped by column.
-// out0_kernel gives every wave ONE image row: 54 MFMAs per tile from 72 ds_read_b128 (per tap and k-half a weight pair and a pixel
-// pair: 1.33 reads per MFMA; LDS active 0.57 of the cycles, MfmaUtil 0.66 at a clock of 1.53 GHz -- profiles/r05e_unet_pmc_by_kernel.txt),
-// and all of a wave's MFMAs chain through one accumulator.  A 32 -> 32 convolution's weights are 9 taps x 2 k-halves x (hi, lo) = 36
-// operand fragments = 144 registers per lane: with 8 waves per block (two per SIMD, 256 registers each) they stay in the register
-// file for the whole kernel, and the LDS holds nothing but the two halo buffers -- which therefore grow to 16-row tiles (halo 18 x 34
-// = 1.20 x the tile; 12-row tiles read 1.24 x).  A wave owns TWO rows; for a k-half and a column shift kx it reads the FOUR halo rows
-// under them once (8 reads) and multiplies the three taps (ky, kx) of both rows from them: 18 MFMAs alternating between the two
-// accumulators.  48 reads per 108 MFMAs (0.44 per MFMA; LDS bytes per pixel a third of out0_kernel's).  No operand double buffering:
-// the other wave of the SIMD multiplies while this one waits for its eight fragments.
-constexpr int kR_Waves = 8;
-constexpr int kR_Rows = 2 * kR_Waves;                    // rows of a tile
-constexpr int kR_Threads = kR_Waves * 64;
-constexpr int kR_Halo = (kR_Rows + 2) * kPitch;          // 612 halo pixels
-constexpr int kR_NJ = (kR_Halo + 7) / 8;                 // 77 DMA instructions of 8 pixel-chunks
-constexpr int kR_HaloBytes = kR_NJ * 1024;
-constexpr int kR_PerWave = (kR_NJ + kR_Waves - 1) / kR_Waves;  // 10
-
-__global__ __launch_bounds__(kR_Threads) void out0r_kernel(const Out0Args A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *halo = smem;                                                   // two halo buffers
-    float *hw = reinterpret_cast<float *>(halo + 2 * kR_HaloBytes);              // classifier: [32 channels][4], then the constant [4]
-    float *prm = hw + 32 * 4 + 4;                                                 // bias / winv [32]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kgrp = lane >> 5;
-
-    // classifier with the BatchNorm affine and the weight scale folded in (see out0_kernel)
-    for (int i = tid; i < 32 * 4 + 4 + 32; i += kR_Threads) {
-        const int NC = A.nc;
-        if (i < 128) {
-            const int ch = i >> 2, c = i & 3;
-            hw[i] = c < NC ? A.head_w[ch * NC + c] * A.scale[ch] * A.winv : 0.f;
-        } else if (i < 132) {
-            const int c = i - 128;
-            float acc0 = c < NC ? A.head_b[c] : 0.f;
-            if (c < NC)
-                for (int ch = 0; ch < 32; ++ch) acc0 = fmaf(A.head_w[ch * NC + c], A.shift[ch], acc0);
-            hw[i] = acc0;
-        } else {
-            prm[i - 132] = A.bias[i - 132] / A.winv;
-        }
-    }
-    // the weights: conv_s3_kernel's slot image [tap][plane][32 channels][64 B]; this lane's fragment of (tap, k-half, plane)
-    const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
-    f16x8 wr[9][2][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                wr[t][kk][pl] = *reinterpret_cast<const f16x8 *>(static_cast<const unsigned char *>(A.w) + t * 4096 + pl * 2048 + (woff ^ (kk * 32)));
-    // pixels: halo row 2 wave + r (r = 0..3: the rows under this wave's two output rows), column shift kx, plane hi, k-half 0
-    // (computed where it is read -- six vector instructions per offset, issued beside the other wave's MFMAs -- instead of twelve
-    //  registers: the weights leave 48 for everything else)
-    const int hp_w = 2 * wave * kPitch + l31;
-
-    // this lane's share of the halo requests: instruction j = wave + 8 i moves pixels 8 j .. 8 j + 7, lane = (pixel, piece).  Piece i of
-    // a lane is halo pixel hp_i = hp_0 + 64 i: the swizzle bits (hp >> 1 .. 3) -- hence (plane, q) -- are the lane's for every i, and
-    // (row, column) advance by 64 = 34 + 30.  Ten row / column / offset triples per lane would be 20 registers the weights need.
-    const int hp_first = wave * 8 + (lane >> 3);
-    const int hy_first = hp_first / kPitch, hx_first = hp_first - hy_first * kPitch;
-    const unsigned piece_const = (unsigned)((((lane & 7) >> 2) ^ ((hp_first >> 1) & 1)) * 64 + (((lane & 7) & 3) ^ ((hp_first >> 2) & 3)) * 16);
-    const unsigned px_bytes = (unsigned)A.ldx * 4u;
-    const unsigned halo_lds = lds_off(halo);
-    const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
-
-    const int tiles_x = A.W / 32, tiles_y = (A.H + kR_Rows - 1) / kR_Rows;  // (the last row of tiles may reach beyond the slice)
-    const int per_img = tiles_x * tiles_y;
-    const int ntiles = A.B * per_img;
-    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
-        b = t / per_img;
-        const int r = t - b * per_img;
-        const int ty = r / tiles_x;
-        y0 = ty * kR_Rows;
-        x0 = (r - ty * tiles_x) * 32;
-    };
-    auto request_halo = [&](int t, int buf) {
-        int b, y0, x0;
-        tile_origin(t, b, y0, x0);
-        const unsigned long long base =
-            (unsigned long long)xbase + (unsigned long long)(((((long long)b * A.H + y0 - 1) * A.W + x0 - 1) * A.ldx + A.xoff) * 4);
-        i32x4 rsrc;
-        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffull));
-        rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffull));
-        rsrc[2] = 0x40000000;
-        rsrc[3] = 0x00020000;
-        int hy = hy_first, hx = hx_first;
-#pragma unroll
-        for (int i = 0; i < kR_PerWave; ++i) {
-            const int j = wave + kR_Waves * i;
-            if (j < kR_NJ) {  // (wave-uniform)
-                const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-                const bool ok = hy < kR_Rows + 2 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-                const unsigned off = (unsigned)(hy * A.W + hx) * px_bytes + piece_const;
-                dma16_buf(ok ? off : 0xFFFFFFF0u, rsrc, halo_lds + (unsigned)(buf * kR_HaloBytes + j * 1024));
-            }
-            hx += 64 - kPitch;  // + 64 pixels = one row + 30 columns
-            hy += 1;
-            if (hx >= kPitch) {
-                hx -= kPitch;
-                hy += 1;
-            }
-            asm volatile("" : "+v"(hy), "+v"(hx));  // (one piece at a time: volatile statements keep their order, so the ten offsets are not all computed -- and held -- up front)
-        }
-    };
-
-    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
-    if ((gridDim.x & 7) == 0) {  // XCD x walks a contiguous eighth of the tiles (see out0_kernel)
-        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
-        t_first = xcd * per + (blockIdx.x >> 3);
-        t_stride = gridDim.x >> 3;
-        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
-    }
-    int tile = t_first;
-    if (tile >= t_end) return;
-    int t_b, t_y0, t_x0;
-    tile_origin(tile, t_b, t_y0, t_x0);
-    request_halo(tile, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int buf = 0;
-
-    // The classifier of tile t runs UNDER the multiplications of tile t + 1: the barrier at the end of a tile starts all eight waves
-    // together, so a per-tile sequence [MFMA loop | classifier] would leave the matrix pipes idle while every wave is in its vector
-    // phase (that form measured 1.46-1.52 ms against out0_kernel's 1.27-1.31).  A finished tile's accumulators move to `prev`; the
-    // next tile's groups 1 and 3 carry the previous tile's vector work (a row each: bias, ReLU, classifier, partner sum, stores).
-    f32x16 prev[2];
-    int p_b = 0, p_y0 = 0, p_x0 = 0;
-    bool have_prev = false;
-    // the classifier of row o of `prev` (self-contained: nothing but `prev` lives from one group to the next)
-    auto classifier_row = [&](int o) {
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int kg = kgrp;
-            asm volatile("" : "+v"(kg));  // (the parameter reads of one channel quad at a time: all sixteen float4s up front do not fit beside the weights)
-            const int c0 = 8 * q + 4 * kg;
-            const float4 b4 = *reinterpret_cast<const float4 *>(prm + c0);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(prev[o][4 * q + r] + bb[r], 0.f);
-                const float4 w4 = *reinterpret_cast<const float4 *>(hw + (c0 + r) * 4);
-                z[0] = fmaf(v, w4.x, z[0]);
-                z[1] = fmaf(v, w4.y, z[1]);
-                z[2] = fmaf(v, w4.z, z[2]);
-                z[3] = fmaf(v, w4.w, z[3]);
-            }
-        }
-        // both halves of the wave need the sum over all 32 channels (v_permlane32_swap: see out0_kernel)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[c]), __float_as_uint(z[c]), false, false);
-            z[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        }
-        const int yy = p_y0 + 2 * wave + o;
-        if (kgrp == 0 && yy < A.H) {
-            const long long pix = ((long long)p_b * A.H + yy) * A.W + p_x0 + l31;
-            const int NC = A.nc;
-            float zz[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) zz[c] = z[c] + hw[128 + c];
-            if (NC == 4) {
-                if (A.logits) *reinterpret_cast<float4 *>(A.logits + pix * 4) = make_float4(zz[0], zz[1], zz[2], zz[3]);
-                if (A.mask)
-                    *reinterpret_cast<unsigned *>(A.mask + pix * 4) = (zz[0] > 0.f ? 1u : 0u) | (zz[1] > 0.f ? 0x100u : 0u) |
-                                                                      (zz[2] > 0.f ? 0x10000u : 0u) | (zz[3] > 0.f ? 0x1000000u : 0u);
-            } else {
-                for (int c = 0; c < NC; ++c) {
-                    if (A.logits) A.logits[pix * NC + c] = zz[c];
-                    if (A.mask) A.mask[pix * NC + c] = zz[c] > 0.f ? 1 : 0;
-                }
-            }
-        }
-    };
-    // stores a wave has in flight from the classifier of the tile at row origin y0 (they are issued AFTER the next halo's requests)
-    auto stores_of = [&](int y0) -> int {
-        const int rows_stored = y0 + 2 * wave + 1 < A.H ? 2 : (y0 + 2 * wave < A.H ? 1 : 0);  // (wave-uniform)
-        return A.nc == 4 ? rows_stored * ((A.logits ? 1 : 0) + (A.mask ? 1 : 0)) : -1;       // (-1: a loop of stores -> drain)
-    };
-
-    while (true) {
-        const int next = tile + t_stride;
-        const bool more = next < t_end;
-        if (more) request_halo(next, buf ^ 1);  // (in front of the MFMA loop: see out0_kernel)
-        const unsigned char *hb = halo + buf * kR_HaloBytes;
-
-        f32x16 acc[2];
-        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc[1] = acc[0];
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {  // group g = (k-half kk, column shift kx)
-            const int kk = g / 3, kx = g % 3;
-            // the hi-plane fragments of the four halo rows first (12 MFMAs: hi and lo weight parts on them), then the lo-plane fragments
-            // into the SAME registers (6 MFMAs): 16 fragment registers instead of 32 -- what `prev` needs beside the 144 of the weights
-            f16x8 x4[4];
-            int off[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int hp = hp_w;
-                asm volatile("" : "+v"(hp));
-                off[r] = halo_off(hp + r * kPitch + kx, 0, kgrp) ^ (kk * 32);
-                x4[r] = *reinterpret_cast<const f16x8 *>(hb + off[r]);
-            }
-            // (ky, output row o): taps (ky, kx) on halo row o + ky; consecutive MFMAs alternate between the two accumulators
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int o = 0; o < 2; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kk][0], x4[o + ky], acc[o], 0, 0, 0);
-#pragma unroll
-                for (int o = 0; o < 2; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kk][1], x4[o + ky], acc[o], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x4[r] = *reinterpret_cast<const f16x8 *>(hb + (off[r] ^ 64));
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int o = 0; o < 2; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ky * 3 + kx][kk][0], x4[o + ky], acc[o], 0, 0, 0);
-            }
-            if ((g == 1 || g == 3) && have_prev) classifier_row(g >> 1);  // (group 0 follows the requests, group 5 precedes the barrier)
-            __builtin_amdgcn_sched_barrier(0);  // one group at a time: hoisting the next groups' reads costs the weights their registers
-        }
-        const int p_stores = have_prev ? stores_of(p_y0) : 0;
-        prev[0] = acc[0];
-        prev[1] = acc[1];
-        p_b = t_b;
-        p_y0 = t_y0;
-        p_x0 = t_x0;
-        have_prev = true;
-        if (next >= t_end) break;
-        tile = next;
-        tile_origin(tile, t_b, t_y0, t_x0);
-        buf ^= 1;
-        // the next halo has landed (this wave's pieces; then, past the barrier, everyone's) and every wave is done with the old buffer.
-        // The wait is COUNTED: the logits / mask stores this wave issued after its requests stay in flight -- exactly as many as it DID
-        // issue (a row below the slice stores nothing, and a count that is too high would leave that many halo pieces unwaited)
-        if (p_stores == 4)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (p_stores == 2)
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (p_stores == 1)
-            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // the last tile's classifier
-    classifier_row(0);
-    classifier_row(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // mid0_kernel -- Conv2D(64 -> 32, 3x3) + ReLU on the 384^2-class level (the first convolution after the top concatenation,
 // oaiunet2d.py:266-276), same skeleton with TWO input chunks: 73 KB of LDS-resident weights + one halo buffer per chunk
 // (2 x 43 KB) fill the CU's LDS, so the buffers rotate by chunk, not by tile: chunk 0 of tile t + 1 is requested in front of
@@ -1143,31 +887,10 @@ size_t out0_lds_bytes() { return out0_lds_bytes_n(kOut0Waves); }
 
 bool out0_supported(const Out0Args &k) { return k.W % 32 == 0 && k.B > 0 && k.H > 0 && k.nc >= 1 && k.nc <= 4; }
 
-static size_t out0r_lds_bytes() { return 2 * (size_t)kR_HaloBytes + (32 * 4 + 4 + 32) * 4; }
-static_assert(2 * kR_HaloBytes + 672 <= 160 * 1024, "LDS");
-
-// QMRI_OUT0 = 1 (default): out0_kernel (LDS-resident weights, 12 waves of one row); 2: out0r_kernel (weights in registers, 16-row tiles:
-// measured 1.45-1.52 ms against 1.27-1.31 in four forms, profiles/r05_out0r_ab.txt)
-static int out0_variant() {
-    static const int v = [] {
-        const char *e = std::getenv("QMRI_OUT0");
-        return e ? std::atoi(e) : 1;
-    }();
-    return v;
-}
-
+// (round 5 tried the same layer with the weights in registers -- out0r_kernel, 8 waves of two rows, 16-row tiles, a third of the LDS
+//  bytes per pixel -- in four forms: 1.45-1.52 ms against this kernel's 1.27-1.31, profiles/r05_out0r_ab.txt; removed again)
 hipError_t out0_launch(const Out0Args &k, int num_cu, hipStream_t stream) {
     if (!out0_supported(k)) return hipErrorInvalidValue;
-    if (out0_variant() >= 2) {
-        const size_t lds = out0r_lds_bytes();
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(out0r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        const long long ntiles = (long long)k.B * ((k.H + kR_Rows - 1) / kR_Rows) * (k.W / 32);
-        const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(out0r_kernel, dim3((unsigned)grid), dim3(kR_Threads), lds, stream, k);
-        return hipGetLastError();
-    }
     const size_t lds = out0_lds_bytes();
     auto fn = out0_kernel<kOut0Waves>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

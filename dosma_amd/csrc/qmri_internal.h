@@ -254,8 +254,8 @@ struct ConvS3Args {
     // cost model picks the kernel per layer, 1 = conv_c4_kernel (error if it does not take the layer), -1 = conv_s3_kernel.
     const void *w_c4;
     int c4_mode;
-    int c4_split;        // filled by conv_c4_launch: split the items of the last, partial round by channels (QMRI_C4_SPLIT=0 turns it off);
-                         // filled by conv_d4_launch: 1 = tile-major item order (the channel blocks of a tile side by side on one XCD)
+    int c4_split;        // filled by conv_c4_launch: split the items of the last, partial round by channels (QMRI_C4_SPLIT=0 turns it off)
+    int d4_tile_major;   // filled by conv_d4_launch: 1 = tile-major item order (the channel blocks of a tile side by side on one XCD)
 };
 bool conv_s3_supported(const ConvS3Args &k);
 bool conv_c4_supported(const ConvS3Args &k);

@@ -173,12 +173,12 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
 
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     // work item -> (channel block, tile).  Channel-major (an XCD's blocks share one channel block's weights, tiles re-read per block)
-    // where the layer's weights are bigger than an L2 can keep; TILE-MAJOR (A.c4_split = 1, set by the launcher: a layer's whole
+    // where the layer's weights are bigger than an L2 can keep; TILE-MAJOR (A.d4_tile_major, set by the launcher: a layer's whole
     // weight image <= 1.5 MB) where they fit: the channel blocks of a tile run side by side on one XCD, the tile's halo comes from HBM
     // once and from that L2 for the other blocks -- the transposed convolutions of the 96 x 96 and 48 x 48 levels moved 2.1-4.2 x
     // their input through the fabric (profiles/r04g_unet_reads_by_layer.txt) at 3.6-4.1 TB/s of total traffic.
     const int nbk = A.nb;
-    const bool tile_major = A.c4_split != 0;
+    const bool tile_major = A.d4_tile_major != 0;
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
         int t;
         if (tile_major) {
@@ -459,7 +459,8 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
         d4_sched_rows<6, 4, kRB_, kRB_, kRB_>();                                                          \
         /* every halo piece of the next k-step and every weight piece of earlier k-steps this wave requested has landed; */ \
         /* every wave has issued its last operand reads of this k-step */                                 \
-        if (!D4_DBG(128)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitN) : "memory");                    \
+        /* (lgkmcnt(0): group D's operand reads, issued during C, have RETURNED before any wave may request into the buffer they read) */ \
+        if (!D4_DBG(128)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kWaitN) : "memory");          \
         if (!D4_DBG(64)) asm volatile("s_barrier" ::: "memory");                                           \
         /* ---- D (12): reads A's operands of the next k-step; the first halo pieces of k-step u + 2 (the buffer is free now) ---- */ \
         if (!last_) {                                                                                     \
@@ -724,7 +725,7 @@ hipError_t conv_d4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         return e ? std::atoi(e) : -1;
     }();
     const size_t wbytes = (size_t)k.Cin * 9 * k.Cout * 4;
-    k.c4_split = (k.nb > 1 && k.nb <= kPrmBlocks && (order < 0 ? wbytes <= (size_t)3 << 19 : order != 0)) ? 1 : 0;
+    k.d4_tile_major = (k.nb > 1 && k.nb <= kPrmBlocks && (order < 0 ? wbytes <= (size_t)3 << 19 : order != 0)) ? 1 : 0;
     static const int dbg = [] {
         const char *e = std::getenv("QMRI_D4_DBG");
         return e ? std::atoi(e) : 0;

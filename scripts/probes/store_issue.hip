@@ -54,7 +54,7 @@ __global__ void k(unsigned char *out, long long per_block, int iters, int stride
 // bursts between compute phases, like a persistent convolution kernel: `items` times { spin for `spin` shader clocks without touching
 // memory; every wave issues `per_burst` wave-stores and does NOT wait for them }.  What the burst costs = (time - items * spin) / items.
 template <int PATTERN>
-__global__ void kb(unsigned char *out, long long per_block, int items, int per_burst, int stride, int spin) {
+__global__ void kb(unsigned char *out, long long per_block, int items, int per_burst, int stride, int spin, int stagger) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     unsigned char *base = out + (long long)blockIdx.x * per_block;
     u32x4 v = {(unsigned)lane, (unsigned)wave, 3u, 4u};
@@ -70,6 +70,11 @@ __global__ void kb(unsigned char *out, long long per_block, int items, int per_b
         step = 8LL * stride;
     }
     long long n = 0;
+    if (stagger > 0) {  // (out of phase: CU groups start a fraction of a compute phase apart; blockIdx / 8 so that every XCD has all phases)
+        const unsigned long long late = (unsigned long long)((blockIdx.x >> 3) % stagger) * (unsigned long long)spin / stagger;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < late) __builtin_amdgcn_s_sleep(2);
+    }
     for (int it = 0; it < items; ++it) {
         if (spin > 0) {
             const unsigned long long t0 = __builtin_readcyclecounter();
@@ -86,14 +91,16 @@ __global__ void kb(unsigned char *out, long long per_block, int items, int per_b
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+static int g_blocks = 256;      // CUs that take part
+static int g_stagger = 0;       // > 0: block b starts (b % g_stagger) * spin / g_stagger clocks late (CUs out of phase)
 template <int PATTERN>
 static double run_bursts(unsigned char *buf, long long per_block, int items, int per_burst, int stride, int spin) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((kb<PATTERN>), dim3(256), dim3(256), 0, 0, buf, per_block, items, per_burst, stride, spin);
+    hipLaunchKernelGGL((kb<PATTERN>), dim3(g_blocks), dim3(256), 0, 0, buf, per_block, items, per_burst, stride, spin, g_stagger);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((kb<PATTERN>), dim3(256), dim3(256), 0, 0, buf, per_block, items, per_burst, stride, spin);
+    hipLaunchKernelGGL((kb<PATTERN>), dim3(g_blocks), dim3(256), 0, 0, buf, per_block, items, per_burst, stride, spin, g_stagger);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -154,6 +161,23 @@ int main() {
         const double t_f5 = run_bursts<2>(buf, per_block, 40, 64, 512, spin);
         printf("spin %6d clocks (%6.1f us per item): contiguous +%5.2f us | 16 x 64 B (c4 epilogue) stride 256: +%5.2f, 512: +%5.2f | 8 x 128 B (full records) stride 256: +%5.2f, 512: +%5.2f\n",
                spin, t_spin / 40, (t_c - t_spin) / 40, (t_h - t_spin) / 40, (t_h5 - t_spin) / 40, (t_f - t_spin) / 40, (t_f5 - t_spin) / 40);
+    }
+    // is the burst's cost the CU's own, or the chip's (everyone bursting at once)?  fewer CUs; and all CUs, out of phase
+    printf("\nthe same burst (c4 epilogue pattern, stride 256, spin 60000) with fewer CUs taking part, and with the CUs out of phase:\n");
+    for (int nb : {256, 128, 64, 32, 8}) {
+        g_blocks = nb;
+        const double t_spin = run_bursts<0>(buf, per_block, 40, 0, 256, 60000);
+        const double t_h = run_bursts<1>(buf, per_block, 40, 64, 256, 60000);
+        const double t_f = run_bursts<2>(buf, per_block, 40, 64, 256, 60000);
+        printf("%3d CUs: half-records +%5.2f us per burst, full records +%5.2f\n", nb, (t_h - t_spin) / 40, (t_f - t_spin) / 40);
+    }
+    g_blocks = 256;
+    for (int st : {2, 4, 8}) {
+        g_stagger = st;
+        const double t_spin = run_bursts<0>(buf, per_block, 40, 0, 256, 60000);
+        const double t_h = run_bursts<1>(buf, per_block, 40, 64, 256, 60000);
+        const double t_f = run_bursts<2>(buf, per_block, 40, 64, 256, 60000);
+        printf("256 CUs in %d phases: half-records +%5.2f us per burst, full records +%5.2f\n", st, (t_h - t_spin) / 40, (t_f - t_spin) / 40);
     }
     return 0;
 }

@@ -30,6 +30,7 @@ namespace qmri {
 namespace {
 
 constexpr int kMaxR = QMRI_MAX_REGIONS;
+constexpr int kMaxBlocks = 2048;  // grid cap of the histogram kernels
 
 struct StatsK {
     const void *values;
@@ -52,6 +53,9 @@ struct StatsState {
     unsigned long long prefix[2 * kMaxR];  // key prefix found so far, per (region, statistic)
     unsigned long long rank[2 * kMaxR];    // remaining rank inside the prefix
     unsigned int hist[2 * kMaxR][2048];  // (rows of 256 with 8-bit digits)
+    // per-block partial sums of the two moment passes: added in a FIXED order by select_pick_kernel (atomicAdd of doubles -- rounds
+    // 1-4 -- made the last bits of mean and standard deviation depend on the order the blocks finished in)
+    double part[kMaxBlocks][kMaxR];
 };
 
 __device__ __forceinline__ double load_value(const StatsK &K, long long i) {
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(BITS == 11 ? 1024 : 256) void select_hist_kernel(co
     extern __shared__ unsigned int s_h[];  // [2 * nreg][1 << BITS]
     __shared__ unsigned long long s_prefix[2 * kMaxR];
     __shared__ double s_a[kMaxR], s_mean[kMaxR];
+    __shared__ double s_w[16][kMaxR];  // per-wave partial sums (added in wave order: no floating-point atomics)
     __shared__ unsigned long long s_n[kMaxR];
     constexpr int NB = 1 << BITS;
     const int nreg = K.nkeys + 1;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(BITS == 11 ? 1024 : 256) void select_hist_kernel(co
                     c += __shfl_down(c, off);
                 }
                 if ((threadIdx.x & 63) == 0) {
-                    atomicAdd(&s_a[r], a);
+                    s_w[threadIdx.x >> 6][r] = a;
                     if (MOMENT == 1) atomicAdd(&s_n[r], (unsigned long long)c);
                 }
             }
@@ -190,27 +195,43 @@ __global__ __launch_bounds__(BITS == 11 ? 1024 : 256) void select_hist_kernel(co
         if (c) atomicAdd(&S->hist[i / NB][i % NB], c);
     }
     if (MOMENT && threadIdx.x < nreg) {
-        if (MOMENT == 1) {
-            atomicAdd(&S->sum[threadIdx.x], s_a[threadIdx.x]);
-            atomicAdd(&S->count[threadIdx.x], s_n[threadIdx.x]);
-        } else {
-            atomicAdd(&S->ssd[threadIdx.x], s_a[threadIdx.x]);
-        }
+        double a = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += s_w[w][threadIdx.x];
+        S->part[blockIdx.x][threadIdx.x] = a;  // (this block's share: select_pick_kernel adds the blocks' shares in block order)
+        if (MOMENT == 1) atomicAdd(&S->count[threadIdx.x], s_n[threadIdx.x]);
     }
 }
 
 // One block per (region, statistic): [first pass: mean and the wanted rank,] the bin that holds the rank (block-wide scan of
 // the histogram row), prefix extended by the digit, row cleared for the next pass.
 template <int BITS>
-__global__ __launch_bounds__(256) void select_pick_kernel(StatsState *S, int pass, int shift) {
+__global__ __launch_bounds__(256) void select_pick_kernel(StatsState *S, int pass, int shift, int nblocks) {
     constexpr int NB = 1 << BITS, PER = NB / 256;
     __shared__ unsigned long long s_scan[256];
     __shared__ unsigned long long s_rank;
+    __shared__ double s_tree[256];
     const int q = blockIdx.x, r = q >> 1, t = threadIdx.x;
+    if (pass < 2) {
+        // the moment of this pass: the histogram blocks' partial sums in a fixed order (thread t: blocks t, t + 256, ...; then a fixed
+        // tree).  Both blocks of a region compute it (the odd one needs the count only, but keeps the barriers uniform); the even one stores
+        double a = 0.0;
+        for (int b = t; b < nblocks; b += 256) a += S->part[b][r];
+        s_tree[t] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) s_tree[t] += s_tree[t + o];
+            __syncthreads();
+        }
+        if (t == 0 && (q & 1) == 0) {
+            if (pass == 0) S->sum[r] = s_tree[0];
+            else S->ssd[r] = s_tree[0];
+        }
+        __syncthreads();
+    }
     if (t == 0) {
         if (pass == 0) {
             const unsigned long long n = S->count[r];
-            if ((q & 1) == 0) S->mean[r] = n ? S->sum[r] / (double)n : NAN;
+            if ((q & 1) == 0) S->mean[r] = n ? s_tree[0] / (double)n : NAN;
             // numpy.median: mean of elements (n-1)//2 and n//2 of the sorted values
             s_rank = n ? ((q & 1) ? n / 2 : (n - 1) / 2) : 0ull;
         } else {
@@ -305,6 +326,7 @@ hipError_t region_stats_launch(const void *values, int f64, const void *labels, 
     const int nreg = K.nkeys + 1;
     long long blocks = (N + 256 * 8 - 1) / (256 * 8);
     if (blocks > (long long)num_cu * 8) blocks = (long long)num_cu * 8;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     if (blocks < 1) blocks = 1;
     hipError_t e = hipMemsetAsync(S, 0, sizeof(StatsState), stream);
     if (e != hipSuccess) return e;
@@ -334,12 +356,12 @@ hipError_t region_stats_launch(const void *values, int f64, const void *labels, 
             if (pass == 0) hipLaunchKernelGGL((select_hist_kernel<11, 1>), g, b, lds, stream, K, S, pass, shift, width);
             else if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<11, 2>), g, b, lds, stream, K, S, pass, shift, width);
             else hipLaunchKernelGGL((select_hist_kernel<11, 0>), g, b, lds, stream, K, S, pass, shift, width);
-            hipLaunchKernelGGL(select_pick_kernel<11>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift);
+            hipLaunchKernelGGL(select_pick_kernel<11>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift, (int)g.x);
         } else {
             if (pass == 0) hipLaunchKernelGGL((select_hist_kernel<8, 1>), g, b, lds, stream, K, S, pass, shift, width);
             else if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<8, 2>), g, b, lds, stream, K, S, pass, shift, width);
             else hipLaunchKernelGGL((select_hist_kernel<8, 0>), g, b, lds, stream, K, S, pass, shift, width);
-            hipLaunchKernelGGL(select_pick_kernel<8>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift);
+            hipLaunchKernelGGL(select_pick_kernel<8>, dim3(2 * nreg), dim3(256), 0, stream, S, pass, shift, (int)g.x);
         }
         ++pass;
     }

@@ -120,6 +120,12 @@ def test_full_size_map_against_a_histogram():
         std = float(np.sqrt((h * (vals - mean) ** 2).sum() / n))
         assert g["# Voxels"] == n and g["Median"] == 0.5 * (lo + hi)
         assert abs(g["Mean"] - mean) < 1e-11 * mean and abs(g["Std"] - std) < 1e-10 * std
+    # the same bits every time: the moments are per-block partial sums added in a fixed order (round 5; floating-point atomics
+    # before that made the last bits of mean / std depend on the order the blocks finished in)
+    for _ in range(3):
+        again = qv.to_metrics(mask, labels, bounds=(0, 100))
+        for col in ("Mean", "Std", "Median", "# Voxels"):
+            assert np.array_equal(again[col].to_numpy(), gpu[col].to_numpy()), col
 
 
 def test_device_pointer_entry_matches_the_host_entry():

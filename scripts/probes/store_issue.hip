@@ -36,8 +36,7 @@ __global__ void k(unsigned char *out, long long per_block, int iters, int stride
     for (int i = 0; i < iters; ++i) {
         long long off = ((long long)i * nw + wave) * step + lane_off;
         if (PATTERN == 1 && (i & 1)) off += 64;  // (hi plane, then lo plane of the same records)
-        off %= per_block - 4096 * 4;
-        off &= ~15LL;
+        off &= (per_block >> 1) - 16;  // (wrap by a power-of-two mask: a 64-bit modulo here was ~190 clocks of ALU per store -- the first version of this probe measured that)
         u32x4 *dst = reinterpret_cast<u32x4 *>(base + off);
         if (NT)
             __builtin_nontemporal_store(v, dst);
@@ -83,14 +82,58 @@ __global__ void kb(unsigned char *out, long long per_block, int items, int per_b
         for (int i = 0; i < per_burst; ++i, ++n) {
             long long off = (n * nw + wave) * step + lane_off;
             if (PATTERN == 1 && (i & 1)) off += 64;
-            off %= per_block - 4096 * 4;
-            off &= ~15LL;
+            off &= (per_block >> 1) - 16;
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(base + off));
             v.x += 1;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// the same burst with narrower stores (8 and 4 bytes per lane), full-record pattern: is the CU's limit bytes or instructions?
+template <int WORDS>
+__global__ void kw(unsigned char *out, long long per_block, int items, int per_burst, int spin) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned char *base = out + (long long)blockIdx.x * per_block;
+    unsigned v = lane;
+    long long n = 0;
+    for (int it = 0; it < items; ++it) {
+        if (spin > 0) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(2);
+        }
+        for (int i = 0; i < per_burst; ++i, ++n) {
+            long long off = ((n * nw + wave) * 64 + lane) * (4LL * WORDS);   // contiguous: 64 lanes x WORDS dwords
+            off &= (per_block >> 1) - 4LL * WORDS;
+            if (WORDS == 4) {
+                u32x4 t = {v, v, v, v};
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(base + off));
+            } else if (WORDS == 2) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 t = {v, v};
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x2 *>(base + off));
+            } else {
+                __builtin_nontemporal_store(v, reinterpret_cast<unsigned *>(base + off));
+            }
+            v += 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int WORDS>
+static double run_width(unsigned char *buf, long long per_block, int waves, int items, int per_burst, int spin) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kw<WORDS>), dim3(256), dim3(waves * 64), 0, 0, buf, per_block, items, per_burst, spin);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kw<WORDS>), dim3(256), dim3(waves * 64), 0, 0, buf, per_block, items, per_burst, spin);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3;
+}
+
 static int g_blocks = 256;      // CUs that take part
 static int g_stagger = 0;       // > 0: block b starts (b % g_stagger) * spin / g_stagger clocks late (CUs out of phase)
 template <int PATTERN>
@@ -178,6 +221,19 @@ int main() {
         const double t_h = run_bursts<1>(buf, per_block, 40, 64, 256, 60000);
         const double t_f = run_bursts<2>(buf, per_block, 40, 64, 256, 60000);
         printf("256 CUs in %d phases: half-records +%5.2f us per burst, full records +%5.2f\n", st, (t_h - t_spin) / 40, (t_f - t_spin) / 40);
+    }
+    // bytes or instructions?  64 wave-stores per wave and burst, contiguous, 16 / 8 / 4 bytes per lane; and 8 waves (two per SIMD) of 32
+    printf("\n64 wave-stores per wave and burst (4 waves, contiguous, spin 60000): us per burst beyond the spin-only run\n");
+    {
+        const double t0 = run_width<4>(buf, per_block, 4, 40, 0, 60000);
+        printf("16 B per lane (256 KB per CU): +%5.2f us | 8 B per lane (128 KB): +%5.2f | 4 B per lane (64 KB): +%5.2f\n",
+               (run_width<4>(buf, per_block, 4, 40, 64, 60000) - t0) / 40, (run_width<2>(buf, per_block, 4, 40, 64, 60000) - t0) / 40,
+               (run_width<1>(buf, per_block, 4, 40, 64, 60000) - t0) / 40);
+        const double t8 = run_width<4>(buf, per_block, 8, 40, 0, 60000);
+        printf("8 waves x 32 wave-stores of 16 B per lane (256 KB per CU): +%5.2f us; 1 wave x 256: +%5.2f; 2 waves x 128: +%5.2f\n",
+               (run_width<4>(buf, per_block, 8, 40, 32, 60000) - t8) / 40,
+               (run_width<4>(buf, per_block, 1, 40, 256, 60000) - run_width<4>(buf, per_block, 1, 40, 0, 60000)) / 40,
+               (run_width<4>(buf, per_block, 2, 40, 128, 60000) - run_width<4>(buf, per_block, 2, 40, 0, 60000)) / 40);
     }
     return 0;
 }

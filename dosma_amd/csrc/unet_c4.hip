@@ -80,6 +80,7 @@ struct C4Geo {
     static constexpr int HSLOTS = (NJ + 3) / 4;              // halo pieces per wave: 10 (the 40th repeats the wave's first) / 14
     static constexpr int STAGE = 8192;                       // epilogue staging per wave: two 4 KB windows (the tiles of a row pair)
 };
+constexpr int kPrmBlocksC4 = 2;          // channel blocks whose epilogue parameters the LDS holds at once (tile-major item order: two-block layers)
 constexpr int kRing = 8;                 // weight ring slots of [2 planes][32 CT rows][32 B] = 2048 CT bytes
 // One s_barrier per kBarEvery steps.  What the ring allows: the operands of step u are read during step u - 1, i.e. after the last
 // barrier at or before step u - 2; a wave's counted wait in front of a barrier covers everything it issued kInFlight or more steps
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     unsigned char *ring = smem + 2 * kHBuf;                            // [kRing][2 planes][128][32 B swizzled]
     int *outpix = reinterpret_cast<int *>(ring + kRing * kSlot);       // [kMTile] output pixel of a tile position, or -1 (FLAT only)
     float *prm = reinterpret_cast<float *>(outpix + (FLAT ? kMTile : 0));  // bias | scale | shift, [128] each
-    unsigned *hofft = reinterpret_cast<unsigned *>(prm + 3 * kBN);     // [kHSlots][256] per-lane halo source offsets (see below)
+    unsigned *hofft = reinterpret_cast<unsigned *>(prm + 3 * kBN * kPrmBlocksC4);  // [kHSlots][256] per-lane halo source offsets (see below)
 #ifdef QMRI_C4_TIMELINE
     unsigned long long *tsbuf = reinterpret_cast<unsigned long long *>(hofft + kHSlots * kThreads);
 #endif
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     const int P = FLAT ? A.P : kPitch2D;
     const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
     const int ntiles = A.ntiles;
+    const bool tile_major = A.d4_tile_major != 0;
     const int wsteps = A.steps;  // chunks * 18 steps per work item
 
     // the activation descriptor's base is the first IMAGE the requested tile's halo touches (set_halo_sources): per-lane offsets
@@ -220,8 +222,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
 
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
-        nb = w / ntiles;
-        const int t = w - nb * ntiles;
+        // channel-major (an XCD's blocks share one channel block's weights; every block re-reads the tiles) or -- where the launcher
+        // found the layer's whole weight image small enough to stay in an XCD's L2 beside the activations (A.d4_tile_major; two-block
+        // layers) -- TILE-MAJOR: the two channel blocks of a tile run side by side on one XCD and its halo comes from HBM once
+        int t;
+        if (tile_major) {
+            t = w >> 1;
+            nb = w & 1;
+        } else {
+            nb = w / ntiles;
+            t = w - nb * ntiles;
+        }
         if (FLAT) {
             f0 = A.P + t * kMTile;
             b = y0 = x0 = 0;
@@ -308,7 +319,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         w_so = wrap ? w_next : w_so + (unsigned)kSlot;
         w_left = wrap ? wsteps : w_left;
     };
-    auto refresh_w_next = [&](int k) { w_next = first_slot_of(item_at(k + 1) / ntiles); };
+    auto refresh_w_next = [&](int k) {
+        const int w = item_at(k + 1);
+        w_next = first_slot_of(tile_major ? (w & 1) : w / ntiles);
+    };
     refresh_w_next(0);
 
     // ---- per-lane LDS read offsets ----
@@ -390,10 +404,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         for (int j = 0; j < kJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
     };
 
+    // epilogue parameters: [block slot][bias | scale | shift][kBN]; channel-major: slot 0 = the current block (reloaded when it
+    // changes), tile-major: both blocks of the layer, once
     auto load_prm = [&](int nb) {
-        for (int i = tid; i < 3 * kBN; i += kThreads) {
-            const int c = i % kBN, which = i / kBN;
-            const int n = nb * kBN + c;
+        const int nslots = tile_major ? 2 : 1;
+        for (int i = tid; i < 3 * kBN * nslots; i += kThreads) {
+            const int sl = i / (3 * kBN), j = i - sl * 3 * kBN;
+            const int c = j % kBN, which = j / kBN;
+            const int n = (tile_major ? sl : nb) * kBN + c;
             prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
         }
     };
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             const int jc = kSub ? sub_cq : j;
             const int cbase = n0 + jc * 32;
             if (pr == 0) {
-                const float *pp = prm + jc * 32 + 8 * oc;
+                const float *pp = prm + (tile_major ? t_nb * 3 * kBN : 0) + jc * 32 + 8 * oc;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     p.b[h] = *reinterpret_cast<const f32x4 *>(pp + 4 * h);
@@ -695,7 +713,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
         refresh_w_next(cur);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t_nb != prev_nb) {
+        if (t_nb != prev_nb && !tile_major) {
             load_prm(t_nb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -775,7 +793,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
 template <bool FLAT, int CT>
 static constexpr size_t c4_lds_bytes() {
     using G = C4Geo<FLAT, CT>;
-    size_t n = (size_t)2 * G::HBUF + (size_t)kRing * 2048 * CT + (FLAT ? G::MTILE * 4 : 0) + (size_t)3 * 32 * CT * 4 + (size_t)G::HSLOTS * kThreads * 4;
+    size_t n = (size_t)2 * G::HBUF + (size_t)kRing * 2048 * CT + (FLAT ? G::MTILE * 4 : 0) + (size_t)3 * 32 * CT * 4 * kPrmBlocksC4 + (size_t)G::HSLOTS * kThreads * 4;
 #ifdef QMRI_C4_TIMELINE
     n += 128;
 #endif
@@ -841,6 +859,14 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     }
     k.nj = 0;  // (conv_s3_kernel's field: the halo geometry is C4Geo's here)
     k.nwork = k.nb * k.ntiles;
+    // item order: tile-major for two-block layers whose weight image (<= 2.4 MB) stays in an XCD's 4 MB L2 beside the activations -- a
+    // property of the layer (QMRI_C4_ORDER = 0 / 1 forces channel- / tile-major: the A/B switch).  The sums do not depend on it.
+    static const int order = [] {
+        const char *e = std::getenv("QMRI_C4_ORDER");
+        return e ? std::atoi(e) : -1;
+    }();
+    const size_t wbytes = (size_t)k.Cin * 9 * k.Cout * 4;
+    k.d4_tile_major = (k.nb == 2 && (order < 0 ? wbytes <= (size_t)2400 << 10 : order != 0)) ? 1 : 0;
     static const int split = [] {
         const char *e = std::getenv("QMRI_C4_SPLIT");
         return e ? std::atoi(e) : 1;

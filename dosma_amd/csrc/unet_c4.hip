@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     const int P = FLAT ? A.P : kPitch2D;
     const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
     const int ntiles = A.ntiles;
-    const bool tile_major = A.d4_tile_major != 0;
+    const bool tile_major = A.d4_tile_major != 0;  // (groups of TWO channel blocks: see decode_work)
+    const int per_group = 2 * ntiles;
     const int wsteps = A.steps;  // chunks * 18 steps per work item
 
     // the activation descriptor's base is the first IMAGE the requested tile's halo touches (set_halo_sources): per-lane offsets
@@ -223,12 +224,13 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
         // channel-major (an XCD's blocks share one channel block's weights; every block re-reads the tiles) or -- where the launcher
-        // found the layer's whole weight image small enough to stay in an XCD's L2 beside the activations (A.d4_tile_major; two-block
-        // layers) -- TILE-MAJOR: the two channel blocks of a tile run side by side on one XCD and its halo comes from HBM once
+        // found two channel blocks' weights small enough to stay in an XCD's L2 beside the activations (A.d4_tile_major) -- TILE-MAJOR in
+        // groups of two channel blocks: the pair runs side by side on one XCD and the tile's halo comes from HBM once per pair
         int t;
-        if (tile_major) {
-            t = w >> 1;
-            nb = w & 1;
+        if (tile_major) {  // w = (group * ntiles + tile) * 2 + j, channel block = 2 group + j (two-block layers: one group)
+            const int cg = w / per_group, r = w - cg * per_group;
+            t = r >> 1;
+            nb = 2 * cg + (r & 1);
         } else {
             nb = w / ntiles;
             t = w - nb * ntiles;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     };
     auto refresh_w_next = [&](int k) {
         const int w = item_at(k + 1);
-        w_next = first_slot_of(tile_major ? (w & 1) : w / ntiles);
+        w_next = first_slot_of(tile_major ? 2 * (w / per_group) + ((w % per_group) & 1) : w / ntiles);
     };
     refresh_w_next(0);
 
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         for (int i = tid; i < 3 * kBN * nslots; i += kThreads) {
             const int sl = i / (3 * kBN), j = i - sl * 3 * kBN;
             const int c = j % kBN, which = j / kBN;
-            const int n = (tile_major ? sl : nb) * kBN + c;
+            const int n = (tile_major ? (nb & ~1) + sl : nb) * kBN + c;
             prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
         }
     };
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
             const int jc = kSub ? sub_cq : j;
             const int cbase = n0 + jc * 32;
             if (pr == 0) {
-                const float *pp = prm + (tile_major ? t_nb * 3 * kBN : 0) + jc * 32 + 8 * oc;
+                const float *pp = prm + (tile_major ? (t_nb & 1) * 3 * kBN : 0) + jc * 32 + 8 * oc;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     p.b[h] = *reinterpret_cast<const f32x4 *>(pp + 4 * h);
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
         refresh_w_next(cur);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t_nb != prev_nb && !tile_major) {
+        if (tile_major ? (t_nb >> 1) != (prev_nb >> 1) : t_nb != prev_nb) {
             load_prm(t_nb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -859,14 +861,14 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     }
     k.nj = 0;  // (conv_s3_kernel's field: the halo geometry is C4Geo's here)
     k.nwork = k.nb * k.ntiles;
-    // item order: tile-major for two-block layers whose weight image (<= 2.4 MB) stays in an XCD's 4 MB L2 beside the activations -- a
+    // item order: tile-major in groups of two channel blocks where a group's weights (<= 2.4 MB) stay in an XCD's 4 MB L2 beside the activations -- a
     // property of the layer (QMRI_C4_ORDER = 0 / 1 forces channel- / tile-major: the A/B switch).  The sums do not depend on it.
     static const int order = [] {
         const char *e = std::getenv("QMRI_C4_ORDER");
         return e ? std::atoi(e) : -1;
     }();
-    const size_t wbytes = (size_t)k.Cin * 9 * k.Cout * 4;
-    k.d4_tile_major = (k.nb == 2 && (order < 0 ? wbytes <= (size_t)2400 << 10 : order != 0)) ? 1 : 0;
+    const size_t pair_bytes = (size_t)k.Cin * 9 * 2 * bn * 4;  // weights of two channel blocks
+    k.d4_tile_major = (k.nb % 2 == 0 && (order < 0 ? pair_bytes <= (size_t)2400 << 10 : order != 0)) ? 1 : 0;
     static const int split = [] {
         const char *e = std::getenv("QMRI_C4_SPLIT");
         return e ? std::atoi(e) : 1;

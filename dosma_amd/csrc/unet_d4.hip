@@ -178,12 +178,19 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
     // once and from that L2 for the other blocks -- the transposed convolutions of the 96 x 96 and 48 x 48 levels moved 2.1-4.2 x
     // their input through the fabric (profiles/r04g_unet_reads_by_layer.txt) at 3.6-4.1 TB/s of total traffic.
     const int nbk = A.nb;
-    const bool tile_major = A.d4_tile_major != 0;
+    // G = A.d4_tile_major: channel blocks per GROUP (0 / 1: channel-major).  Items run group by group; inside a group tile by tile, the
+    // group's G channel blocks of a tile side by side: w = (group * ntiles + tile) * G + j, channel block = group * G + j.  The launcher
+    // picks the largest G (<= kPrmBlocks) whose G blocks of weights stay in an XCD's L2 (<= 2.4 MB): the layer's input is then read
+    // nb / G times instead of nb times (up3: 2 instead of 8, up4: 8 instead of 16; up2 / up1: once).
+    const int G = A.d4_tile_major;
+    const bool tile_major = G > 1;
+    const int per_group = ntiles * (G > 1 ? G : 1);
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
         int t;
         if (tile_major) {
-            t = w / nbk;
-            nb = w - t * nbk;
+            const int cg = w / per_group, r = w - cg * per_group;
+            t = __builtin_amdgcn_readfirstlane(r / G);  // (wave-uniform; the divisions run on the vector ALU)
+            nb = __builtin_amdgcn_readfirstlane(cg * G + (r - t * G));
         } else {
             nb = w / ntiles;
             t = w - nb * ntiles;
@@ -282,7 +289,11 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
         w_so = wrap ? w_next : w_so + (unsigned)kWSlot;
         w_left = wrap ? ksteps : w_left;
     };
-    auto nb_of = [&](int w) -> int { return tile_major ? w % nbk : w / ntiles; };
+    auto nb_of = [&](int w) -> int {
+        if (!tile_major) return w / ntiles;
+        const int cg = w / per_group, r = w - cg * per_group;
+        return __builtin_amdgcn_readfirstlane(cg * G + r % G);
+    };
     auto refresh_w_next = [&](int k) { w_next = first_slot_of(nb_of(item_at(k + 1))); };
     refresh_w_next(0);
 
@@ -368,13 +379,13 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
     };
 
     // epilogue parameters: [block slot][bias | scale | shift][32]; channel-major: slot 0 = the current block (reloaded when it
-    // changes), tile-major: every block of the layer, once
+    // changes), tile-major: the G blocks of the current group (reloaded when the group changes)
     auto load_prm = [&](int nb) {
-        const int nslots = tile_major ? nbk : 1;
+        const int nslots = tile_major ? G : 1;
         for (int i = tid; i < 3 * 32 * nslots; i += kThreads) {
             const int sl = i / 96, j = i - sl * 96;
             const int c = j & 31, which = j >> 5;
-            const int n = (tile_major ? sl : nb) * 32 + c;
+            const int n = (tile_major ? (nb / G) * G + sl : nb) * 32 + c;
             prm[i] = which == 0 ? (A.bias ? A.bias[n] : 0.f) : which == 1 ? (A.scale ? A.scale[n] : 1.f) : (A.shift ? A.shift[n] : 0.f);
         }
     };
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
         put_pair(0);
         Prm8 p;
         {
-            const float *pp = prm + (tile_major ? t_nb * 96 : 0) + 8 * (lane & 3);
+            const float *pp = prm + (tile_major ? (t_nb % G) * 96 : 0) + 8 * (lane & 3);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 p.b[h] = *reinterpret_cast<const f32x4 *>(pp + 4 * h);
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
         decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
         refresh_w_next(cur);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t_nb != prev_nb && !tile_major) {
+        if (tile_major ? t_nb / G != prev_nb / G : t_nb != prev_nb) {
             load_prm(t_nb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -719,13 +730,16 @@ hipError_t conv_d4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     k.nj = 0;
     k.nwork = k.nb * k.ntiles;
     // item order (see the kernel): tile-major where the layer's weight image stays in an XCD's L2 beside the activations -- a
-    // property of the layer (QMRI_D4_ORDER = 0 / 1 forces channel- / tile-major: the A/B switch)
+    // property of the layer (QMRI_D4_ORDER = 0: channel-major everywhere, 1: the largest group whatever the weights' size; the A/B switch)
     static const int order = [] {
         const char *e = std::getenv("QMRI_D4_ORDER");
         return e ? std::atoi(e) : -1;
     }();
-    const size_t wbytes = (size_t)k.Cin * 9 * k.Cout * 4;
-    k.d4_tile_major = (k.nb > 1 && k.nb <= kPrmBlocks && (order < 0 ? wbytes <= (size_t)3 << 19 : order != 0)) ? 1 : 0;
+    const size_t block_bytes = (size_t)k.Cin * 9 * 32 * 4;  // weights of one 32-channel block
+    int G = 0;
+    for (int g = 2; g <= kPrmBlocks && g <= k.nb; ++g)
+        if (k.nb % g == 0 && (order > 0 || g * block_bytes <= (size_t)2400 << 10)) G = g;
+    k.d4_tile_major = order == 0 ? 0 : G;
     static const int dbg = [] {
         const char *e = std::getenv("QMRI_D4_DBG");
         return e ? std::atoi(e) : 0;

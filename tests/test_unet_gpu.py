@@ -92,6 +92,8 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     # XCD, which runs as four 32-channel sub-items (the channel-split last round); flattened: 285 tiles -> 36 per XCD, 4 leftover
     (32, 128, (16, 32), 264),
     (64, 128, (12, 12), 800),
+    (256, 512, (12, 12), 3),    # four channel blocks = two groups of two (2.4 MB per pair): group by group, tile-major inside (down4.conv1)
+    (96, 256, (16, 64), 70),    # one group of two on image tiles, more items than blocks: pairs side by side, parameters of both resident
 ])
 def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     """conv_c4_kernel (one wave per SIMD, 128 x 128 register tiles; unet_c4.hip) forced on, against the fp64 convolution
@@ -124,7 +126,9 @@ def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     (64, 64, (48, 48), 3),      # flattened, several 512-position tiles
     (128, 96, (24, 24), 3),     # flattened, tiles straddle images, three channel blocks
     (512, 64, (12, 12), 7),     # flattened 12 x 12 (the deepest level's transposed convolution), 16 chunks
-    (512, 128, (12, 12), 3),    # four channel blocks, 2.4 MB of weights: channel-major item order (the smaller layers above run tile-major)
+    (512, 128, (12, 12), 3),    # four channel blocks = one group of four (2.4 MB of weights stay in L2): tile-major
+    (512, 256, (12, 12), 2),    # eight channel blocks = two groups of four: group by group, tile-major inside (the up3.deconv shape)
+    (2048, 64, (5, 6), 2),      # 2.4 MB of weights PER channel block: no group fits -- channel-major item order
     (64, 32, (5, 6), 2),        # flattened, less than one tile
     (32, 32, (16, 32), 300),    # more work items than CUs (300 tiles): several items per block, the K stream crosses item boundaries
     (64, 64, (12, 12), 500),    # the same flattened: 56 tiles x 2 channel blocks per ... > 256 items

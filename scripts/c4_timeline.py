@@ -25,4 +25,5 @@ print("per launch (the forward's c4 layers in order), microseconds; item 2 | ite
 for r in a:
     ct, flat, chunks, items = r[:4]
     print(f"CT {ct} flat {flat} chunks {chunks:2d} items {items:3d} | " + " ".join(f"{v / 100:7.2f}" for v in r[4:7]) + " | " + " ".join(f"{v / 100:7.2f}" for v in r[9:12])
+          + (f"  first 3 steps {r[7] / 100:.2f} / {r[12] / 100:.2f}, their wait + barrier {r[8] / 100:.2f} / {r[13] / 100:.2f}" if r[7] else "")
           + f"   per step {(r[4] + r[9]) / 2 / (18 * chunks) / 100:.3f} us, epilogue + next_item = {(r[5] + r[6] + r[10] + r[11]) / 2 / 100:.2f} us = {(r[5] + r[6] + r[10] + r[11]) / (r[4] + r[9] + r[5] + r[6] + r[10] + r[11]) * 100:.1f} % of the item")

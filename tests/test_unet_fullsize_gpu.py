@@ -191,6 +191,24 @@ def test_odd_level_widths_take_the_general_kernel(net):
     eng.close()
 
 
+@pytest.mark.parametrize("hw", [(160, 160), (320, 320), (448, 448), (96, 288), (64, 160), (352, 480), (32, 512), (512, 32), (384, 512)])
+def test_parity_over_slice_shapes(net, hw):
+    """Shapes between the pinned ones: every mix of tilings the dispatch can choose (image tiles where a level is a multiple of 32
+    wide, the flattened tiling up to 48, the general kernel elsewhere; non-square slices; one-tile-wide levels).  Same bar: 1e-3
+    abs on the logits, masks equal outside the tolerance band.  scripts/unet_size_sweep.py runs all 27 shapes
+    (profiles/r05_unet_size_sweep.txt)."""
+    w, tensors = net
+    H, W = hw
+    vol = _volume(1, H, W, H * 1000 + W)
+    xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
+    ref = uo.forward(w, xw, dtype="float64")
+    eng = L.Unet2dEngine(tensors, H, W, max_batch=3, precision="fp16x3")
+    logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
+    eng.close()
+    assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
+    assert not ((mask.astype(bool) != (ref > 0)) & (np.abs(ref) >= 1e-3)).any()
+
+
 def test_forward_is_bitwise_repeatable(net):
     """No atomics and no data-dependent scheduling in the convolution kernels: the same volume through the same engine gives the
     same bits, whatever the timing of the LDS-DMA requests (a request landing after its counted wait would show up here first)."""

@@ -5,6 +5,8 @@
 //   0 contiguous        lane i -> base + 16 i                               (1 KB contiguous per wave-store)
 //   1 c4 epilogue       lane = (pixel = lane >> 2, piece = lane & 3): pixel * stride + piece * 16      (16 x 64 B, `stride` apart)
 //   2 full records      lane = (pixel = lane >> 3, piece = lane & 7): pixel * stride + piece * 16      (8 x 128 B)
+//   3 full records from split lanes: lanes 0-31 the hi halves (pixel = lane >> 2, piece = lane & 3), lanes 32-63 the lo halves of the SAME 8
+//     pixels (what a v_permlane32_swap of the epilogue's hi / lo pieces would give: 8 x 128 B per wave-store, each record from two lane groups)
 // nt = 1: __builtin_nontemporal_store.  Output: bytes per clock and CU (s_memtime), GB/s per CU and of the chip.
 //   hipcc --offload-arch=gfx950 -O3 scripts/probes/store_issue.hip -o scripts/probes/store_issue && scripts/probes/store_issue
 #include <hip/hip_runtime.h>
@@ -26,8 +28,11 @@ __global__ void k(unsigned char *out, long long per_block, int iters, int stride
     } else if (PATTERN == 1) {
         lane_off = (long long)(lane >> 2) * stride + (lane & 3) * 16;
         step = 16LL * stride;
-    } else {
+    } else if (PATTERN == 2) {
         lane_off = (long long)(lane >> 3) * stride + (lane & 7) * 16;
+        step = 8LL * stride;
+    } else {
+        lane_off = (long long)((lane & 31) >> 2) * stride + (lane >> 5) * 64 + (lane & 3) * 16;
         step = 8LL * stride;
     }
     __syncthreads();
@@ -64,8 +69,11 @@ __global__ void kb(unsigned char *out, long long per_block, int items, int per_b
     } else if (PATTERN == 1) {
         lane_off = (long long)(lane >> 2) * stride + (lane & 3) * 16;
         step = 16LL * stride;
-    } else {
+    } else if (PATTERN == 2) {
         lane_off = (long long)(lane >> 3) * stride + (lane & 7) * 16;
+        step = 8LL * stride;
+    } else {
+        lane_off = (long long)((lane & 31) >> 2) * stride + (lane >> 5) * 64 + (lane & 3) * 16;
         step = 8LL * stride;
     }
     long long n = 0;
@@ -188,6 +196,7 @@ int main() {
         for (int stride : {128, 256, 512}) {
             run<1, true>("c4 epilogue (16 x 64 B), nt", buf, per_block, waves, iters, stride, dcyc);
             run<2, true>("full records (8 x 128 B), nt", buf, per_block, waves, iters, stride, dcyc);
+            run<3, true>("full records, split lanes, nt", buf, per_block, waves, iters, stride, dcyc);
         }
     }
     // short bursts like one epilogue: 64 wave-stores per wave (256 KB per CU with 4 waves)
@@ -202,6 +211,8 @@ int main() {
         const double t_f = run_bursts<2>(buf, per_block, 40, 64, 256, spin);
         const double t_h5 = run_bursts<1>(buf, per_block, 40, 64, 512, spin);
         const double t_f5 = run_bursts<2>(buf, per_block, 40, 64, 512, spin);
+        const double t_s = run_bursts<3>(buf, per_block, 40, 64, 256, spin);
+        printf("spin %6d: full records from split lanes stride 256: +%5.2f us\n", spin, (t_s - t_spin) / 40);
         printf("spin %6d clocks (%6.1f us per item): contiguous +%5.2f us | 16 x 64 B (c4 epilogue) stride 256: +%5.2f, 512: +%5.2f | 8 x 128 B (full records) stride 256: +%5.2f, 512: +%5.2f\n",
                spin, t_spin / 40, (t_c - t_spin) / 40, (t_h - t_spin) / 40, (t_h5 - t_spin) / 40, (t_f - t_spin) / 40, (t_f5 - t_spin) / 40);
     }

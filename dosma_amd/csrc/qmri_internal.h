@@ -258,6 +258,10 @@ struct ConvS3Args {
     int d4_tile_major;   // filled by conv_d4_launch: 1 = tile-major item order (the channel blocks of a tile side by side on one XCD)
 };
 bool conv_s3_supported(const ConvS3Args &k);
+// which tiling conv_c4_kernel / deconv_d4_kernel give a level of width W: the flattened zero-framed stack up to W = 48 (unless 32 wide),
+// image tiles of 32 columns otherwise -- with a ragged last column tile when W % 32 != 0 (conv_s3_kernel has no such tile: there the
+// general kernel is the fallback)
+inline bool conv_tiles_flat(int W) { return W % 32 != 0 && W + 2 <= 50; }
 bool conv_c4_supported(const ConvS3Args &k);
 // deconv_d4_kernel (unet_d4.hip): the transposed convolution on one wave per SIMD (4 row-tiles x 4 phases x 32 channels).  w_c4 then
 // holds ITS weight image: per (32-channel block, k-step = chunk * 2 + half) nine taps of [plane][32 rows][2 x 16 B] in shift-group

@@ -663,17 +663,32 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                 } else {
                     const int yy = t_y0 + wave * kRT + i;  // (scalar)
                     if (yy < A.H) {
-                        amax = fmaxf(fmaxf(amax, tmax[0]), tmax[1]);
-                        asm volatile("" : "+v"(amax));  // (pinned: see the flattened branch)
                         unsigned char *rowp = static_cast<unsigned char *>(A.y) +
                                               (((long long)(t_b * A.H + yy) * A.W + t_x0) * A.ldy + A.yoff + cbase) * 4;  // scalar pointer
                         const unsigned pstep = (unsigned)A.ldy * 4u;  // bytes per output pixel
+                        const int xlim = A.W - t_x0;  // (scalar) pixels of this tile inside the image: < 32 only in the last column tile of a level with W % 32 != 0
+                        if (xlim >= 32) {
+                            amax = fmaxf(fmaxf(amax, tmax[0]), tmax[1]);
+                            asm volatile("" : "+v"(amax));  // (pinned: see the flattened branch)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const unsigned off = (unsigned)(t * 16 + opx_t) * pstep + (unsigned)oc_t * 16u;
-                            if (!C4_DBG(32)) {
-                                nt_store16(rowp + (size_t)off, hi[t]);
-                                nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                            for (int t = 0; t < 2; ++t) {
+                                const unsigned off = (unsigned)(t * 16 + opx_t) * pstep + (unsigned)oc_t * 16u;
+                                if (!C4_DBG(32)) {
+                                    nt_store16(rowp + (size_t)off, hi[t]);
+                                    nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                                }
+                            }
+                        } else {  // ragged tile: pixels at or beyond W are neither stored nor tracked
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                const bool in = t * 16 + opx_t < xlim;
+                                amax = fmaxf(amax, in ? tmax[t] : 0.f);
+                                asm volatile("" : "+v"(amax));
+                                const unsigned off = (unsigned)(t * 16 + opx_t) * pstep + (unsigned)oc_t * 16u;
+                                if (in && !C4_DBG(32)) {
+                                    nt_store16(rowp + (size_t)off, hi[t]);
+                                    nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                                }
                             }
                         }
                     }
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
                 split8(m, hi, lo);
                 const int Hp = A.H >> 1, Wp = A.W >> 1;
                 const int yy = (t_y0 >> 1) + wave * (kRT / 2) + pr;
-                if (yy < Hp) {
+                if (yy < Hp && (t_x0 >> 1) + opx_t < Wp) {  // (the column test only bites in the ragged last column tile)
                     const long long pix = (long long)(t_b * Hp + yy) * Wp + (t_x0 >> 1) + opx_t;
                     unsigned char *dst = static_cast<unsigned char *>(A.pool_y) + (pix * A.pool_ld + cbase) * 4 + oc_t * 16;
                     nt_store16(dst, hi);
@@ -818,11 +833,11 @@ bool conv_c4_supported(const ConvS3Args &k) {
     // the images ONE halo can span (+ the chunk's 128) must stay below the descriptor's num_records.  A property of the layer's
     // shape, not of the batch: a slice's bits must not depend on the pass it travels in.
     const unsigned long long img = (unsigned long long)k.H * k.W * (unsigned long long)k.ldx * 4ull;
-    if (k.W % 32 == 0) {
+    if (!conv_tiles_flat(k.W)) {  // image tiles; W % 32 != 0 (and too wide for the flattened tiling): the last column tile is ragged
         if (img >= (unsigned long long)kPadOff) return false;
         return !k.pool_y || (!(k.H & 1) && !(k.W & 1));
     }
-    if (!(k.W + 2 <= 50 && !k.pool_y)) return false;  // flattened zero-framed stack (halo: 512 + 2 (W + 2) + 2 <= 624 pixels)
+    if (k.pool_y) return false;  // flattened zero-framed stack (halo: 512 + 2 (W + 2) + 2 <= 624 pixels)
     const unsigned long long span = (624ull + (unsigned long long)(k.H + 1) * (k.W + 2) - 1) / ((unsigned long long)(k.H + 1) * (k.W + 2)) + 1;
     return span * img < (unsigned long long)kPadOff;
 }
@@ -841,7 +856,7 @@ static hipError_t c4_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
 hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
     ConvS3Args k = k0;
     if (!conv_c4_supported(k) || !k.w_c4) return hipErrorInvalidValue;
-    const bool flat = k.W % 32 != 0;
+    const bool flat = conv_tiles_flat(k.W);
     k.chunks = k.Cin / 32;
     k.steps = k.chunks * 18;
     const int bn = conv_c4_block_channels(k.Cout);
@@ -854,7 +869,7 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         k.tiles_x = k.tiles_y = 0;
     } else {
         k.P = kPitch2D;
-        k.tiles_x = k.W / 32;
+        k.tiles_x = (k.W + 31) / 32;
         const int rows = c4_tile_rows(k.Cout);
         k.tiles_y = (k.H + rows - 1) / rows;
         k.ntiles = k.B * k.tiles_x * k.tiles_y;

@@ -621,16 +621,31 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
                 } else {
                     const int yy = t_y0 + wave * kRT + i;  // input row (scalar)
                     if (yy < A.H) {
-                        amax = fmaxf(fmaxf(amax, tmax[0]), tmax[1]);
-                        asm volatile("" : "+v"(amax));
                         unsigned char *rowp = static_cast<unsigned char *>(A.y) +
                                               (((long long)(2 * (t_b * A.H + yy) + py) * (2 * A.W) + 2 * t_x0 + pxo) * A.ldy + A.yoff + cbase) * 4;  // scalar pointer
+                        const int xlim = A.W - t_x0;  // (scalar) input positions of this tile inside the image: < 32 only in the last column tile of a level with W % 32 != 0
+                        if (xlim >= 32) {
+                            amax = fmaxf(fmaxf(amax, tmax[0]), tmax[1]);
+                            asm volatile("" : "+v"(amax));
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const unsigned off = (unsigned)(2 * (t * 16 + opx_t)) * pstep + (unsigned)oc_t * 16u;
-                            if (!D4_DBG(32)) {
-                                nt_store16(rowp + (size_t)off, hi[t]);
-                                nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                            for (int t = 0; t < 2; ++t) {
+                                const unsigned off = (unsigned)(2 * (t * 16 + opx_t)) * pstep + (unsigned)oc_t * 16u;
+                                if (!D4_DBG(32)) {
+                                    nt_store16(rowp + (size_t)off, hi[t]);
+                                    nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                                }
+                            }
+                        } else {  // ragged tile: positions at or beyond W are neither stored nor tracked
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                const bool in = t * 16 + opx_t < xlim;
+                                amax = fmaxf(amax, in ? tmax[t] : 0.f);
+                                asm volatile("" : "+v"(amax));
+                                const unsigned off = (unsigned)(2 * (t * 16 + opx_t)) * pstep + (unsigned)oc_t * 16u;
+                                if (in && !D4_DBG(32)) {
+                                    nt_store16(rowp + (size_t)off, hi[t]);
+                                    nt_store16(rowp + (size_t)(off + 64u), lo[t]);
+                                }
                             }
                         }
                     }
@@ -692,8 +707,7 @@ bool conv_d4_supported(const ConvS3Args &k) {
     if (!k.deconv || k.one || k.head_w || k.pool_y) return false;
     if (k.Cin % 32 || k.Cout % 32) return false;
     const unsigned long long img = (unsigned long long)k.H * k.W * (unsigned long long)k.ldx * 4ull;  // (see conv_c4_supported)
-    if (k.W % 32 == 0) return img < (unsigned long long)kPadOff;
-    if (k.W + 2 > 50) return false;
+    if (!conv_tiles_flat(k.W)) return img < (unsigned long long)kPadOff;  // image tiles (W % 32 != 0: a ragged last column tile)
     const unsigned long long span = (624ull + (unsigned long long)(k.H + 1) * (k.W + 2) - 1) / ((unsigned long long)(k.H + 1) * (k.W + 2)) + 1;
     return span * img < (unsigned long long)kPadOff;
 }
@@ -712,7 +726,7 @@ static hipError_t d4_launch_t(ConvS3Args &k, int num_cu, hipStream_t stream) {
 hipError_t conv_d4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) {
     ConvS3Args k = k0;
     if (!conv_d4_supported(k) || !k.w_c4) return hipErrorInvalidValue;
-    const bool flat = k.W % 32 != 0;
+    const bool flat = conv_tiles_flat(k.W);
     k.chunks = k.Cin / 32;
     k.steps = 2 * k.chunks;
     k.nb = k.Cout / 32;
@@ -723,7 +737,7 @@ hipError_t conv_d4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         k.tiles_x = k.tiles_y = 0;
     } else {
         k.P = kPitch2D;
-        k.tiles_x = k.W / 32;
+        k.tiles_x = (k.W + 31) / 32;
         k.tiles_y = (k.H + kRows - 1) / kRows;
         k.ntiles = k.B * k.tiles_x * k.tiles_y;
     }

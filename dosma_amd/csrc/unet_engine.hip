@@ -109,7 +109,10 @@ struct ConvLayer {
     std::vector<float> bias_h, shift_h;  // host copies of the ADDITIVE epilogue parameters (rescaled by Unet::set_act_shift)
 
     // fp16 hi / lo images of the host weights W[co][K] (K = (chunk * ntaps + tap) * 32 + c)
-    hipError_t upload_parity(const std::vector<float> &wk, bool for_s3) {
+    // for_s3: the level is one conv_s3_kernel tiles (W % 32 == 0 or W <= 48): its image + conv_c4_kernel's / deconv_d4_kernel's;
+    // otherwise the general kernel's parts -- plus, with `ragged` (W % 32 != 0, wider than the flattened tiling), the c4 / d4 image:
+    // those kernels take such a level on image tiles with a ragged last column, the general kernel stays the fallback (QMRI_C4 = 0)
+    hipError_t upload_parity(const std::vector<float> &wk, bool for_s3, bool ragged = false) {
         const int sh = weight_shift(wk);
         const float sc = std::ldexp(1.f, sh);
         winv = std::ldexp(1.f, -sh);
@@ -122,15 +125,15 @@ struct ConvLayer {
             if (e == hipSuccess) e = h_lo.alloc(n * 2);
             if (e == hipSuccess) e = hipMemcpy(h_hi.p, hi.data(), n * 2, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(h_lo.p, lo.data(), n * 2, hipMemcpyHostToDevice);
-            return e;
+            if (e != hipSuccess || !ragged || ntaps != 9 || Cin % 32) return e;
         }
         // conv_s3_kernel: [nb][step][plane][BN rows][4 positions x 8 halfs], position pos of row n holds the K piece
         // q = pos ^ ((n >> 2) & 3) (the bank-conflict swizzle of the LDS image; the DMA copies the image linearly)
         const int BN = qmri::conv_s3_block_channels(Cout, deconv);
         const int steps = ntaps * (Cin / 32);
         const size_t K = (size_t)steps * 32;
-        std::vector<unsigned short> img((size_t)Cout * K * 2);
-        for (int nb = 0; nb < Cout / BN; ++nb)
+        std::vector<unsigned short> img(for_s3 ? (size_t)Cout * K * 2 : 0);
+        for (int nb = 0; for_s3 && nb < Cout / BN; ++nb)
             for (int st = 0; st < steps; ++st)
                 for (int plane = 0; plane < 2; ++plane)
                     for (int r = 0; r < BN; ++r)
@@ -141,8 +144,10 @@ struct ConvLayer {
                             const unsigned short *from = (plane ? lo.data() : hi.data()) + src;
                             for (int k = 0; k < 8; ++k) img[dst + k] = from[k];
                         }
-        e = w_s3.alloc(img.size() * 2);
-        if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        if (for_s3) {
+            e = w_s3.alloc(img.size() * 2);
+            if (e == hipSuccess) e = hipMemcpy(w_s3.p, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess || ntaps != 9) return e;
         if (deconv) {
             // deconv_d4_kernel: [nb = Cout / 32][k-step = chunk * 2 + half] slots of nine taps in SHIFT-GROUP order -- A: shift (0, 0),
@@ -365,6 +370,7 @@ qmri::ConvKArgs conv_args(const ConvLayer &L, const void *x, long long ldx, int 
 }
 
 bool s3_width_ok(int W) { return W % 32 == 0 || W + 2 <= 50; }  // what conv_s3_kernel tiles (unet_s3.hip: conv_s3_supported)
+bool c4_ragged(int W) { return W % 32 != 0 && W + 2 > 50; }    // what only conv_c4_kernel / deconv_d4_kernel tile: image tiles with a ragged last column
 
 struct Unet {
     int depth = 0, ncls = 0, H = 0, W = 0, maxB = 0, device = 0, split3 = 1, num_cu = 256;
@@ -562,7 +568,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             U->down1[l]->relu = 1;
             pack_conv3x3(k1, Cin, C, *U->down1[l], wk);
             U_TRY(U->down1[l]->upload(wk, b1, nullptr, nullptr));
-            U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+            U_TRY(U->down1[l]->upload_parity(wk, s3_width_ok(U->Wl[l]), c4_ragged(U->Wl[l])));
             if (s3_width_ok(U->Wl[l])) U_TRY(U->down1[l]->upload_s3_bf16(wk));
         }
         fold_bn(C, sc, sh);
@@ -570,7 +576,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         U->down2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->down2[l], wk);
         U_TRY(U->down2[l]->upload(wk, b2, &sc, &sh));
-        U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        U_TRY(U->down2[l]->upload_parity(wk, s3_width_ok(U->Wl[l]), c4_ragged(U->Wl[l])));
         if (s3_width_ok(U->Wl[l])) U_TRY(U->down2[l]->upload_s3_bf16(wk));
     }
     for (int l = d->depth - 2; l >= 0; --l) {
@@ -583,7 +589,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
             L->relu = 0;
             pack_deconv_fused(kd, Cup, C, *L, wk);
             U_TRY(L->upload(wk, bd, nullptr, nullptr));
-            U_TRY(L->upload_parity(wk, U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1])));  // tiles of the INPUT grid (level l + 1)
+            U_TRY(L->upload_parity(wk, U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1]), U->fac[l] == 2 && c4_ragged(U->Wl[l + 1])));  // tiles of the INPUT grid (level l + 1)
             if (U->fac[l] == 2 && s3_width_ok(U->Wl[l + 1])) U_TRY(L->upload_s3_bf16(wk));
             if (U->fac[l] == 3)
                 for (int ph = 0; ph < 9; ++ph) {
@@ -608,14 +614,14 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
         U->up1[l]->relu = 1;
         pack_conv3x3(k1, 2 * C, C, *U->up1[l], wk);
         U_TRY(U->up1[l]->upload(wk, b1, nullptr, nullptr));
-        U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        U_TRY(U->up1[l]->upload_parity(wk, s3_width_ok(U->Wl[l]), c4_ragged(U->Wl[l])));
         if (s3_width_ok(U->Wl[l])) U_TRY(U->up1[l]->upload_s3_bf16(wk));
         fold_bn(C, sc, sh);
         U->up2[l].reset(new ConvLayer);
         U->up2[l]->relu = 1;
         pack_conv3x3(k2, C, C, *U->up2[l], wk);
         U_TRY(U->up2[l]->upload(wk, b2, &sc, &sh));
-        U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->Wl[l])));
+        U_TRY(U->up2[l]->upload_parity(wk, s3_width_ok(U->Wl[l]), c4_ragged(U->Wl[l])));
         if (s3_width_ok(U->Wl[l])) U_TRY(U->up2[l]->upload_s3_bf16(wk));
     }
     // head: Keras (1,1,C0,NC) == [C0][NC]
@@ -678,7 +684,9 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
                           int W, void *y, long long ldy, int yoff, void *pool_y, int pool_ld, bool head, float *logits,
                           unsigned char *mask, hipStream_t st) {
     char buf[96];
-    if (L.w_s3.p) {
+    // (a level conv_s3_kernel does not tile -- W % 32 != 0, wider than the flattened tiling -- has w_c4 only: conv_c4_kernel runs it on image
+    //  tiles with a ragged last column, or, with QMRI_C4 = 0 / a layer that kernel does not take, the general kernel below)
+    if (L.w_s3.p || L.w_c4.p) do {
         qmri::ConvS3Args k;
         std::memset(&k, 0, sizeof(k));
         k.x = x; k.ldx = ldx; k.xoff = xoff;
@@ -694,16 +702,17 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         k.y = y; k.ldy = ldy; k.yoff = yoff;
         k.sat = U->sat_ptr();
         const int bn = qmri::conv_s3_block_channels(L.Cout, 0);
-        const bool flat = W % 32 != 0;
-        const bool fuse_pool = pool_y && !flat && bn >= 64 && !(H & 1);
+        const bool flat = qmri::conv_tiles_flat(W);
+        const bool fuse_pool = pool_y && !flat && bn >= 64 && !(H & 1) && !(W & 1);
         if (fuse_pool) { k.pool_y = pool_y; k.pool_ld = pool_ld; }
-        const bool fuse_head = head && !flat && L.Cout == 32;
+        const bool fuse_head = head && W % 32 == 0 && L.Cout == 32;
         if (fuse_head) {
             k.y = nullptr;  // the last feature map is only consumed by the head: never written to HBM
             k.head_w = U->head_w.as<float>(); k.head_b = U->head_b.as<float>(); k.head_nc = U->ncls;
             k.logits = logits; k.mask = mask;
         }
         const bool c4 = qmri::conv_s3_takes_c4(k, U->num_cu);  // (the launcher's own choice: one wave per SIMD, 128 x 128 register tiles)
+        if (!L.w_s3.p && !c4) break;                           // (ragged level, not on conv_c4_kernel: the general kernel)
         U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
         if (c4)
             snprintf(buf, sizeof(buf), "%s:s3/%s/c4x%d%s;", name, flat ? "flat" : "2d", qmri::conv_c4_block_channels(L.Cout), fuse_pool ? "+pool" : "");
@@ -720,7 +729,7 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
             U->trace += "head:split;";
         }
         return QMRI_OK;
-    }
+    } while (false);
     auto k = conv_args(L, x, ldx, xoff, Bt, H, W, y, ldy, yoff, H, W, 1, 1, 0, 0);
     k.w_hi = L.h_hi.as<__bf16>();
     k.w_lo = L.h_lo.as<__bf16>();
@@ -848,19 +857,19 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             U->trace += nm;
         } else {
             const ConvLayer &L = *U->updec[(size_t)l];
-            if (L.w_s3.p) {
-                qmri::ConvS3Args k;
-                std::memset(&k, 0, sizeof(k));
-                k.x = src; k.ldx = Cup; k.B = Bt; k.H = U->Hl[l + 1]; k.W = U->Wl[l + 1];
-                k.Cin = L.Cin; k.Cout = L.Cout; k.deconv = 1;
-                k.w = L.w_s3.p; k.winv = L.winv;
-                k.w_c4 = L.w_c4.p;  // (a transposed convolution's w_c4 is deconv_d4_kernel's image)
-                k.bias = L.bias.as<float>();
-                k.y = cat; k.ldy = 2 * C; k.yoff = 0;
-                k.sat = U->sat_ptr();
-                const bool d4 = qmri::conv_s3_takes_d4(k);
+            qmri::ConvS3Args k;
+            std::memset(&k, 0, sizeof(k));
+            k.x = src; k.ldx = Cup; k.B = Bt; k.H = U->Hl[l + 1]; k.W = U->Wl[l + 1];
+            k.Cin = L.Cin; k.Cout = L.Cout; k.deconv = 1;
+            k.w = L.w_s3.p; k.winv = L.winv;
+            k.w_c4 = L.w_c4.p;  // (a transposed convolution's w_c4 is deconv_d4_kernel's image)
+            k.bias = L.bias.as<float>();
+            k.y = cat; k.ldy = 2 * C; k.yoff = 0;
+            k.sat = U->sat_ptr();
+            const bool d4 = (L.w_s3.p || L.w_c4.p) && qmri::conv_s3_takes_d4(k);
+            if (L.w_s3.p || d4) {  // (w_c4 only: an input grid only deconv_d4_kernel tiles -- image tiles with a ragged last column)
                 U_TRY(qmri::conv_s3_launch(k, U->num_cu, st));
-                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/%s32;", l, U->Wl[l + 1] % 32 ? "flat" : "2d", d4 ? "d4x" : "bn");
+                snprintf(nm, sizeof(nm), "up%d.deconv:s3/%s/%s32;", l, qmri::conv_tiles_flat(U->Wl[l + 1]) ? "flat" : "2d", d4 ? "d4x" : "bn");
             } else {
                 auto k = conv_args(L, src, Cup, 0, Bt, H / 2, W / 2, cat, 2 * C, 0, H, W, 2, 2, 0, 0);
                 k.w_hi = L.h_hi.as<__bf16>();
@@ -1254,8 +1263,18 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
         U_TRY(hipGetDeviceProperties(&prop, device));
         // precision 1: the kernel the engine would pick for this layer; 2: force the general kernel (tests compare both)
         // 4: conv_c4_kernel or an error; 5: conv_s3_kernel whatever the layer; 6: conv_c4_kernel, whole work items only (tests compare them)
-        const bool s3 = !ab && precision != 2 && s3_width_ok(W);
-        if (!ab) U_TRY(L.upload_parity(wk, s3));
+        const bool rag = !ab && (precision == 1 || precision == 4 || precision == 6) && c4_ragged(W);  // image tiles with a ragged last column: conv_c4_kernel / deconv_d4_kernel only
+        const bool s3 = !ab && precision != 2 && (s3_width_ok(W) || rag);
+        if (!ab) U_TRY(L.upload_parity(wk, s3 && !rag, rag));
+        auto run_general = [&]() -> hipError_t {
+            auto k = conv_args(L, dxb.p, Cin, 0, B, H, W, dyb.p, Cout, 0, Ho, Wo, transposed ? 2 : 1, transposed ? 2 : 1, 0, 0);
+            if (!ab) {
+                k.w_hi = L.h_hi.as<__bf16>();
+                k.w_lo = L.h_lo.as<__bf16>();
+                k.winv = L.winv;
+            }
+            return qmri::conv_igemm_launch(k, !ab, nullptr);
+        };
         if (precision == 3) {
             if (Cin % 64 || !s3_width_ok(W)) return ufail(QMRI_ERR_UNSUPPORTED, "bf16 on conv_s3_kernel needs Cin %% 64 == 0 and a width it tiles");
             U_TRY(L.upload_s3_bf16(wk));
@@ -1285,15 +1304,14 @@ int qmri_conv2d_nhwc_host(const float *x, int32_t B, int32_t H, int32_t W, int32
             k.shift = L.has_affine ? L.shift.as<float>() : nullptr;
             k.relu = relu;
             k.y = dyb.p; k.ldy = Cout;
-            U_TRY(qmri::conv_s3_launch(k, prop.multiProcessorCount, nullptr));
-        } else {
-            auto k = conv_args(L, dxb.p, Cin, 0, B, H, W, dyb.p, Cout, 0, Ho, Wo, transposed ? 2 : 1, transposed ? 2 : 1, 0, 0);
-            if (!ab) {
-                k.w_hi = L.h_hi.as<__bf16>();
-                k.w_lo = L.h_lo.as<__bf16>();
-                k.winv = L.winv;
+            if (rag && !(transposed ? qmri::conv_s3_takes_d4(k) : qmri::conv_s3_takes_c4(k, prop.multiProcessorCount))) {
+                if (precision != 1) return ufail(QMRI_ERR_UNSUPPORTED, "conv_c4_kernel / deconv_d4_kernel do not take this layer");
+                U_TRY(run_general());  // (what the engine does with such a layer)
+            } else {
+                U_TRY(qmri::conv_s3_launch(k, prop.multiProcessorCount, nullptr));
             }
-            U_TRY(qmri::conv_igemm_launch(k, !ab, nullptr));
+        } else {
+            U_TRY(run_general());
         }
         U_TRY(hipDeviceSynchronize());
     }

@@ -905,7 +905,7 @@ bool conv_s3_takes_c4(const ConvS3Args &k, int num_cu) {
     // (64-channel blocks on the FLATTENED levels -- 4 x 2 tiles, 24 MFMAs per k-step -- were 5-10 % slower than conv_s3_kernel<64>
     //  when last measured and appear in no network of the bench: kept for tests, not picked)
     (void)num_cu;
-    return !(conv_c4_block_channels(k.Cout) == 64 && k.W % 32 != 0);
+    return !(conv_c4_block_channels(k.Cout) == 64 && conv_tiles_flat(k.W));
 }
 
 // The transposed convolutions: deconv_d4_kernel (unet_d4.hip) wherever it supports the layer -- by layer shape only, like

@@ -120,6 +120,20 @@ def whiten_volume(x, eps=0.0):
     return (x - np.mean(x)) / (np.std(x) + eps)
 
 
+def _cpu_budget():
+    """Cores this process may actually use: the affinity mask, cut by the cgroup's cpu.max quota where there is one."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def forward(w, x, nf=NF, dtype="float32", return_features=False):
     """Logits (S, H, W, n_classes) of the network for slices ``x`` (S, H, W), torch CPU.
 
@@ -129,6 +143,9 @@ def forward(w, x, nf=NF, dtype="float32", return_features=False):
     import torch
     import torch.nn.functional as F
 
+    # torch's CPU convolutions start one thread per VISIBLE core; under a cgroup CPU quota far below that (the GPU boxes: 16 of
+    # several hundred) the spinning workers can take minutes for a forward that needs seconds -- cap them at the quota
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), _cpu_budget())))
     tdt = torch.float32 if dtype == "float32" else torch.float64
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(tdt)  # noqa: E731
     feats = {}

@@ -47,13 +47,13 @@ def _expect_families(trace, H, W):
     fused0 = H % 8 == 0 and W % 32 == 0
     for lvl in range(6):
         wl = W >> lvl
-        fam = "s3/2d" if wl % 32 == 0 else ("s3/flat" if wl + 2 <= 50 else "igemm")
+        fam = "s3/flat" if wl % 32 and wl + 2 <= 50 else "s3/2d"  # (W % 32 != 0 and wider: image tiles with a ragged last column)
         for name in (([f"down{lvl}.conv2"] if lvl or not fused0 else []) + ([f"down{lvl}.conv1"] if lvl else [])
                      + ([f"up{lvl}.conv1", f"up{lvl}.conv2"] if lvl < 5 and (lvl or not fused0) else [])):
             assert by[name].startswith(fam), (name, by[name], fam)
         if lvl < 5:  # the transposed convolution tiles the INPUT grid (level lvl + 1)
             win = W >> (lvl + 1)
-            famd = "s3/2d" if win % 32 == 0 else ("s3/flat" if win + 2 <= 50 else "igemm")
+            famd = "s3/flat" if win % 32 and win + 2 <= 50 else "s3/2d"
             assert by[f"up{lvl}.deconv"].startswith(famd), (lvl, by[f"up{lvl}.deconv"], famd)
     assert (by["down0"] == "enc0") if fused0 else (by["down0.conv1"] == "c1/split")
     assert by["up0.conv2"] == ("out0+head" if fused0 else by["up0.conv2"]) and by["up0.conv2"].endswith("+head")  # never goes to HBM
@@ -175,9 +175,10 @@ def test_512_logits_at_cfg5_batch(net):
     assert by64["up1.conv1"] == by["up1.conv1"]
 
 
-def test_odd_level_widths_take_the_general_kernel(net):
-    """224 x 224: 224 = 7 x 32 (8 x 32 tiles), 112 and 56 are neither multiples of 32 nor <= 48 (general kernel on the split
-    layout), 28 / 14 / 7 flattened -- all three families in one network, same 1e-3 bar."""
+def test_odd_level_widths_take_ragged_image_tiles(net):
+    """224 x 224: 224 = 7 x 32 (whole image tiles), 112 and 56 are neither multiples of 32 nor <= 48 -- image tiles with a RAGGED
+    last column tile on conv_c4_kernel / deconv_d4_kernel (round 5; the general kernel before that: 20-35 % of the forward on such
+    sizes) --, 28 / 14 / 7 flattened: all three tilings in one network, same 1e-3 bar."""
     w, tensors = net
     vol = _volume(2, 224, 224, 224)
     xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
@@ -187,7 +188,9 @@ def test_odd_level_widths_take_the_general_kernel(net):
     assert np.abs(logits - ref).max() < 1e-3, np.abs(logits - ref).max()
     tr = eng.trace()
     _expect_families(tr, 224, 224)
-    assert any(t.startswith("down1.conv2:igemm") for t in tr) and any(t.startswith("down3.conv1:s3/flat") for t in tr)
+    assert any(t.startswith("down1.conv2:s3/2d/c4x64+pool") for t in tr) and any(t.startswith("down2.conv1:s3/2d/c4x128") for t in tr)
+    assert any(t.startswith("up1.deconv:s3/2d/d4x32") for t in tr) and any(t.startswith("down3.conv1:s3/flat") for t in tr)
+    assert not any("igemm" in t for t in tr)
     eng.close()
 
 

@@ -94,6 +94,13 @@ def test_conv_layer_vs_torch(cin, cout, hw, transposed):
     (64, 128, (12, 12), 800),
     (256, 512, (12, 12), 3),    # four channel blocks = two groups of two (2.4 MB per pair): group by group, tile-major inside (down4.conv1)
     (96, 256, (16, 64), 70),    # one group of two on image tiles, more items than blocks: pairs side by side, parameters of both resident
+    # W % 32 != 0 and wider than the flattened tiling: image tiles with a RAGGED last column tile (pixels at or beyond W read as zero
+    # padding, are neither stored nor tracked) -- the 80 / 56 / 104 / 120-wide levels of 320 / 448 / 416 / 480-pixel slices
+    (64, 128, (20, 80), 2),
+    (32, 64, (26, 56), 3),
+    (128, 256, (17, 104), 1),
+    (96, 64, (24, 120), 2),
+    (64, 128, (33, 51), 2),     # the narrowest such level: one whole and one 19-pixel column tile
 ])
 def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     """conv_c4_kernel (one wave per SIMD, 128 x 128 register tiles; unet_c4.hip) forced on, against the fp64 convolution
@@ -132,6 +139,10 @@ def test_conv_c4_kernel_vs_torch(cin, cout, hw, B):
     (64, 32, (5, 6), 2),        # flattened, less than one tile
     (32, 32, (16, 32), 300),    # more work items than CUs (300 tiles): several items per block, the K stream crosses item boundaries
     (64, 64, (12, 12), 500),    # the same flattened: 56 tiles x 2 channel blocks per ... > 256 items
+    # input grids with W % 32 != 0, wider than the flattened tiling: image tiles with a ragged last column tile
+    (64, 32, (10, 60), 2),
+    (128, 64, (18, 52), 3),
+    (64, 96, (16, 104), 2),
 ])
 def test_deconv_d4_kernel_vs_torch(cin, cout, hw, B):
     """deconv_d4_kernel (the transposed convolution on one wave per SIMD: 4 row-tiles x 4 phases x 32 channels; unet_d4.hip)

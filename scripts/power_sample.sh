@@ -15,3 +15,17 @@ while kill -0 $PID 2>/dev/null; do
   sleep 0.5
 done
 tail -c 300 /tmp/unet_loop.txt | cut -c1-200
+# ---- the headline fit kernel (fp64 vector work): 500 steps of the bench loop ----
+python bench.py --steps 500 --warmup 3 --no-cpu-baseline --no-cfg5 --no-parity --no-unet --recipes A > /tmp/fit_loop.txt 2>&1 &
+PID=$!
+sleep 8
+echo "== during the fit kernel's bench loop (monoexp_lm_kernel, 512 x 512 x 160 x 8 echoes per step)"
+while kill -0 $PID 2>/dev/null; do
+  rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed 's/^GPU\[0\]\s*: //' | paste -sd' ' -
+  sleep 0.5
+done
+python - <<'PY'
+import json
+d = json.loads(open("/tmp/fit_loop.txt").read().strip().splitlines()[-1])
+print("ms_per_step", d["ms_per_step"], "voxel-fits/s", d["value"])
+PY

@@ -50,7 +50,7 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     printf("%s, %d CUs, clock %d MHz\n", p.name, cus, p.clockRate / 1000);
-    for (int data = 0; data < 3; ++data) {
+    for (int data = 0; data < 5; ++data) {
         srand(1);
         for (size_t i = 0; i < h.size(); ++i) {
             float u = 0.f;
@@ -60,6 +60,13 @@ int main() {
                 u = s - 6.f;
             } else if (data == 2) {  // the LOW parts of a hi + lo split: small magnitudes, random mantissas
                 u = ((float)rand() / RAND_MAX - 0.5f) * 9.7e-4f;
+            } else {  // data 3: ONE operand after a ReLU (the even fragment planes = every a[]: half of its elements zero), the
+                      // other N(0,1); data 4: both operands half zeros
+                float s = 0.f;
+                for (int k = 0; k < 12; ++k) s += (float)rand() / RAND_MAX;
+                u = s - 6.f;
+                const bool plane_a = ((i / 8 / 65536) & 1) == 0;
+                if ((plane_a || data == 4) && u < 0.f) u = 0.f;
             }
             h[i] = (_Float16)u;
         }
@@ -84,7 +91,7 @@ int main() {
             // 8 passes of 4 cycles per 32x32x16 f16 MFMA and SIMD: clock = MFMAs per SIMD * 32 / time (if the pipe never idles)
             const double ghz = (double)iters * 8 * 4 * waves * 32 / (best * 1e-3) / 1e9;
             printf("%-34s %d wave(s)/SIMD: best %8.2f ms = %7.1f TFLOP/s (4th run %7.1f); pipe never idle <=> %.2f GHz\n",
-                   data == 0 ? "zeros" : data == 1 ? "N(0,1) operands" : "low parts of a split (|x|<5e-4)", waves, best, tf,
+                   data == 0 ? "zeros" : data == 1 ? "N(0,1) operands" : data == 2 ? "low parts of a split (|x|<5e-4)" : data == 3 ? "A = relu(N(0,1)), B = N(0,1)" : "A, B = relu(N(0,1))", waves, best, tf,
                    tf_last, ghz);
         }
     }

@@ -13,6 +13,13 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--reps", type=int, default=3)
 args = ap.parse_args()
 w = W.random_weights(seed=0)
+# QMRI_PROF_BN_SHIFT0=1: BatchNorm without shift (moving_mean = beta = 0): the normalised tensors are scale * relu(.) -- half
+# zeros -- instead of dense.  Same kernels, same work; what changes is the data the matrix pipes toggle on, i.e. the power the
+# forward draws against the board's cap.  The A/B prices a network that DEFERS the shift into its consumers.
+if os.environ.get("QMRI_PROF_BN_SHIFT0", "0") == "1":
+    for k in w:
+        if k.endswith("_bn_mean") or k.endswith("_bn_beta"):
+            w[k] = np.zeros_like(w[k])
 eng = L.Unet2dEngine(W.to_abi_order(w), args.hw, args.hw, max_batch=args.batch, precision=args.precision.split(",")[0])
 dev = torch.device("cuda", 0)
 x = torch.randn((args.slices, args.hw, args.hw), device=dev)

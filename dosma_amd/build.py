@@ -1,6 +1,7 @@
 """Build the HIP shared library (libqmri_hip.so) in-tree for gfx950.
 
     python -m dosma_amd.build            # hipcc --offload-arch=gfx950 ... -> dosma_amd/libqmri_hip.so
+    python -m dosma_amd.build --clean    # drop experiment variants / probe binaries (what gpurun would push for nothing)
 
 The .so is git-ignored but travels with the gpurun snapshot.  hipcc cross-compiles without a GPU.
 """
@@ -101,8 +102,43 @@ def _build_locked(bdir: str, verbose: bool, force: bool = False) -> str:
     return SO
 
 
+def clean(verbose: bool = True) -> list:
+    """Remove everything a timing experiment leaves behind and `gpurun` would otherwise push to the GPU box: the variant
+    object trees (dosma_amd/build/<name>/), the variant libraries (libqmri_hip_<name>.so) and the probe binaries under
+    scripts/probes/ (their .hip sources stay).  The product library and its objects are kept."""
+    removed = []
+    bdir = os.path.join(HERE, "build")
+    if os.path.isdir(bdir):
+        for name in sorted(os.listdir(bdir)):
+            d = os.path.join(bdir, name)
+            if os.path.isdir(d):
+                shutil.rmtree(d)
+                removed.append(d)
+    for name in sorted(os.listdir(HERE)):
+        if name.startswith("libqmri_hip_") and name.endswith(".so"):
+            os.remove(os.path.join(HERE, name))
+            removed.append(os.path.join(HERE, name))
+    probes = os.path.join(ROOT, "scripts", "probes")
+    if os.path.isdir(probes):
+        for name in sorted(os.listdir(probes)):
+            f = os.path.join(probes, name)
+            if os.path.isfile(f) and not name.endswith(".hip"):
+                os.remove(f)
+                removed.append(f)
+    for name in sorted(os.listdir(os.path.join(ROOT, "scripts"))):
+        if name.endswith(".so"):
+            os.remove(os.path.join(ROOT, "scripts", name))
+            removed.append(os.path.join(ROOT, "scripts", name))
+    if verbose:
+        for r in removed:
+            print("removed", os.path.relpath(r, ROOT))
+    return removed
+
+
 if __name__ == "__main__":
-    if "--experiments" in sys.argv:
+    if "--clean" in sys.argv:
+        clean()
+    elif "--experiments" in sys.argv:
         print(build_variant("exp", ["-DQMRI_S3_EXPERIMENTS"]))
     elif "--variant" in sys.argv:  # python -m dosma_amd.build --variant NAME -DFLAG ...
         i = sys.argv.index("--variant")

@@ -51,6 +51,14 @@ __device__ __forceinline__ double div_p10(double x, double p10, double ip10) {
 // (they issue on the scalar unit) into s[100:101] and ONE vector instruction.  A 64-bit constant cannot be an immediate of
 // v_fma_f64 / v_mul_f64; left to itself hipcc hoists such constants out of the caller's loop and keeps them there -- in
 // scalar registers that the loop then spills, or in vector registers with a v_mov_b64 + v_fmac_f64 pair per step.
+//
+// s[100:101] is the top pair of the 102 addressable SGPRs of gfx9: hipcc reserves s96..s101 for itself ("clobber list
+// contains reserved registers", silenced below) and never allocates them, and naming the pair as a clobber makes it
+// count the kernel's SGPR block up to s101 (.amdhsa_next_free_sgpr 102), so the registers exist in every wave that
+// runs the asm.  tests/test_abi.py::test_reserved_sgpr_pair_is_only_touched_by_the_constant_macros checks both facts
+// on the generated code of every kernel that contains the pair.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <unsigned long long K>
 __device__ __forceinline__ double fma_sk_bits(double a, double b) {
     double d;
@@ -72,6 +80,7 @@ __device__ __forceinline__ double fma_ks_bits(double a, double c) {
         : "=v"(d) : "v"(a), "v"(c), "n"((unsigned)(K & 0xffffffffull)), "n"((unsigned)(K >> 32)) : "s100", "s101");
     return d;
 }
+#pragma clang diagnostic pop
 #define QMRI_K64(k) __builtin_bit_cast(unsigned long long, static_cast<double>(k))
 #define QMRI_FMA_SK(a, b, k) ::qmri::fma_sk_bits<QMRI_K64(k)>((a), (b))   /* a * b + k */
 #define QMRI_MUL_SK(a, k) ::qmri::mul_sk_bits<QMRI_K64(k)>((a))          /* a * k */

@@ -259,3 +259,52 @@ def test_deconv_d4_kernel_has_no_scratch_traffic(tmp_path):
 def test_conv_c4_lds_layouts_are_bank_conflict_free():
     """scripts/lds_bank_check.py: the halo and weight images of conv_c4_kernel against the guide's ds_read_b128 lane groups."""
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "lds_bank_check.py")])
+
+
+def test_reserved_sgpr_pair_is_only_touched_by_the_constant_macros(tmp_path):
+    """csrc/fp64_fast.h (fma_sk_bits / mul_sk_bits / fma_ks_bits) makes 64-bit constants in s[100:101] from inline asm -- the top
+    pair of gfx9's 102 addressable SGPRs, which hipcc reserves and never allocates.  Two facts make that safe and neither is
+    visible in the source: (1) the clobber makes hipcc size the kernel's SGPR block up to s101 (.amdhsa_next_free_sgpr >= 102),
+    so the pair exists in every wave that runs the asm; (2) nothing else in such a kernel reads or writes the pair.  Guard
+    both on the generated gfx950 code of EVERY kernel of the translation units that include the header (all 44
+    monoexp_lm_kernel instantiations + the library's self-test kernel), and that a build stays quiet (the 6 000
+    -Winline-asm warnings of round 5 are silenced by a scoped pragma, not by a global flag)."""
+    import re
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "dosma_amd", "csrc")
+    users = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and "fp64_fast.h" in open(os.path.join(csrc, f)).read()]
+    assert "monoexp_lm.hip" in users
+    procs = []
+    for f in users:
+        out = tmp_path / (f[:-4] + ".s")
+        procs.append((f, out, subprocess.Popen([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-S",
+                                                "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(csrc, f), "-o", str(out)],
+                                               stderr=subprocess.PIPE)))
+    pair = re.compile(r"\bs100\b|\bs101\b|s\[100:101\]|s\[(9[0-9]|100):10[1-9]\]")
+    ok_mov = re.compile(r"^s_mov_b32 s10[01], (0x[0-9a-f]+|-?\d+)$")
+    ok_valu = re.compile(r"^v_(fma|mul)_f64 v\[\d+:\d+\], (v\[\d+:\d+\]|s\[100:101\])(, (v\[\d+:\d+\]|s\[100:101\])){1,2}$")
+    kernels_with_pair = 0
+    for f, out, p in procs:
+        err = p.communicate()[1].decode()
+        assert p.returncode == 0, err[-2000:]
+        assert err.count("warning:") < 20, (f, err.count("warning:"), err[:1500])
+        text = out.read_text()
+        for m in re.finditer(r"^(\w+):\s*; @\1\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            hits = [ln.strip() for ln in body.splitlines() if pair.search(ln.split(";")[0])]
+            if not hits:
+                continue
+            kernels_with_pair += 1
+            for ln in hits:
+                ln = ln.split(";")[0].strip()
+                assert ok_mov.match(ln) or (ok_valu.match(ln) and ln.count("s[100:101]") == 1), (name, ln)
+            movs = sum(ln.startswith("s_mov_b32") for ln in hits)
+            assert movs == 2 * (len(hits) - movs), (name, movs, len(hits))  # two s_mov_b32 per vector instruction, nothing shared
+            desc = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(.*?)\.end_amdhsa_kernel", text, re.S)
+            assert desc is not None, name  # (only kernels, no device functions, may hold the pair)
+            nfree = int(re.search(r"\.amdhsa_next_free_sgpr (\d+)", desc.group(1)).group(1))
+            assert nfree >= 102, (name, nfree)
+    assert kernels_with_pair >= 40, kernels_with_pair

@@ -213,6 +213,12 @@ def _scaling_ladder(fitter, y_T, cores):
         if w >= 4 and ladder[w] < 1.15 * ladder[w // 2] and ladder[w // 2] < 1.15 * ladder[w // 4]:
             break   # flat twice in a row: more workers only add processes
         w *= 2
+    if cores not in ladder:  # the reference's own default for "all cores" (num_workers = os.cpu_count()), for the record
+        with mp.Pool(cores) as pool:
+            pool.map(fitter, y_T[: cores * 4], chunksize=4)
+            t = time.perf_counter()
+            pool.map(fitter, y_T[:m], chunksize=max(50, min(1000, m // (4 * cores))))
+            ladder[cores] = m / (time.perf_counter() - t)
     return ladder
 
 
@@ -247,11 +253,6 @@ def cpu_baseline(y_dev, cores_cap=None):
         t = time.perf_counter()
         pool.map(fitter, y_T[:m1], chunksize=1000)
         dt_one = time.perf_counter() - t
-    with mp.Pool(cores) as pool:
-        pool.map(fitter, y_T[: cores * 4], chunksize=4)  # start the workers
-        t = time.perf_counter()
-        pool.map(fitter, y_T, chunksize=1000)
-        dt = time.perf_counter() - t
     # how many cores does the host really give this process?  cgroup quota if there is one, else where the worker
     # ladder of the same call pattern flattens (throughput with all workers / throughput with one)
     ladder = _scaling_ladder(fitter, y_T, cores)
@@ -261,6 +262,14 @@ def cpu_baseline(y_dev, cores_cap=None):
         eff, eff_how = min(float(cores), quota), "cgroup cpu.max quota"
     else:
         eff, eff_how = min(float(cores), max(1.0, scale)), "all-worker / one-worker throughput of the reference's call pattern"
+    # the baseline is the host's BEST -- the ladder's best rung (Pool(256) on a 16-core quota cost it 25 %),
+    # timed on the whole sample
+    best_w = max(ladder, key=ladder.get)
+    with mp.Pool(best_w) as pool:
+        pool.map(fitter, y_T[: best_w * 4], chunksize=4)  # start the workers
+        t = time.perf_counter()
+        pool.map(fitter, y_T, chunksize=1000)
+        dt = time.perf_counter() - t
     # single-thread C restatement of MINPACK on a slice, for scale
     m = min(n, 200_000)
     t = time.perf_counter()
@@ -272,15 +281,18 @@ def cpu_baseline(y_dev, cores_cap=None):
     fo.curve_fit_c(TE, ys, P0_A, threads=cores)
     dt_call = time.perf_counter() - t
     return {
-        "value": n / dt, "unit": "voxel-fits/s", "cores": cores, "kind": "port",
+        "value": n / dt, "unit": "voxel-fits/s", "cores": best_w, "kind": "port",
         "sample": (f"first {n} voxels of the bench volume (70% tissue / 30% zero background): one "
-                   f"scipy.optimize.curve_fit per voxel, rows of y.T through multiprocessing.Pool({cores}).map("
-                   f"partial(fitter), chunksize=1000) (the reference's call pattern, fitting.py:860-868), scipy "
+                   f"scipy.optimize.curve_fit per voxel, rows of y.T through multiprocessing.Pool({best_w}).map("
+                   f"partial(fitter), chunksize=1000) (the reference's call pattern, fitting.py:860-868) with the number "
+                   f"of workers that was fastest on this host (worker_ladder_voxel_fits_per_s; {cores} cores visible), scipy "
                    f"{scipy.__version__}, {dt:.1f} s wall, pool start-up excluded"),
+        "workers": best_w,
+        "visible_cores": cores,
         "effective_cores": eff,
         "effective_cores_how": eff_how,
         "per_core": n / dt / eff,
-        "per_visible_core": n / dt / cores,
+        "per_worker": n / dt / best_w,
         "worker_ladder_voxel_fits_per_s": {str(k): v for k, v in ladder.items()},
         "cgroup_cpu_quota_cores": quota,
         "num_workers_0_serial": m1 / dt_serial,
@@ -372,6 +384,111 @@ def _mfma_ceiling():
     return None
 
 
+UNET_REF_SCLK_GHZ = 1.82  # the clock round 5's 1.38 kW forward held (profiles/r05_power.txt): the reference point of value_at_ref_clock
+
+
+class GpuSampler:
+    """Shader clock and board power of one GPU, sampled in a side thread while a timed loop runs (the MFMA
+    legs run against the 1.4 kW cap and boxes differ by +-3 % in the clock they hold; without the clock in the line two rounds'
+    numbers cannot be compared).  Reads the amdgpu hwmon files of the device's PCI function (freq1_input = sclk in Hz,
+    power1_average / power1_input in microwatts: what rocm-smi prints) every few ms; where the box exposes no hwmon node it
+    falls back to polling `rocm-smi --showpower --showclocks` (the logic of scripts/power_sample.sh; ~3 samples per second).
+    Never raises: a box without either yields {"samples": 0}."""
+
+    def __init__(self, torch, dev_index, period_s=0.004):
+        import glob
+        import threading
+
+        self.period, self.rows, self._stop, self._thr, self.dev_index = period_s, [], threading.Event(), None, dev_index
+        self.how, self.f_clk, self.f_pow = None, None, None
+        cands = []
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cands = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+        except Exception:
+            pass
+        if not cands:  # no PCI address from torch: the dev_index-th amdgpu hwmon node in PCI order
+            nodes = []
+            for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                try:
+                    if open(os.path.join(h, "name")).read().strip() == "amdgpu":
+                        nodes.append((os.path.realpath(os.path.join(h, "..", "..")), h))
+                except OSError:
+                    pass
+            nodes.sort()
+            if dev_index < len(nodes):
+                cands = [nodes[dev_index][1]]
+        for h in cands:
+            clk = os.path.join(h, "freq1_input")
+            pw = next((os.path.join(h, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+            if os.path.exists(clk) and self._read(clk) is not None:
+                self.how, self.f_clk, self.f_pow = f"hwmon ({os.path.basename(clk)}, {os.path.basename(pw) if pw else 'no power file'})", clk, pw
+                break
+        if self.how is None:
+            import shutil
+
+            self.smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+            if os.path.exists(self.smi):
+                self.how = "rocm-smi --showpower --showclocks (polled)"
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _poll_smi(self):
+        import re
+        import subprocess
+
+        try:
+            txt = subprocess.run([self.smi, "-d", str(self.dev_index), "--showpower", "--showclocks"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True, timeout=5).stdout
+        except Exception:
+            return None, None
+        c = re.search(r"sclk clock level:\s*\w+:\s*\((\d+)Mhz\)", txt)
+        w = re.search(r"Power \(W\):\s*([\d.]+)", txt)
+        return (float(c.group(1)) * 1e6 if c else None), (float(w.group(1)) * 1e6 if w else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            if self.f_clk:
+                c, w = self._read(self.f_clk), (self._read(self.f_pow) if self.f_pow else None)
+                self._stop.wait(self.period)
+            else:
+                c, w = self._poll_smi()
+            self.rows.append((time.perf_counter(), c, w))
+
+    def __enter__(self):
+        import threading
+
+        if self.how is not None:
+            self.rows, self._stop = [], threading.Event()
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=10)
+            self._thr = None
+        return False
+
+    def summary(self, t0=None, t1=None):
+        """Means over the samples taken in [t0, t1] (time.perf_counter values; the whole run when omitted)."""
+        rows = [r for r in self.rows if (t0 is None or r[0] >= t0) and (t1 is None or r[0] <= t1)]
+        clk = [r[1] for r in rows if r[1]]
+        pw = [r[2] for r in rows if r[2]]
+        return {"samples": len(rows), "how": self.how,
+                "sclk_ghz_mean": (sum(clk) / len(clk) / 1e9) if clk else None,
+                "sclk_ghz_min": (min(clk) / 1e9) if clk else None, "sclk_ghz_max": (max(clk) / 1e9) if clk else None,
+                "power_w_mean": (sum(pw) / len(pw) / 1e6) if pw else None, "power_w_max": (max(pw) / 1e6) if pw else None}
+
+
 def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_device):
     """UNet2D slices/s (BASELINE.json configs[3]: IWOAIOAIUnet2DNormalized, 384x384x160, MFMA conv).
 
@@ -391,25 +508,49 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
     mask = torch.empty((UNET_SLICES, UNET_HW, UNET_HW, 4), device=device, dtype=torch.uint8)
     stream = torch.cuda.current_stream(device)
     steps = max(2, args.steps // 4)
-    res = {}
+    res, clocks = {}, {}
+    sampler = GpuSampler(torch, local_rank)
+    rank_zero_extras = (not dist.is_initialized()) or dist.get_rank() == 0
     for prec in ("bf16", UNET_PARITY_MODE):
         eng.set_precision(prec)
         for _ in range(max(1, args.warmup // 2)):
             eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
                                stream=stream.cuda_stream)
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
-                               stream=stream.cuda_stream)
-        barrier()
-        el = time.perf_counter() - t0
+        with sampler:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
+                                   stream=stream.cuda_stream)
+            barrier()
+            t1 = time.perf_counter()
+        el = t1 - t0
         if dist.is_initialized():
             t = torch.tensor([el], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t[0].item()
         res[prec] = UNET_SLICES * world * steps / el
+        clocks[prec] = sampler.summary(t0, t1)
+    # the timed loop is a fraction of a second; under a power cap the clock keeps settling for longer than that.  The same
+    # forward for ~2 s more (outside `value`), sampled: the steady-state rate and the clock / power it is held at -- the pair that
+    # makes two boxes' (two rounds') numbers comparable
+    eng.set_precision(UNET_PARITY_MODE)
+    sustained = None
+    if rank_zero_extras:
+        n_sus = max(steps, int(2.0 / max(1e-3, UNET_SLICES * world / res[UNET_PARITY_MODE])))
+        torch.cuda.synchronize(device)
+        with sampler:
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                eng.forward_device(x.data_ptr(), UNET_SLICES, logits.data_ptr(), mask.data_ptr(), whiten=True,
+                                   stream=stream.cuda_stream)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+        sustained = {"steps": n_sus, "seconds": t1 - t0, "slices_per_s_this_rank": UNET_SLICES * n_sus / (t1 - t0),
+                     **sampler.summary(t0 + 0.25 * (t1 - t0), t1)}
     eng.close()
+    ck = clocks[UNET_PARITY_MODE]
+    ref_clock = (res[UNET_PARITY_MODE] * UNET_REF_SCLK_GHZ / ck["sclk_ghz_mean"]) if ck.get("sclk_ghz_mean") else None
     tf = res[UNET_PARITY_MODE] / world * UNET_GFLOP_PER_SLICE / 1e3
     tf16 = res["bf16"] / world * UNET_GFLOP_PER_SLICE / 1e3
     return {
@@ -420,9 +561,16 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
                      "(tests/test_unet_gpu.py); the plain-bf16 mode (1 MFMA per product, logits within ~0.25) is "
                      "`slices_per_s_bf16`",
         "slices_per_s_bf16": res["bf16"],
+        "value_at_ref_clock": ref_clock,
+        "value_at_ref_clock_note": f"value x {UNET_REF_SCLK_GHZ} GHz / sclk_ghz_mean of the timed loop (rank 0's GPU): the MFMA kernels run "
+                                   "against the 1.4 kW board cap and their time follows the clock the box holds; compare rounds on this "
+                                   "field (README: comparing rounds), not on `value`",
+        "sustained": sustained,
         "data": "synthetic (random He weights of the reference architecture, random-normal input)",
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_BF16_PEAK_TFLOPS, "gflop_per_slice": UNET_GFLOP_PER_SLICE,
+                     "sclk_ghz_mean": ck.get("sclk_ghz_mean"), "power_w_mean": ck.get("power_w_mean"),
+                     "clock_samples": ck, "bf16_mode_clock_samples": clocks.get("bf16"),
                      "mfma_issued_frac": 3 * tf / MFMA_BF16_PEAK_TFLOPS,
                      "mfma_ceiling_measured": _mfma_ceiling(),
                      "frac_of_measured_ceiling": (3 * tf / _mfma_ceiling()["tflops"]) if _mfma_ceiling() else None,
@@ -539,7 +687,13 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
     wts = qd.broadcast_weights(wts, src=0)
     t_bcast = time.perf_counter() - t0
     checksum = float(sum(float(np.asarray(v, dtype=np.float64).sum()) for v in wts.values()))
-    sums = qd.allgather_scalars([checksum])[:, 0]
+    import zlib
+
+    crc = 0
+    for k in sorted(wts):  # every byte of every tensor, in name order (a CRC-32 is exact in a float64)
+        crc = zlib.crc32(np.ascontiguousarray(wts[k]).tobytes(), crc)
+    gathered = qd.allgather_scalars([checksum, float(crc)])
+    sums, crcs = gathered[:, 0], gathered[:, 1]
     wbytes = int(sum(np.asarray(v).size for v in wts.values()) * 4)
     eng = L.Unet2dEngine(W.to_abi_order(wts), H, W_, max_batch=args.cfg5_unet_batch, precision=UNET_PARITY_MODE,
                          device=local_rank)
@@ -570,7 +724,7 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
         t_seg = time.perf_counter() - t
         fitted = float((popt[:, 1] > 0).sum().item())
         return {"fit_s": t_fit, "seg_s": t_seg, "voxels": float(n), "slices": float(S), "t2_nonzero": fitted,
-                "mask_voxels": float(mask[..., 0].sum().item())}
+                "mask_voxels": float(mask[..., 0].sum().item()), "owner_rank": float(rank), "volume_index": float(v)}
 
     # The same batch with the two pipes overlapped: the fit is fp64 VALU at three waves per SIMD, the network
     # MFMA at one -- independent calls in the reference (qdess.py:64-103 segmentation, cube_quant.py:139-185 fit).  Volume v + 1's fit
@@ -601,7 +755,8 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
             torch.cuda.synchronize(device) if i + 1 == len(mine) else None
             res[v] = {"fit_s": float("nan"), "seg_s": float("nan"), "voxels": float(n), "slices": float(S),
                       "t2_nonzero": float((bufs[i & 1][0][:, 1] > 0).sum().item()),
-                      "mask_voxels": float(mask[..., 0].sum().item()), "wall_s": time.perf_counter() - t}
+                      "mask_voxels": float(mask[..., 0].sum().item()), "owner_rank": float(rank), "volume_index": float(v),
+                      "wall_s": time.perf_counter() - t}
         return res
 
     # warm-up (kernel module load, workspace allocation) on this rank's own volume, then the batch
@@ -614,25 +769,29 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
     same = bool(np.array_equal(osumm["t2_nonzero"], summ["t2_nonzero"]) and np.array_equal(osumm["mask_voxels"], summ["mask_voxels"]))
     out["two_streams"] = {
         "what": "the same batch with volume v + 1's fit launched on a second HIP stream before volume v's segmentation "
-                "(fp64 VALU kernel beside the MFMA kernels); cfg5's wall_s / rates are this schedule's iff `adopted`",
+                "(fp64 VALU kernel beside the MFMA kernels); reported beside cfg5's headline, which is always back to back",
         "wall_s": ovl["wall_s"], "volumes_per_s": ovl["volumes_per_s"], "speedup_vs_back_to_back": out["wall_s"] / ovl["wall_s"],
         "same_results": same, "back_to_back_wall_s": out["wall_s"], "back_to_back_volumes_per_s": out["volumes_per_s"],
     }
-    # adopted as cfg5's schedule only when it is worth it (>= 5 %: the MFMA clock is power-limited, a second kernel costs clock)
-    adopt = same and ovl["wall_s"] * 1.05 <= out["wall_s"]
-    out["two_streams"]["adopted"] = bool(adopt)
-    if adopt:
-        out["wall_s"], out["volumes_per_s"], out["rank_busy_s"] = ovl["wall_s"], ovl["volumes_per_s"], ovl["rank_busy_s"]
+    # the headline (wall_s / volumes_per_s / the rates below) is ALWAYS the back-to-back schedule -- one fixed schedule
+    # from run to run and box to box; the two-stream schedule is reported beside it under fixed keys and never replaces it
+    out["schedule"] = "back_to_back"
     out.update({
         "config": f"{n_vol} volumes of 512x512x160 x 8 echoes: mono-exponential fit (MonoExponentialFit defaults) + UNet2D "
-                  f"segmentation at 512x512 ({UNET_PARITY_MODE}) per volume, {per_gpu} volumes per GPU (BASELINE configs[4])",
+                  f"segmentation at 512x512 ({UNET_PARITY_MODE}) per volume, {per_gpu} volumes per GPU, fit and segmentation back to back "
+                  f"on one stream (BASELINE configs[4])",
         "voxel_fits_per_s": float(np.nansum(summ["voxels"])) / out["wall_s"],
         "slices_per_s": float(np.nansum(summ["slices"])) / out["wall_s"],
         "fit_s_per_volume": float(np.nanmean(summ["fit_s"])), "seg_s_per_volume": float(np.nanmean(summ["seg_s"])),
         "unet_gflop_per_slice_512": UNET_GFLOP_PER_SLICE * (512 / 384) ** 2,
         "host_feed_note": "inputs generated on-device from per-volume seeds, resident in HBM before the clock starts",
+        # which rank ran which volume (gathered after the clock): every index 0 .. n_vol - 1 owned by exactly one rank
+        "volume_owner": [None if np.isnan(r) else int(r) for r in summ["owner_rank"]],
+        "every_volume_once": bool(np.array_equal(summ["volume_index"], np.arange(n_vol)) and sum(out["per_rank"]) == n_vol
+                                  and all(int(r) == v % world for v, r in enumerate(summ["owner_rank"]))),
         "weights_broadcast": {"bytes": wbytes, "seconds": t_bcast, "make_seconds_rank0": t_make,
-                              "identical_on_all_ranks": bool(np.all(sums == sums[0])),
+                              "identical_on_all_ranks": bool(np.all(sums == sums[0]) and np.all(crcs == crcs[0])),
+                              "crc32_per_rank": [int(c) for c in crcs],
                               "collective": "one torch.distributed.broadcast of the packed fp32 weights (RCCL) from rank 0"},
     })
     eng.close()
@@ -805,25 +964,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    fit_sampler = GpuSampler(torch, local_rank)
+
     def timed_fit(a):
         for _ in range(args.warmup):
             L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         barrier()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(args.steps):
-            L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
-        ev1.record(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        with fit_sampler:
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(args.steps):
+                L.check(lib.qmri_monoexp_fit_device(ctypes.byref(a), None))
+            ev1.record(stream)
+            barrier()
+            t1 = time.perf_counter()
+        elapsed = t1 - t0
+        clocks = fit_sampler.summary(t0, t1)
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
         if use_dist:
             t = torch.tensor([elapsed, kernel_ms], device=red_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kernel_ms = t[0].item(), t[1].item()
-        return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode())
+        return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=lib.qmri_monoexp_kernel_name(ctypes.byref(a)).decode(), clocks=clocks)
 
     results = {}
     # float64 outputs (what the drop-in API returns: 56 B/voxel) first, the headline (fp32 outputs) last so that the
@@ -920,6 +1084,8 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_voxel": BYTES_PER_VOXEL,
+                "sclk_ghz_mean": ra["clocks"].get("sclk_ghz_mean"), "power_w_mean": ra["clocks"].get("power_w_mean"),
+                "clock_samples": ra["clocks"],
                 "kernel_ms": ra["kernel_ms"],
                 "note": "the kernel is fp64-VALU bound, not HBM bound: MINPACK's early-stopped trajectory is ~20 LM rounds "
                         "per voxel (53 charged model evaluations) of ~1000 fp64 VALU instructions each (lmpar, model "

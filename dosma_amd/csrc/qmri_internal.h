@@ -255,7 +255,9 @@ struct ConvS3Args {
     const void *w_c4;
     int c4_mode;
     int c4_split;        // filled by conv_c4_launch: split the items of the last, partial round by channels (QMRI_C4_SPLIT=0 turns it off)
-    int d4_tile_major;   // filled by conv_d4_launch: 1 = tile-major item order (the channel blocks of a tile side by side on one XCD)
+    int tile_group;      // filled by the launchers: channel blocks per tile-major GROUP (the blocks of a tile side by side on one XCD, the
+                         // tile's halo fetched once per group).  conv_c4_launch: 0 = channel-major, 1 = groups of TWO blocks (the only
+                         // group size conv_c4_kernel knows); conv_d4_launch: 0 / 1 = channel-major, G = 2..4 blocks per group
 };
 bool conv_s3_supported(const ConvS3Args &k);
 // which tiling conv_c4_kernel / deconv_d4_kernel give a level of width W: the flattened zero-framed stack up to W = 48 (unless 32 wide),

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 
 #include "qmri.h"
@@ -328,7 +329,8 @@ hipError_t region_stats_launch(const void *values, int f64, const void *labels, 
     if (blocks > (long long)num_cu * 8) blocks = (long long)num_cu * 8;
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     if (blocks < 1) blocks = 1;
-    hipError_t e = hipMemsetAsync(S, 0, sizeof(StatsState), stream);
+    // (the per-block partial sums `part` are written by every block before select_pick_kernel reads [0, nblocks): not cleared)
+    hipError_t e = hipMemsetAsync(S, 0, offsetof(StatsState, part), stream);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     // digit width: 11 bits when the LDS histograms of all (region, statistic) pairs fit next to the other kernels' share

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     const int P = FLAT ? A.P : kPitch2D;
     const int hpix = FLAT ? kMTile + 2 * P + 2 : kHalo2D;
     const int ntiles = A.ntiles;
-    const bool tile_major = A.d4_tile_major != 0;  // (groups of TWO channel blocks: see decode_work)
+    const bool tile_major = A.tile_group != 0;  // (groups of TWO channel blocks: see decode_work)
     const int per_group = 2 * ntiles;
     const int wsteps = A.steps;  // chunks * 18 steps per work item
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
         // channel-major (an XCD's blocks share one channel block's weights; every block re-reads the tiles) or -- where the launcher
-        // found two channel blocks' weights small enough to stay in an XCD's L2 beside the activations (A.d4_tile_major) -- TILE-MAJOR in
+        // found two channel blocks' weights small enough to stay in an XCD's L2 beside the activations (A.tile_group) -- TILE-MAJOR in
         // groups of two channel blocks: the pair runs side by side on one XCD and the tile's halo comes from HBM once per pair
         int t;
         if (tile_major) {  // w = (group * ntiles + tile) * 2 + j, channel block = 2 group + j (two-block layers: one group)
@@ -883,7 +883,7 @@ hipError_t conv_c4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
         return e ? std::atoi(e) : -1;
     }();
     const size_t pair_bytes = (size_t)k.Cin * 9 * 2 * bn * 4;  // weights of two channel blocks
-    k.d4_tile_major = (k.nb % 2 == 0 && (order < 0 ? pair_bytes <= (size_t)2400 << 10 : order != 0)) ? 1 : 0;
+    k.tile_group = (k.nb % 2 == 0 && (order < 0 ? pair_bytes <= (size_t)2400 << 10 : order != 0)) ? 1 : 0;
     static const int split = [] {
         const char *e = std::getenv("QMRI_C4_SPLIT");
         return e ? std::atoi(e) : 1;

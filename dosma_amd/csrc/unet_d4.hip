@@ -173,16 +173,16 @@ __global__ __launch_bounds__(kThreads, 1) void deconv_d4_kernel(const ConvS3Args
 
     int t_nb = 0, t_b = 0, t_y0 = 0, t_x0 = 0, t_f0 = 0;
     // work item -> (channel block, tile).  Channel-major (an XCD's blocks share one channel block's weights, tiles re-read per block)
-    // where the layer's weights are bigger than an L2 can keep; TILE-MAJOR (A.d4_tile_major, set by the launcher: a layer's whole
-    // weight image <= 1.5 MB) where they fit: the channel blocks of a tile run side by side on one XCD, the tile's halo comes from HBM
+    // where the layer's weights are bigger than an L2 can keep; TILE-MAJOR (A.tile_group, set by the launcher: a layer's whole
+    // weight group <= 2.4 MB, the launcher's budget) where they fit: the channel blocks of a tile run side by side on one XCD, the tile's halo comes from HBM
     // once and from that L2 for the other blocks -- the transposed convolutions of the 96 x 96 and 48 x 48 levels moved 2.1-4.2 x
     // their input through the fabric (profiles/r04g_unet_reads_by_layer.txt) at 3.6-4.1 TB/s of total traffic.
     const int nbk = A.nb;
-    // G = A.d4_tile_major: channel blocks per GROUP (0 / 1: channel-major).  Items run group by group; inside a group tile by tile, the
+    // G = A.tile_group: channel blocks per GROUP (0 / 1: channel-major).  Items run group by group; inside a group tile by tile, the
     // group's G channel blocks of a tile side by side: w = (group * ntiles + tile) * G + j, channel block = group * G + j.  The launcher
     // picks the largest G (<= kPrmBlocks) whose G blocks of weights stay in an XCD's L2 (<= 2.4 MB): the layer's input is then read
     // nb / G times instead of nb times (up3: 2 instead of 8, up4: 8 instead of 16; up2 / up1: once).
-    const int G = A.d4_tile_major;
+    const int G = A.tile_group;
     const bool tile_major = G > 1;
     const int per_group = ntiles * (G > 1 ? G : 1);
     auto decode_work = [&](int w, int &nb, int &b, int &y0, int &x0, int &f0) {
@@ -753,7 +753,7 @@ hipError_t conv_d4_launch(const ConvS3Args &k0, int num_cu, hipStream_t stream) 
     int G = 0;
     for (int g = 2; g <= kPrmBlocks && g <= k.nb; ++g)
         if (k.nb % g == 0 && (order > 0 || g * block_bytes <= (size_t)2400 << 10)) G = g;
-    k.d4_tile_major = order == 0 ? 0 : G;
+    k.tile_group = order == 0 ? 0 : G;
     static const int dbg = [] {
         const char *e = std::getenv("QMRI_D4_DBG");
         return e ? std::atoi(e) : 0;

@@ -618,10 +618,10 @@ class CurveFitter(_Fitter):
         # function's own arguments, the rest go to scipy
         fit_kw = dict(self.kwargs)
         named = {k: fit_kw.pop(k) for k in ("maxfev", "ftol", "eps") if k in fit_kw}
-        model, solver = _kernel_route(self._func, fit_kw, np.asarray(x).shape[-1] if not isinstance(x, MedicalVolume) else 0,
+        model, solver = _kernel_route(self._func, fit_kw, np.asarray(x).reshape(-1).shape[0] if not isinstance(x, MedicalVolume) else 0,
                                       "CurveFitter")
         if model is None:
-            return self._fit_scipy_loop(x, y, mask, p0, copy_headers, named, fit_kw, solver)
+            return self._fit_scipy_loop(x, y, mask, p0, copy_headers, named, fit_kw, solver, _decimals, _tc_only)
         if "maxfev" in named:
             solver["maxfev"] = int(named["maxfev"])
         if "ftol" in named:
@@ -684,11 +684,31 @@ class CurveFitter(_Fitter):
             self._last_tc = out["tc"]
         return popt_mv, r2_mv
 
-    def _fit_scipy_loop(self, x, y, mask, p0, copy_headers, named, scipy_kwargs, why):
+    def _loglin_p0(self, x, y, mask):
+        """tc0 = "polyfit" exactly as the reference builds it (:701-718): degree-1 PolyFitter on log(y + eps * (y == 0)),
+        p0 = (exp(intercept), slope) per voxel (flattened, all voxels)."""
+        vols = [sv.astype(np.float32) if np.issubdtype(sv.dtype, np.integer) else sv for sv in y]
+        vols = [np.log(sv + 1e-10 * (sv == 0)) for sv in vols]
+        params, _ = PolyFitter(1, r2_threshold=0, num_workers=None, nan_to_num=0.0).fit(x, vols, mask=mask, copy_headers=False)
+        pv = params.volume.reshape(-1, 2)
+        return [np.ascontiguousarray(np.exp(pv[:, 1]), dtype=np.float64), np.ascontiguousarray(pv[:, 0], dtype=np.float64)]
+
+    def _tc_and_r2(self, y0, popt, r2, copy_headers, decimals):
+        """What MonoExponentialFit.fit returns (:739-744) from the (popt, r2) pair of a route without the fused epilogue."""
+        tc = popt.volume[..., 1]
+        if decimals is not None:
+            tc = np.around(tc, decimals)
+        headers = deepcopy(y0.headers()) if (copy_headers and y0.headers() is not None) else None
+        return (y0._partial_clone(volume=np.ascontiguousarray(tc), headers=headers),
+                y0._partial_clone(volume=r2.volume, headers=True if headers is not None else None))
+
+    def _fit_scipy_loop(self, x, y, mask, p0, copy_headers, named, scipy_kwargs, why, decimals=None, tc_only=False):
         """A request the kernels do not implement, as the reference runs it (:157-235, :422-435): gather the masked columns,
-        one scipy.optimize.curve_fit per voxel, post-process, scatter back."""
+        one scipy.optimize.curve_fit per voxel, post-process, scatter back.  MonoExponentialFit's private requests (the
+        log-linear initial guess, the rounded tc map as the only result) are honoured here as on the kernel routes."""
         if isinstance(x, MedicalVolume):
             raise RuntimeError("`x` must be on the CPU")
+        mask_in = mask
         x, y, svs, mask_flat = self._prepare(x, y, mask)
         N = svs.shape[1]
         if p0 is np._NoValue:
@@ -696,6 +716,8 @@ class CurveFitter(_Fitter):
         given_p0 = p0 is not None
         p0 = self._format_p0(p0, ref=y[0], flatten=True)
         p0 = _format_p0(p0, _func_param_names(self._func), N)
+        if getattr(self, "_loglin_init", False):
+            p0, given_p0 = self._loglin_p0(x, y, mask_in), True
         sel = None if mask_flat is None else np.flatnonzero(mask_flat)
         cols = svs if sel is None else svs[:, sel]
         p0 = [v[sel] if (sel is not None and isinstance(v, np.ndarray)) else v for v in p0]
@@ -714,27 +736,15 @@ class CurveFitter(_Fitter):
             r2 = np.full(N, fill, dtype=np.float64)
             popt[sel] = popt_s
             r2[sel] = r2_s
-        return self._wrap(y[0], popt, r2, copy_headers)
+        popt, r2 = self._wrap(y[0], popt, r2, copy_headers)
+        return self._tc_and_r2(y[0], popt, r2, copy_headers, decimals) if tc_only else (popt, r2)
 
     def _fit_many_samples(self, x, y, rows, mask, mask_flat, p0, copy_headers, solver, decimals, tc_only):
         if getattr(self, "_loglin_init", False):
-            # tc0 = "polyfit" exactly as the reference builds it (:701-718): degree-1 PolyFitter on log(y + eps * (y == 0)),
-            # p0 = (exp(intercept), slope) per voxel
-            vols = [sv.astype(np.float32) if np.issubdtype(sv.dtype, np.integer) else sv for sv in y]
-            vols = [np.log(sv + 1e-10 * (sv == 0)) for sv in vols]
-            params, _ = PolyFitter(1, r2_threshold=0, num_workers=None, nan_to_num=0.0).fit(x, vols, mask=mask, copy_headers=False)
-            pv = params.volume.reshape(-1, 2)
-            p0 = [np.ascontiguousarray(np.exp(pv[:, 1]), dtype=np.float64), np.ascontiguousarray(pv[:, 0], dtype=np.float64)]
+            p0 = self._loglin_p0(x, y, mask)
         svs = np.stack([np.asarray(r) for r in rows], axis=0)
         popt, r2 = self._fit_general("monoexponential", x, y, svs, mask_flat, p0, copy_headers, solver)
-        if not tc_only:
-            return popt, r2
-        tc = popt.volume[..., 1]
-        if decimals is not None:
-            tc = np.around(tc, decimals)
-        headers = deepcopy(y[0].headers()) if (copy_headers and y[0].headers() is not None) else None
-        return (y[0]._partial_clone(volume=np.ascontiguousarray(tc), headers=headers),
-                y[0]._partial_clone(volume=r2.volume, headers=True if headers is not None else None))
+        return self._tc_and_r2(y[0], popt, r2, copy_headers, decimals) if tc_only else (popt, r2)
 
     def _fit_general(self, model, x, y, svs, mask_flat, p0, copy_headers, solver):
         """Models on the general lmdif kernel (bi-exponential): gather the masked columns like the

@@ -6,7 +6,7 @@ golden vectors are produced here from seeded inputs by calling the reference's p
 ``dosma.curve_fit``, ``dosma.CurveFitter``, ``dosma.MonoExponentialFit`` (dosma/core/fitting.py).
 A fixture is data only: inputs + the reference's outputs (+ scipy's ier/nfev for the same call).
 
-    python oracle/make_golden.py [g1 ... g9]   # writes tests/golden/g*.npz  (~30 s, 8 workers)
+    python oracle/make_golden.py [g0 ... g9]   # writes tests/golden/g*.npz  (~30 s, 8 workers)
 """
 import os
 import sys
@@ -445,9 +445,31 @@ def g9():
     save("g9_generate_mask.npz", **out)
 
 
+def g0():
+    """More samples per voxel than any kernel keeps (65 > 64): MonoExponentialFit with a numeric tc0 and with
+    tc0="polyfit", masked, and the plain CurveFitter (fitting.py:607-749, 238-458) -- the route ADVICE r5 found broken."""
+    rng = np.random.default_rng(10)
+    shape = (6, 5, 4)
+    E = 65
+    x = np.linspace(2.0, 90.0, E)
+    s0 = rng.uniform(300, 1500, shape)
+    t2 = rng.uniform(15, 80, shape)
+    y = s0 * np.exp(-x.reshape(-1, 1, 1, 1) / t2) + 6.0 * rng.standard_normal((E,) + shape)
+    y[:, 0, 0, 0] = 0          # skip rule
+    y[3, 1, 1, 1] = 0          # a zero sample: eps enters the log of the polyfit guess
+    mask = rng.random(shape) > 0.3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tc_def, r2_def = dosma.MonoExponentialFit(decimal_precision=6).fit(x, vols(y))
+        tc_pf, r2_pf = dosma.MonoExponentialFit(tc0="polyfit", decimal_precision=3).fit(x, vols(y), mask)
+        popt, r2 = dosma.CurveFitter(dosma.monoexponential, p0=(1.0, -1 / 30.0)).fit(x, vols(y), mask=mask)
+    save("g0_many_samples.npz", x=x, y=y, mask=mask, tc_default=tc_def.A, r2_default=r2_def.A,
+         tc_polyfit_masked=tc_pf.A, r2_polyfit_masked=r2_pf.A, popt_masked=popt.A, r2_masked=r2.A)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for name in which:
         t = time.time()
         print(name, "...")

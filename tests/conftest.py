@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# QMRI_TEST_DEVICE=k: the GPU tests that name a device (the golden fit test, the whole-network parity test) run on HIP
+# ordinal k -- on a multi-GPU box this exercises the per-device contexts of the library on a device other than 0
+TEST_DEVICE = int(os.environ.get("QMRI_TEST_DEVICE", "0"))
 
 
 def pytest_configure(config):
@@ -36,6 +39,11 @@ def pytest_collection_modifyitems(config, items):
     skip = pytest.mark.skip(reason="no HIP device visible (the gpu tests run on the MI355X box: pytest -m gpu)")
     for it in gpu_items:
         it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def test_device():
+    return TEST_DEVICE
 
 
 @pytest.fixture(scope="session")

@@ -286,3 +286,47 @@ def test_bench_one_rank_through_rccl():
     c5 = out["cfg5"]
     assert c5["per_rank"] == [1] and c5["weights_broadcast"]["identical_on_all_ranks"] and c5["weights_broadcast"]["bytes"] > 1.3e8
     assert out["parity"]["nfev_equal_frac"] > 0.999 and out["unet2d"]["value"] > 100
+
+
+@pytest.mark.gpu
+def test_bench_cfg5_rehearsal_at_world_size_8():
+    """BASELINE configs[4] at its REAL world size on the one GPU a test box has: `python bench.py --gpus 8`
+    with NO launcher -- bench.py starts its own eight ranks under torch.distributed.run -- QMRI_BENCH_BACKEND=gloo so the ranks
+    share the device, 8 volumes of 512 x 512 x 160 x 8 per rank = the 64-volume batch, fit + 512 x 512 segmentation each; the UNet
+    engines take 32 slices per pass so that eight of them (and 8 x 9 resident volumes) fit one GPU's 288 GB.  What it rehearses
+    for the first 8-GPU lease: the 8-process rendezvous on a free port, the weight broadcast to seven receivers (CRC-32 of every
+    byte equal on all ranks), volume v -> rank v mod 8 with every index owned exactly once, eight page-locked result pools and
+    eight host-fed uploads at once, the max-over-ranks timing, ONE JSON line from rank 0, exit code 0."""
+    import json
+    import time
+
+    env = dict(os.environ, QMRI_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--cfg5-volumes-per-gpu", "8", "--no-cpu-baseline", "--unet-batch", "32", "--cfg5-unet-batch", "32"]
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    took = time.time() - t0
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["process_group"]["world_size"] == 8 and out["process_group"]["backend"] == "gloo"
+    n = 512 * 512 * 160
+    assert abs(out["value"] - 8 * n * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    c5 = out["cfg5"]
+    assert c5["volumes"] == 64 and c5["per_rank"] == [8] * 8 and c5["schedule"] == "back_to_back"
+    assert c5["volume_owner"] == [v % 8 for v in range(64)] and c5["every_volume_once"]
+    wb = c5["weights_broadcast"]
+    assert wb["identical_on_all_ranks"] and len(wb["crc32_per_rank"]) == 8 and len(set(wb["crc32_per_rank"])) == 1
+    assert wb["bytes"] > 1.3e8
+    assert c5["two_streams"]["same_results"]
+    assert len(c5["rank_busy_s"]) == 8 and c5["wall_s"] >= max(c5["rank_busy_s"]) > 0
+    hf = c5["host_feed"]
+    assert len(hf["seconds_per_rank"]) == 8 and len(hf["int16"]["seconds_per_rank"]) == 8
+    assert len(hf["copy_bandwidth"]["h2d"]["gb_per_s_per_rank"]) == 8
+    assert out["parity"]["nfev_equal_frac"] > 0.999 and out["parity"]["max_rel"] < 1e-4
+    assert out["unet2d"]["value"] > 100 and "cpu_baseline" not in out
+    assert took < 240, f"{took:.0f} s"

@@ -534,3 +534,25 @@ def test_solver_kwargs_are_forwarded():
     pg, _ = CurveFitter(monoexponential, p0=p0, r2_threshold=None).fit(x, small)
     ok = ~np.isnan(pg.volume[..., 0]) & ~np.isnan(ps.volume[..., 0])
     assert ok.sum() > 8 and np.abs(ps.volume[ok] / pg.volume[ok] - 1).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_monoexponential_fit_polyfit_guess_with_65_samples_vs_reference_golden(golden):
+    """ADVICE r5, the tc0="polyfit" half: 65 samples per voxel leave the kernels' range, so the solve is the per-voxel scipy
+    loop -- started from the log-linear guess (PolyFitter on the GPU, fitting.py:701-718), masked, returning the rounded tc
+    map.  Before the fix the guess was dropped (p0 = ones, every voxel failed: all zeros).  Golden g0 = the real reference."""
+    import warnings
+
+    g = golden("g0_many_samples.npz")
+    x, y, mask = g["x"], g["y"], g["mask"]
+    vols = [MedicalVolume(v, np.eye(4)) for v in y]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tc, r2 = MonoExponentialFit(tc0="polyfit", decimal_precision=3).fit(x, vols, mask)
+    ref_tc, ref_r2 = g["tc_polyfit_masked"], g["r2_polyfit_masked"]
+    assert tc.shape == ref_tc.shape
+    assert ((tc.volume > 0) == (ref_tc > 0)).all() and (ref_tc > 0).sum() > 70
+    assert np.abs(tc.volume - ref_tc).max() <= 1.001e-3          # one unit of the rounding at most ...
+    assert (tc.volume != ref_tc).mean() < 0.02                    # ... and almost nowhere
+    np.testing.assert_allclose(r2.volume, ref_r2, rtol=1e-6, atol=1e-9)
+    assert (tc.volume[~mask] == 0).all()

@@ -310,3 +310,25 @@ def test_bench_bookkeeping_helpers():
     assert q is None or q > 0
     tr = bench._unet_traffic()
     assert tr["algorithmic_bytes"] == total and ("traffic_source" not in tr or "stale" in tr["traffic_source"])
+
+
+def test_monoexponential_fit_with_more_samples_than_the_kernels_keep(golden):
+    """with 65 samples per voxel (> 64, the general lmdif kernel's limit) MonoExponentialFit.fit goes through the
+    per-voxel scipy loop and must still return what the reference returns (fitting.py:720-744): the ROUNDED tc map (not the
+    unrounded (a, tc) pairs) and r2.  Golden g0 = the real reference on the same inputs; same scipy call on the same numbers,
+    so equal.  The plain CurveFitter with a mask through the same route as well.  No GPU involved."""
+    import warnings
+
+    g = golden("g0_many_samples.npz")
+    x, y, mask = g["x"], g["y"], g["mask"]
+    vols = [MedicalVolume(v, np.eye(4)) for v in y]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tc, r2 = MonoExponentialFit(decimal_precision=6).fit(x, vols)
+        popt, r2m = CurveFitter(monoexponential, p0=(1.0, -1 / 30.0)).fit(x, vols, mask=mask)
+    assert tc.shape == y.shape[1:] and r2.shape == y.shape[1:]
+    np.testing.assert_allclose(tc.volume, g["tc_default"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(r2.volume, g["r2_default"], rtol=1e-9, atol=1e-12)
+    assert tc.volume[0, 0, 0] == 0 and (tc.volume > 0).sum() > 100
+    np.testing.assert_allclose(popt.volume, g["popt_masked"], rtol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(r2m.volume, g["r2_masked"], rtol=1e-9, atol=1e-12, equal_nan=True)

@@ -201,12 +201,13 @@ def weights_in_abi_order(w, depth=6):
     return t
 
 
-def test_full_network_logits_vs_restatement(small_net):
+def test_full_network_logits_vs_restatement(small_net, test_device):
     w, tensors = small_net
     rng = np.random.default_rng(0)
     S, H, W = 5, 64, 96
     vol = (rng.standard_normal((S, H, W)) * 120 + 300).astype(np.float32)
-    eng = L.Unet2dEngine(tensors, H, W, max_batch=2, precision="fp16x3")  # 5 slices -> batches 2,2,1
+    # 5 slices -> batches 2,2,1; QMRI_TEST_DEVICE picks the HIP ordinal (a non-zero one on a multi-GPU box)
+    eng = L.Unet2dEngine(tensors, H, W, max_batch=2, precision="fp16x3", device=test_device)
     logits, mask = eng.forward_host(vol, whiten=True, eps=0.0)
     xw = uo.whiten_volume(vol.astype(np.float64)).astype(np.float32)
     ref = uo.forward(w, xw, dtype="float64")

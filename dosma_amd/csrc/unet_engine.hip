@@ -375,6 +375,13 @@ bool c4_ragged(int W) { return W % 32 != 0 && W + 2 > 50; }    // what only conv
 struct Unet {
     int depth = 0, ncls = 0, H = 0, W = 0, maxB = 0, device = 0, split3 = 1, num_cu = 256;
     std::string trace;  // kernel family of every layer of the last forward batch (tests assert the dispatch)
+    // QMRI_UNET_CHECKSUMS=1 (debugging aid, round 6's race hunt): after every layer of every pass an exact checksum (sum of the
+    // output buffer's 32-bit words in 64 bits) is queued; qmri_unet2d_trace then appends "#<pass>.<layer>=<hex>;" entries of the
+    // last forward, so two runs can be compared layer by layer (scripts/unet_layer_bisect.py)
+    DevBuf csum_dev;
+    std::vector<std::string> csum_names;
+    std::string csum_log;
+    int csum_pass = 0;
     std::vector<int> Hl, Wl;   // image size at level l
     std::vector<int> fac;      // pooling / unpooling factor between level l and l + 1: 2, or 3 where the height is odd
     std::vector<std::unique_ptr<ConvLayer>> updec3;  // [level * 9 + phase]: stride-3 transposed convolution, one tap per phase
@@ -666,7 +673,7 @@ int qmri_unet2d_create(const qmri_unet2d_desc *d, void **handle) {
 
 int qmri_unet2d_trace(void *handle, char *buf, int32_t size) {
     if (!handle || !buf || size <= 0) return ufail(QMRI_ERR_ARG, "handle / buf is NULL");
-    const std::string &t = static_cast<Unet *>(handle)->trace;
+    const std::string t = static_cast<Unet *>(handle)->trace + static_cast<Unet *>(handle)->csum_log;
     std::snprintf(buf, (size_t)size, "%s", t.c_str());
     return (int)t.size();
 }
@@ -674,6 +681,57 @@ int qmri_unet2d_trace(void *handle, char *buf, int32_t size) {
 int qmri_unet2d_set_precision(void *handle, int32_t precision) {
     if (!handle) return ufail(QMRI_ERR_ARG, "handle is NULL");
     static_cast<Unet *>(handle)->split3 = precision != 0;
+    return QMRI_OK;
+}
+
+// ---- debugging aid: exact per-layer checksums (QMRI_UNET_CHECKSUMS=1) ----
+static bool csum_wanted() {
+    static const bool on = std::getenv("QMRI_UNET_CHECKSUMS") && std::atoi(std::getenv("QMRI_UNET_CHECKSUMS")) != 0;
+    return on;
+}
+constexpr int kCsumSlots = 4096;
+__global__ __launch_bounds__(256) void csum_kernel(const unsigned int *__restrict__ x, long long nwords, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x) acc += x[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);  // (integer addition: exact in any order)
+}
+static int csum(Unet *U, const char *name, const void *p, long long bytes, hipStream_t st) {
+    if (!csum_wanted() || !p || bytes <= 0) return QMRI_OK;
+    if (!U->csum_dev.p) {
+        U_TRY(U->csum_dev.alloc((size_t)kCsumSlots * 8));
+        U_TRY(hipMemsetAsync(U->csum_dev.p, 0, (size_t)kCsumSlots * 8, st));
+    }
+    if ((int)U->csum_names.size() >= kCsumSlots) return QMRI_OK;
+    const long long nwords = bytes / 4;
+    long long blocks = (nwords + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(csum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const unsigned int *>(p), nwords,
+                       U->csum_dev.as<unsigned long long>() + U->csum_names.size());
+    U_TRY(hipGetLastError());
+    U->csum_names.push_back("#" + std::to_string(U->csum_pass) + "." + name);
+    return QMRI_OK;
+}
+// (start of a forward: forget the previous one's; end: read the sums back)
+static int csum_begin(Unet *U, hipStream_t st) {
+    if (!csum_wanted()) return QMRI_OK;
+    U->csum_names.clear();
+    U->csum_log.clear();
+    U->csum_pass = 0;
+    if (U->csum_dev.p) U_TRY(hipMemsetAsync(U->csum_dev.p, 0, (size_t)kCsumSlots * 8, st));
+    return QMRI_OK;
+}
+static int csum_end(Unet *U, hipStream_t st) {
+    if (!csum_wanted() || U->csum_names.empty()) return QMRI_OK;
+    std::vector<unsigned long long> h(U->csum_names.size());
+    U_TRY(hipMemcpyAsync(h.data(), U->csum_dev.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    U_TRY(hipStreamSynchronize(st));
+    char b[40];
+    for (size_t i = 0; i < h.size(); ++i) {
+        std::snprintf(b, sizeof(b), "=%016llx;", h[i]);
+        U->csum_log += U->csum_names[i] + b;
+    }
     return QMRI_OK;
 }
 
@@ -728,6 +786,11 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
                                           logits, mask, st));
             U->trace += "head:split;";
         }
+        {
+            int rc_ = csum(U, name, k.y ? y : (const void *)logits, k.y ? (long long)Bt * H * W * ldy * 4 : (long long)Bt * H * W * U->ncls * 4, st);
+            if (rc_ == QMRI_OK && pool_y) rc_ = csum(U, (std::string(name) + ".pool").c_str(), pool_y, (long long)Bt * (H / 2) * (W / 2) * pool_ld * 4, st);
+            if (rc_ != QMRI_OK) return rc_;
+        }
         return QMRI_OK;
     } while (false);
     auto k = conv_args(L, x, ldx, xoff, Bt, H, W, y, ldy, yoff, H, W, 1, 1, 0, 0);
@@ -743,6 +806,11 @@ static int conv3x3_parity(Unet *U, const char *name, const ConvLayer &L, const v
         U_TRY(qmri::head_split_launch(y, (long long)Bt * H * W, L.Cout, U->head_w.as<float>(), U->head_b.as<float>(), U->ncls, logits,
                                       mask, st));
         U->trace += "head:split;";
+    }
+    {
+        int rc_ = csum(U, name, y, (long long)Bt * H * W * ldy * 4, st);
+        if (rc_ == QMRI_OK && pool_y) rc_ = csum(U, (std::string(name) + ".pool").c_str(), pool_y, (long long)Bt * (H / 2) * (W / 2) * pool_ld * 4, st);
+        if (rc_ != QMRI_OK) return rc_;
     }
     return QMRI_OK;
 }
@@ -813,6 +881,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             k.sat = U->sat_ptr();
             U_TRY(qmri::enc0_launch(k, U->num_cu, st));
             U->trace += "down0:enc0;";
+            if (csum(U, "down0", k.y, (long long)Bt * H * W * 2 * C * 4, st) != QMRI_OK || csum(U, "down0.pool", k.pool_y, (long long)Bt * (H / 2) * (W / 2) * C * 4, st) != QMRI_OK) return QMRI_ERR_HIP;
             continue;
         }
         if (l == 0) {
@@ -880,6 +949,8 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
                 snprintf(nm, sizeof(nm), "up%d.deconv:igemm;", l);
             }
             U->trace += nm;
+            snprintf(nm, sizeof(nm), "up%d.deconv", l);
+            if (csum(U, nm, cat, (long long)Bt * H * W * 2 * C * 4, st) != QMRI_OK) return QMRI_ERR_HIP;
         }
         void *t1 = U->tmp[l]->p;
         snprintf(nm, sizeof(nm), "up%d.conv1", l);
@@ -896,6 +967,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             k.sat = U->sat_ptr();
             U_TRY(qmri::mid0_launch(k, U->num_cu, st));
             U->trace += "up0.conv1:mid0;";
+            if (csum(U, "up0.conv1", t1, (long long)Bt * H * W * C * 4, st) != QMRI_OK) return QMRI_ERR_HIP;
         } else {
             rc = conv3x3_parity(U, nm, *U->up1[l], cat, 2 * C, 0, Bt, H, W, t1, C, 0, nullptr, 0, false, nullptr, nullptr, st);
         }
@@ -915,6 +987,7 @@ static int forward_batch_parity(Unet *U, int Bt, float *logits, unsigned char *m
             k.logits = logits; k.mask = mask;
             U_TRY(qmri::out0_launch(k, U->num_cu, st));
             U->trace += "up0.conv2:out0+head;";
+            if (csum(U, "up0.conv2", logits, (long long)Bt * H * W * U->ncls * 4, st) != QMRI_OK) return QMRI_ERR_HIP;
             src = out;
             continue;
         }
@@ -1132,6 +1205,7 @@ int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_de
     auto body = [&]() -> int {
         for (int s0 = 0; s0 < S; s0 += U->maxB) {
             const int Bt = (S - s0) < U->maxB ? (S - s0) : U->maxB;
+            U->csum_pass = s0 / U->maxB;
             U_TRY(load_batch(U, xd + (long long)s0 * slice, (long long)Bt * slice, st));
             float *lg = out_on_device ? (logits ? logits + (long long)s0 * slice * U->ncls : nullptr) : lg_dev;
             unsigned char *mk = out_on_device ? (mask ? mask + (long long)s0 * slice * U->ncls : nullptr) : mk_dev;
@@ -1149,8 +1223,10 @@ int qmri_unet2d_forward(void *handle, const float *x, int32_t S, int32_t x_on_de
         }
         return QMRI_OK;
     };
+    if (csum_begin(U, st) != QMRI_OK) return QMRI_ERR_HIP;
     const int rc = run_in_range(U, xd, n, whiten != 0, st, body);
     if (rc != QMRI_OK) return rc;
+    if (csum_end(U, st) != QMRI_OK) return QMRI_ERR_HIP;
     if (!out_on_device || !x_on_device) U_TRY(hipStreamSynchronize(st));
     return QMRI_OK;
 }

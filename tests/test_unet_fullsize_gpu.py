@@ -175,6 +175,37 @@ def test_512_logits_at_cfg5_batch(net):
     assert by64["up1.conv1"] == by["up1.conv1"]
 
 
+def test_512_forward_repeats_bit_for_bit(net):
+    """Round 6's race: with conv_c4_kernel's barrier every THIRD k-step 2-4 % of the forwards of the 512 x 512 network came out with one
+    wave's rows of one work item wrong (logits off by up to 0.5), on every box tried -- found through 27 differing mask voxels in
+    bench.py's cfg5 leg, not by this suite, whose repeat tests ran a handful of forwards.  Here: 80 device-resident forwards of a
+    160-slice volume in passes of 32 (the configuration with the highest measured rate: 3.7 % per forward, i.e. a 95 % chance to see
+    the old cadence fail), every one equal to the first bit for bit.  (Every second step -- the default since -- measured 0 of 4 600.)"""
+    import torch
+
+    w, tensors = net
+    dev = torch.device("cuda", 0)
+    S, H = 160, 512
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn((S, H, H), device=dev, generator=gen) * 150 + 300
+    logits = torch.empty((S, H, H, 4), device=dev)
+    mask = torch.empty((S, H, H, 4), device=dev, dtype=torch.uint8)
+    st = torch.cuda.current_stream(dev)
+    eng = L.Unet2dEngine(tensors, H, H, max_batch=32, precision="fp16x3", device=0)
+    first = None
+    for rep in range(80):
+        eng.forward_device(x.data_ptr(), S, logits.data_ptr(), mask.data_ptr(), whiten=True, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        per_slice = logits.view(torch.int32).flatten(1).to(torch.int64).sum(1)  # (exact: integer sums of the logits' bit patterns)
+        if first is None:
+            first = per_slice.clone()
+            assert torch.isfinite(logits).all()
+        else:
+            bad = (per_slice != first).nonzero().flatten().tolist()
+            assert not bad, f"forward {rep}: slices {bad[:12]} differ from the first forward"
+    eng.close()
+
+
 def test_odd_level_widths_take_ragged_image_tiles(net):
     """224 x 224: 224 = 7 x 32 (whole image tiles), 112 and 56 are neither multiples of 32 nor <= 48 -- image tiles with a RAGGED
     last column tile on conv_c4_kernel / deconv_d4_kernel (round 5; the general kernel before that: 20-35 % of the forward on such

@@ -33,7 +33,6 @@
 #include <cstdlib>
 
 #include "qmri_internal.h"
-#include "unet_c4_common.h"
 
 namespace qmri {
 
@@ -863,221 +862,6 @@ __global__ __launch_bounds__(kO_Threads, 2) void mid0_kernel(const Mid0Args A) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// mid0q_kernel (round 6) -- the same layer as mid0_kernel with FOUR HALF-CHUNK halo buffers instead of two whole-chunk ones.
-// Why: mid0_kernel streams 9.2 GB per 160-slice forward at 4.05 TB/s where a device copy moves 4.9; its inputs being resident
-// in the infinity cache does not make it faster (scripts/mall_probe.sh), i.e. it is bound by the BYTES IN FLIGHT, not by the
-// memory: the LDS beside the 73 KB of resident weights holds two 43 KB buffers, one being multiplied, one in flight -- and the
-// one in flight is also the epilogue's staging area, so chunk 1 of a tile is requested only one MFMA loop (~1 us) before it is
-// needed.  Here the same 88 KB are four buffers of one 16-channel half-chunk each (conv_c4_kernel's 64-byte pixel image):
-// one multiplied, THREE in flight (1.5 x the bytes, each with three half-chunk loops to land), and the epilogue stages the
-// hi and the lo plane one after the other through 2 KB wave windows in the buffer that was multiplied last -- windows that are
-// exactly the destinations of the wave's OWN first two requests of the next half-chunk, so no barrier separates staging from
-// the requests that overwrite it.  Same arithmetic in the same order as mid0_kernel (chunk 0 k-steps 0, 1, chunk 1 k-steps 0, 1,
-// tap-major inside): the outputs are bit-identical (scripts/unet_bits.py).
-constexpr int kQ_NJ = (kO_Halo + 15) / 16;    // 22 DMA instructions of 16 pixels x 64 B per half-chunk
-constexpr int kQ_HBuf = kQ_NJ * 1024;         // 22528 B
-constexpr int kQ_Req = 3;                     // requests per wave and half-chunk: pieces 2 w, 2 w + 1 (its window) and 16 + w % 6
-constexpr int kQ_Stores = 4;                  // global stores per wave and tile
-static_assert(2 * kWBytes + 4 * kQ_HBuf <= 160 * 1024, "mid0q_kernel fills the CU's LDS exactly");
-static_assert(2 * kO_Waves + 6 == kQ_NJ, "window pieces + shared pieces");
-
-__global__ __launch_bounds__(kO_Threads, 2) void mid0q_kernel(const Mid0Args A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *wlds = smem;                                  // [chunk][tap] x 4096 B
-    unsigned char *halo = wlds + kM_Chunks * kWBytes;            // buffer h = half-chunk h (chunk h >> 1, k-step h & 1) of a tile
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kgrp = lane >> 5;
-    float amax = 0.f;  // Mid0Args::sat
-
-    for (int i = tid; i < kM_Chunks * kWBytes / 16; i += kO_Threads)
-        reinterpret_cast<uint4 *>(wlds)[i] = reinterpret_cast<const uint4 *>(A.w)[i];
-    float pb[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) pb[e] = A.bias[(e & 3) + 8 * (e >> 2) + 4 * kgrp];
-    const int woff = l31 * 64 + ((kgrp ^ ((l31 >> 2) & 3)) * 16);
-    // B operand: halo pixel hp of this lane's output pixel for tap t; 64-byte pixel image, piece kgrp at position kgrp ^ ((hp >> 2) & 3),
-    // lo plane ^ 32 (conv_c4_kernel's half-chunk image: conflict-free for every ds_read_b128 lane group at any tap shift)
-    const int hp0 = (wave + 1) * kPitch + l31 + 1;
-    int boff[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int hp = hp0 + (t / 3 - 1) * kPitch + (t % 3 - 1);
-        boff[t] = hp * 64 + ((kgrp ^ ((hp >> 2) & 3)) * 16);
-    }
-    // this wave's requests: DMA instruction j moves 16 pixels x 64 B; lane = (pixel 16 j + (lane >> 2), position lane & 3) holds
-    // piece c = position ^ ((hp >> 2) & 3) = plane * 2 + g: source bytes [plane * 64 + g * 16, + 16) of the pixel's 128-byte chunk
-    // record (chunk and k-step go into the scalar offset)
-    int q_j[kQ_Req];
-    q_j[0] = 2 * wave;
-    q_j[1] = 2 * wave + 1;
-    q_j[2] = 16 + wave % 6;  // (waves 6, 7 repeat pieces 16, 17: the same bytes to the same place)
-    int d_yx[kQ_Req];
-    unsigned d_off[kQ_Req];
-#pragma unroll
-    for (int i = 0; i < kQ_Req; ++i) {
-        const int hp = q_j[i] * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((hp >> 2) & 3);
-        const int hy = hp / kPitch, hx = hp - hy * kPitch;
-        d_yx[i] = hp < kO_Halo ? (hy | (hx << 8)) : -1;
-        d_off[i] = (unsigned)(((long long)hy * A.W + hx) * A.ldx * 4 + (c >> 1) * 64 + (c & 1) * 16);
-    }
-    const unsigned halo_lds = lds_off(halo);
-    const unsigned char *xbase = static_cast<const unsigned char *>(A.x);
-
-    const int tiles_x = A.W / 32, tiles_y = A.H / kO_Waves;
-    const int per_img = tiles_x * tiles_y;
-    const int ntiles = A.B * per_img;
-    auto tile_origin = [&](int t, int &b, int &y0, int &x0) {
-        b = t / per_img;
-        const int r = t - b * per_img;
-        const int ty = r / tiles_x;
-        y0 = ty * kO_Waves;
-        x0 = (r - ty * tiles_x) * 32;
-    };
-    int t_first = blockIdx.x, t_stride = gridDim.x, t_end = ntiles;
-    if ((gridDim.x & 7) == 0) {  // XCD-contiguous tile ranges (see mid0_kernel)
-        const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
-        t_first = xcd * per + (blockIdx.x >> 3);
-        t_stride = gridDim.x >> 3;
-        t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
-    }
-    if (t_first >= t_end) return;
-
-    // the tile whose half-chunks are being REQUESTED (runs ahead of the one being multiplied; past the block's last tile the last one
-    // is requested again -- the bytes land in buffers nobody reads, and every wait keeps its count)
-    int r_tile = t_first, r_b, r_y0, r_x0;
-    c4::i32x4 r_rsrc;
-    unsigned r_voff[kQ_Req];
-    auto set_request_tile = [&](int t) {
-        r_tile = t;
-        tile_origin(t < t_end ? t : t_end - 1 - ((t_end - 1 - t_first) % t_stride), r_b, r_y0, r_x0);
-        // descriptor base = halo pixel (0, 0) of the tile (it may lie before the tensor: those lanes are out of the slice and read zeros)
-        r_rsrc = c4::make_rsrc(xbase + ((((long long)r_b * A.H + r_y0 - 1) * A.W + r_x0 - 1) * A.ldx + A.xoff) * 4);
-#pragma unroll
-        for (int i = 0; i < kQ_Req; ++i) {
-            const int yy = r_y0 - 1 + (d_yx[i] & 0xFF), xx = r_x0 - 1 + ((d_yx[i] >> 8) & 0xFF);
-            const bool ok = d_yx[i] >= 0 && (unsigned)yy < (unsigned)A.H && (unsigned)xx < (unsigned)A.W;
-            r_voff[i] = ok ? d_off[i] : c4::kPadOff;
-        }
-    };
-    auto request = [&](int hc) {  // half-chunk hc of the request tile -> buffer hc
-#pragma unroll
-        for (int i = 0; i < kQ_Req; ++i)
-            c4::dma_buf16(r_voff[i], r_rsrc, (unsigned)((hc >> 1) * 128 + (hc & 1) * 32), halo_lds + (unsigned)(hc * kQ_HBuf + q_j[i] * 1024));
-    };
-
-    struct Frag {
-        f16x8 wh, wl, xh, xl;
-    };
-    f32x16 acc;
-    auto half_chunk = [&](int hc, bool first) {  // 9 taps x (hi hi + lo hi + hi lo) from buffer hc
-        const unsigned char *hb = halo + hc * kQ_HBuf;
-        const unsigned char *wb = wlds + (hc >> 1) * kWBytes;
-        const int kk = hc & 1;
-        auto load_frag = [&](Frag &f, int t) {
-            const unsigned char *wt = wb + t * 4096 + (woff ^ (kk * 32));
-            f.wh = *reinterpret_cast<const f16x8 *>(wt);
-            f.xh = *reinterpret_cast<const f16x8 *>(hb + boff[t]);
-            f.wl = *reinterpret_cast<const f16x8 *>(wt + 2048);
-            f.xl = *reinterpret_cast<const f16x8 *>(hb + (boff[t] ^ 32));
-        };
-        if (first) acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        Frag f[3];
-        load_frag(f[0], 0);
-        load_frag(f[1], 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t + 2 < 9) load_frag(f[(t + 2) % 3], t + 2);
-            const Frag &g = f[t % 3];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(g.wh, g.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(g.wl, g.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(g.wh, g.xl, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-    };
-    // counted wait + barrier: the requests of the NEXT half-chunk to multiply have landed in every wave (a wave's queue behind them:
-    // the requests of the two half-chunks after it, and -- in the two waits that follow an epilogue -- its output stores), and every
-    // wave is done with the buffer that was multiplied
-#define MID0Q_SYNC(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory")
-
-    // ---- prologue: the first tile's four half-chunks; the first one has landed before anything is multiplied ----
-    set_request_tile(t_first);
-    request(0);
-    request(1);
-    request(2);
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (also: the weights are in the LDS)
-    int tile = t_first, t_b = r_b, t_y0 = r_y0, t_x0 = r_x0;
-    bool stored = false;  // an epilogue's stores sit in the queue in front of the requests issued since
-
-    while (true) {
-        // ===== half-chunk 0: request (tile, 3) -> buffer 3 (free since the previous tile's epilogue) =====
-        request(3);
-        half_chunk(0, true);
-        if (stored) MID0Q_SYNC(2 * kQ_Req + kQ_Stores); else MID0Q_SYNC(2 * kQ_Req);  // (tile, 1) landed; behind it: (tile, 2), [stores], (tile, 3)
-        // ===== half-chunk 1: request (next, 0) -> buffer 0 =====
-        set_request_tile(tile + t_stride);
-        request(0);
-        half_chunk(1, false);
-        if (stored) MID0Q_SYNC(2 * kQ_Req + kQ_Stores); else MID0Q_SYNC(2 * kQ_Req);  // (tile, 2) landed; behind it: [stores], (tile, 3), (next, 0)
-        // ===== half-chunk 2: request (next, 1) -> buffer 1 =====
-        request(1);
-        half_chunk(2, false);
-        MID0Q_SYNC(2 * kQ_Req);                                                        // (tile, 3) landed; behind it: (next, 0), (next, 1)
-        // ===== half-chunk 3: request (next, 2) -> buffer 2 =====
-        request(2);
-        half_chunk(3, false);
-        MID0Q_SYNC(2 * kQ_Req);                                                        // (next, 0) landed; everyone is done with buffer 3
-        // ===== epilogue: bias, ReLU, split; the hi plane, then the lo plane through this wave's 2 KB window in buffer 3
-        // ([32 pixels][64 B]: the destinations of its own requests 2 w and 2 w + 1 of the next half-chunk 3) =====
-        {
-            unsigned char *win = halo + 3 * kQ_HBuf + wave * 2048;
-            unsigned hi[8], lo[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(acc[4 * q + i], A.winv, pb[4 * q + i]), 0.f);
-                split2m(v[0], v[1], hi[2 * q], lo[2 * q], amax);
-                split2m(v[2], v[3], hi[2 * q + 1], lo[2 * q + 1], amax);
-            }
-            const long long row = ((long long)t_b * A.H + t_y0 + wave) * A.W + t_x0;
-            unsigned char *ybase = static_cast<unsigned char *>(A.y) + (row * A.ldy + A.yoff) * 4;
-            const int px0 = lane >> 2, pos = lane & 3;
-            // (LDS instructions of a wave execute in order: the lo plane's writes follow the hi plane's read-back)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2 *>(win + l31 * 64 + q * 16 + 8 * kgrp) = make_uint2(hi[2 * q], hi[2 * q + 1]);
-            const uint4 h0 = *reinterpret_cast<const uint4 *>(win + px0 * 64 + pos * 16);
-            const uint4 h1 = *reinterpret_cast<const uint4 *>(win + (px0 + 16) * 64 + pos * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2 *>(win + l31 * 64 + q * 16 + 8 * kgrp) = make_uint2(lo[2 * q], lo[2 * q + 1]);
-            const uint4 l0 = *reinterpret_cast<const uint4 *>(win + px0 * 64 + pos * 16);
-            const uint4 l1 = *reinterpret_cast<const uint4 *>(win + (px0 + 16) * 64 + pos * 16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is free: the next request(3) may land in it)
-            *reinterpret_cast<uint4 *>(ybase + (long long)px0 * A.ldy * 4 + pos * 16) = h0;
-            *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 16) * A.ldy * 4 + pos * 16) = h1;
-            *reinterpret_cast<uint4 *>(ybase + (long long)px0 * A.ldy * 4 + 64 + pos * 16) = l0;
-            *reinterpret_cast<uint4 *>(ybase + (long long)(px0 + 16) * A.ldy * 4 + 64 + pos * 16) = l1;
-        }
-        stored = true;
-        tile += t_stride;
-        if (tile >= t_end) break;
-        t_b = r_b;
-        t_y0 = r_y0;
-        t_x0 = r_x0;
-    }
-#undef MID0Q_SYNC
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this block's DMA may land after it has exited
-    if (A.sat && amax > 65504.f) *A.sat = 1;
-}
-
 }  // namespace
 
 // (one patch row more than is used: the partly empty last halo group reads a row beyond it that it then discards)
@@ -1123,25 +907,19 @@ size_t mid0_lds_bytes() { return (size_t)kM_Chunks * kWBytes + (size_t)kM_Chunks
 
 bool mid0_supported(const Mid0Args &k) { return k.H % kO_Waves == 0 && k.W % 32 == 0 && k.B > 0; }
 
-// QMRI_MID0 = 2: mid0q_kernel (four half-chunk buffers); 1 (default): mid0_kernel; 0: the layer runs on conv_s3_kernel (unet_engine.hip)
-static int mid0_variant() {
-    static const int v = std::getenv("QMRI_MID0") ? std::atoi(std::getenv("QMRI_MID0")) : 1;
-    return v;
-}
+// (round 6 built the same layer with FOUR half-chunk halo buffers -- one multiplied, three in flight instead of one, the epilogue staged
+//  plane by plane through 2 KB windows that are the wave's own next request destinations -- on the theory that the layer is bound by
+//  bytes in flight: correct (97 GPU tests), 2 490-2 500 us against 2 315 for this kernel, profiles/r06_mid0q_ab.txt.  Four barriers and four
+//  pipeline restarts per tile cost more than the deeper prefetch gains; removed again.)
 hipError_t mid0_launch(const Mid0Args &k, int num_cu, hipStream_t stream) {
     if (!mid0_supported(k)) return hipErrorInvalidValue;
-    const bool quad = mid0_variant() == 2;
-    const size_t lds = quad ? (size_t)kM_Chunks * kWBytes + 4 * (size_t)kQ_HBuf : mid0_lds_bytes();
-    const void *fn = quad ? reinterpret_cast<const void *>(mid0q_kernel) : reinterpret_cast<const void *>(mid0_kernel);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = mid0_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mid0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const long long ntiles = (long long)k.B * (k.H / kO_Waves) * (k.W / 32);
     const int grid = ntiles < num_cu ? (int)ntiles : num_cu;
     (void)hipGetLastError();
-    if (quad)
-        hipLaunchKernelGGL(mid0q_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
-    else
-        hipLaunchKernelGGL(mid0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
+    hipLaunchKernelGGL(mid0_kernel, dim3((unsigned)grid), dim3(kO_Threads), lds, stream, k);
     return hipGetLastError();
 }
 

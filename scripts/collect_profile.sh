@@ -22,4 +22,4 @@ python $R/bench.py --print-unet-hash > $OUT/unet_hash.txt
 # ---- per-kernel-family PMC of the parity mode (MfmaUtil, waits, LDS, clock, MFMAs per us) and the deconv_d4 / conv_s3 A/B of the transposed convolutions on this box ----
 bash $R/scripts/pmc_unet_mode.sh fp16x3 > $OUT/unet_pmc_by_kernel.txt 2>&1
 bash $R/scripts/env_ab.sh QMRI_D4 0 1 0 1 > $OUT/d4_ab.txt 2>&1
-python -m dosma_amd.build --clean > /dev/null  # experiment variants / probe binaries do not travel with the next push
+(cd $R && python -m dosma_amd.build --clean > /dev/null)  # experiment variants / probe binaries do not travel with the next push

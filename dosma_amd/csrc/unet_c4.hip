@@ -753,7 +753,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         const int prev_nb = t_nb;
         decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
         refresh_w_next(cur);
+#if defined(QMRI_C4_EPI_VMCNT) && QMRI_C4_EPI_VMCNT >= 0
+        // (round 6's race hunt: at most QMRI_C4_EPI_VMCNT of the epilogue's stores stay in flight into the next item)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(QMRI_C4_EPI_VMCNT) : "memory");
+#else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (tile_major ? (t_nb >> 1) != (prev_nb >> 1) : t_nb != prev_nb) {
             load_prm(t_nb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

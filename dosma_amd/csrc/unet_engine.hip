@@ -379,6 +379,8 @@ struct Unet {
     // output buffer's 32-bit words in 64 bits) is queued; qmri_unet2d_trace then appends "#<pass>.<layer>=<hex>;" entries of the
     // last forward, so two runs can be compared layer by layer (scripts/unet_layer_bisect.py)
     DevBuf csum_dev;
+    std::vector<std::unique_ptr<DevBuf>> keep_bufs;  // QMRI_UNET_KEEP=<layer>: a copy of that layer's output buffer per pass (qmri_debug_unet_keep)
+    std::vector<long long> keep_bytes;
     std::vector<std::string> csum_names;
     std::string csum_log;
     int csum_pass = 0;
@@ -678,6 +680,20 @@ int qmri_unet2d_trace(void *handle, char *buf, int32_t size) {
     return (int)t.size();
 }
 
+// debugging aid (QMRI_UNET_CHECKSUMS=1 QMRI_UNET_KEEP=<layer>): the kept copy of <layer>'s output buffer of pass `pass` of the last forward
+// -> host; returns the bytes the buffer holds (copies min(that, nbytes)), or a negative error.  Not part of include/qmri.h.
+long long qmri_debug_unet_keep(void *handle, int32_t pass, void *host, long long nbytes) {
+    if (!handle) return QMRI_ERR_ARG;
+    Unet *U = static_cast<Unet *>(handle);
+    if (pass < 0 || (size_t)pass >= U->keep_bufs.size() || !U->keep_bufs[(size_t)pass]) return QMRI_ERR_ARG;
+    if (hipSetDevice(U->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return QMRI_ERR_HIP;
+    const long long have = U->keep_bytes[(size_t)pass];
+    if (host && nbytes > 0 &&
+        hipMemcpy(host, U->keep_bufs[(size_t)pass]->p, (size_t)(have < nbytes ? have : nbytes), hipMemcpyDeviceToHost) != hipSuccess)
+        return QMRI_ERR_HIP;
+    return have;
+}
+
 int qmri_unet2d_set_precision(void *handle, int32_t precision) {
     if (!handle) return ufail(QMRI_ERR_ARG, "handle is NULL");
     static_cast<Unet *>(handle)->split3 = precision != 0;
@@ -711,6 +727,20 @@ static int csum(Unet *U, const char *name, const void *p, long long bytes, hipSt
                        U->csum_dev.as<unsigned long long>() + U->csum_names.size());
     U_TRY(hipGetLastError());
     U->csum_names.push_back("#" + std::to_string(U->csum_pass) + "." + name);
+    static const char *keep_name = std::getenv("QMRI_UNET_KEEP");
+    if (keep_name && std::strcmp(keep_name, name) == 0) {  // (the bisect's next step: the layer's bytes themselves, per pass)
+        const size_t ps = (size_t)U->csum_pass;
+        if (U->keep_bufs.size() <= ps) {
+            U->keep_bufs.resize(ps + 1);
+            U->keep_bytes.resize(ps + 1, 0);
+        }
+        if (!U->keep_bufs[ps] || U->keep_bytes[ps] < bytes) {
+            U->keep_bufs[ps].reset(new DevBuf);
+            U_TRY(U->keep_bufs[ps]->alloc((size_t)bytes));
+        }
+        U->keep_bytes[ps] = bytes;
+        U_TRY(hipMemcpyAsync(U->keep_bufs[ps]->p, p, (size_t)bytes, hipMemcpyDeviceToDevice, st));
+    }
     return QMRI_OK;
 }
 // (start of a forward: forget the previous one's; end: read the sums back)

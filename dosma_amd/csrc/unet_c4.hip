@@ -29,7 +29,7 @@
 //     buffer_load_dwordx4 ... lds: the address is an SGPR descriptor + a per-lane 32-bit offset + a scalar offset, so a
 //     request costs no vector ALU, and a lane outside the image reads beyond num_records = ZERO (the SAME padding; no zero
 //     line, no select; scripts/probes/buffer_lds.hip).  Waits are counted (s_waitcnt vmcnt(N): everything issued two or
-//     more steps ago has landed), one s_barrier per THREE steps = 144 MFMAs per wave (the ring protocol: see kBarEvery).
+//     more steps ago has landed), one s_barrier per TWO steps = 96 MFMAs per wave (the ring protocol and round 6's item-start hole: see kBarEvery).
 //   * the operand fragments of step s + 1 are read while step s multiplies (two register sets); the second halo buffer is an
 //     immediate offset; the first k-step of an item starts from the MFMA's constant-zero C operand (no zeroing pass).
 //   * work items are big, so the last, partial round of a launch is split by CHANNELS: each leftover item becomes four
@@ -87,23 +87,35 @@ constexpr int kRing = 8;                 // weight ring slots of [2 planes][32 C
 // earlier, so slots must be requested kAhead >= kBarEvery + kInFlight + 1 steps ahead, and a slot is only rewritten after a barrier
 // that follows its last read: kRing >= kAhead + kBarEvery - 1.  Measured on the nine c4 layers of the 384 x 384 network, same box,
 // alternating (profiles/r04_c4_ab.txt): every step 10.84 ms, every 2nd 10.72, every 3rd (taps 2, 5, 8 of a half-chunk) 10.68.
-// ROUND 6: THE DEFAULT IS EVERY SECOND STEP.  With a barrier every third step 2-4 % of the forwards of the 512 x 512 network came out
-// with one wave's rows of one work item wrong (logits off by up to 0.5; first seen as 27 mask voxels in bench.py's cfg5 leg;
-// scripts/unet_repeat_check.py, scripts/unet_layer_bisect.py: 18 of 20 times first in up3.conv1, the image-tile layer with the longest
-// K loop) -- on every box tried, never with the 384 x 384 network, not with every wait widened to vmcnt(0) lgkmcnt(0), not with
-// default-policy stores, not with idle cycles behind every request, not with kernels serialised by the host, and not when one wave
-// is forced two steps behind the others after every barrier.  Every second step: 0 of 4 600 forwards; every step: 0 of 1 000.  The
-// ring arithmetic below holds for all three cadences and the mechanism is NOT understood (DESIGN 6.6 has the record); the cadence
-// that has never been seen to fail costs 0.4 % on these layers and tests/test_unet_fullsize_gpu.py repeats the 512 x 512 forward
-// bit for bit.
+// ROUND 6: THE DEFAULT IS EVERY SECOND STEP -- the every-third cadence of rounds 4-5 had a hole AT THE START OF A WORK ITEM.  The ring
+// inequality above assumes that the operands of step u are read during step u - 1.  That is false for step 0 of every item: the last
+// step of the previous item reads nothing ahead (the epilogue needs the registers), so step 0's operands are read by load_frags behind
+// next_item's barrier -- in the SAME barrier interval as steps 0, 1, 2 when the first barrier of the item stands at tap 2.  The request of
+// step 2 (the weights of step 8) lands in ring slot (2 + kAhead) mod kRing = step 0's slot: a wave that runs two steps ahead rewrites it while
+// a late wave has not read step 0's weight fragments yet, and the late wave multiplies step 0's pixels by step 8's weights for the column
+// tile(s) it had not read -- one wave's 4 rows x 32 pixels x 32 or 64 channels of one item off by one k-step's contribution.  Measured:
+// 2-12 % of the forwards of the 512 x 512 network (its up3.conv1 first in 18 of 20), 0.07 % at 384 x 384; the damaged unit attributed by
+// scripts/c4_keep_model.py to "k-step 0 multiplied by the weights of step 8" with correlation 0.996; and ONE bare s_barrier behind step 1 of
+// every item (-DQMRI_C4_BAR3F) removes it (0 of 1 500 forwards against 184 of 1 500 on the same box), as does any cadence whose first barrier
+// stands at tap <= kRing - kAhead - 1 = 1: every second step 0 of 5 600, every step 0 of 1 000 (profiles/r06_c4_race.txt).  The
+// condition is a static_assert now.  Every second step costs 0.3 % against every third on the forward and nothing against third + fence.
 #if defined(QMRI_C4_BAR1)                // (A/B switches)
 constexpr int kBarEvery = 1, kInFlight = 3, kAhead = 5;
-#elif defined(QMRI_C4_BAR3)              // (rounds 4-5's default: see above)
+#elif defined(QMRI_C4_BAR3) || defined(QMRI_C4_BAR3F)  // (rounds 4-5's default: see above; BAR3F = with the item fence)
 constexpr int kBarEvery = 3, kInFlight = 2, kAhead = 6;
 #else
 constexpr int kBarEvery = 2, kInFlight = 3, kAhead = 6;  // weights are requested kAhead steps ahead
 #endif
 static_assert(kAhead >= kBarEvery + kInFlight + 1 && 8 >= kAhead + kBarEvery - 1, "ring protocol");
+// item start: step 0's operands are read behind next_item's barrier; the first request into step 0's slot is issued at step 8 - kAhead, so
+// a barrier must stand behind one of the steps 0 .. 7 - kAhead (the first barrier of an item: tap kBarEvery - 1; BAR3F adds its own)
+#if !defined(QMRI_C4_BAR3)
+static_assert(kBarEvery - 1 <= 8 - kAhead - 1
+#if defined(QMRI_C4_BAR3F)
+              || true
+#endif
+              , "the first barrier of a work item must separate load_frags from the request that rewrites step 0's ring slot");
+#endif
 // requests a wave issues in tap t: the step's weight pieces + the halo pieces of c4_halo_pieces(t, n) (n = pieces per wave and
 // half-chunk, spread over the first kHaloTaps taps: 3 3 2 2 for 10, 4 4 3 3 for 14); the counted wait at the end of tap t lets the
 // requests of the last kInFlight steps (taps wrap: every half-chunk has the same pattern) stay in flight
@@ -448,21 +460,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
     // (half NH, tap NT: buffer NH, next ring slot) are read into NXT while it multiplies.  Requests: the weights of the step
     // kAhead ahead, and in the first taps the halo pieces of the half-chunk after this one.  The counted wait at the end lets the
     // requests of this step and the two before it stay in flight (c4_in_flight).
-#if defined(QMRI_C4_WAIT0)   // (experiment build, round 6's race hunt: every barrier waits for everything this wave has in flight, LDS reads included)
-#define C4_WAIT(N) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#elif defined(QMRI_C4_WAITL) // (experiment build: the counted wait + this wave's LDS reads)
-#define C4_WAIT(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory")
-#else
 #define C4_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
-#endif
-#ifdef QMRI_C4_SKEW  // (experiment build, round 6's race hunt: wave QMRI_C4_SKEW falls ~2 steps behind after the barriers at the taps of the mask
-                     //  QMRI_C4_SKEW_TAPS (bit t = tap t; default: every barrier) -- a skew hazard of the ring / halo protocol then fails every time)
-#ifndef QMRI_C4_SKEW_TAPS
-#define QMRI_C4_SKEW_TAPS 0x1ff
-#endif
-#define C4_SKEW(T) do { if (((QMRI_C4_SKEW_TAPS) >> (T)) & 1) { if (wave == (QMRI_C4_SKEW)) __builtin_amdgcn_s_sleep(60); } } while (0)
+// -DQMRI_C4_BAR3F (experiment: the proof of DESIGN 6.6's mechanism): the barrier every third step PLUS one bare s_barrier behind step 1 of every
+// work item -- the operands of an item's step 0 are read behind next_item's barrier, i.e. in the same barrier interval as the request of
+// step 2, which lands in step 0's ring slot.  (The hunt's other builds -- every wait widened to vmcnt(0) lgkmcnt(0), one wave put to sleep behind
+// every loop barrier, the epilogue's stores drained in next_item, idle cycles behind every request -- are in git history: round 6.)
+#if defined(QMRI_C4_BAR3F)
+#define C4_ITEM_FENCE(H, T) if constexpr ((H) == 0 && (T) == 1) { if (chunk == 0) asm volatile("s_barrier" ::: "memory"); }
 #else
-#define C4_SKEW(T)
+#define C4_ITEM_FENCE(H, T)
 #endif
 #define C4_STEP_(H, T, CUR, NXT, FIRST, SUB)                                                                       \
     {                                                                                                              \
@@ -490,7 +496,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         c4_sched_step<0, kRT, (SUB::value ? 1 : kCT)>();                                                           \
         constexpr int kN_ = c4_in_flight((T), kWPieces, kHSlots);                                                  \
         if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS_STEP(1); }                                     \
-        if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) { C4_WAIT(kN_); C4_SKEW(T); } \
+        if constexpr (kBarEvery == 1 || (kBarEvery == 2 && ((9 * (H) + (T)) & 1)) || (kBarEvery == 3 && (T) % 3 == 2)) C4_WAIT(kN_); \
+        C4_ITEM_FENCE(H, T)                                                                                         \
         if constexpr ((H) == 0 && (T) == 2) { if (chunk == 0) C4_TS_STEP(2); }                                     \
         slot = (slot + 1) & (kRing - 1);                                                                           \
     }
@@ -753,12 +760,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_c4_kernel(const ConvS3Args A
         const int prev_nb = t_nb;
         decode_work(item_at(cur), t_nb, t_b, t_y0, t_x0, t_f0);
         refresh_w_next(cur);
-#if defined(QMRI_C4_EPI_VMCNT) && QMRI_C4_EPI_VMCNT >= 0
-        // (round 6's race hunt: at most QMRI_C4_EPI_VMCNT of the epilogue's stores stay in flight into the next item)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(QMRI_C4_EPI_VMCNT) : "memory");
-#else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         if (tile_major ? (t_nb >> 1) != (prev_nb >> 1) : t_nb != prev_nb) {
             load_prm(t_nb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

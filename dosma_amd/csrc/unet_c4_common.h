@@ -25,15 +25,9 @@ __device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(s
 // against num_records: beyond it the lane receives zeros) + soffset (scalar, not range-checked).  Inline asm for the same reason
 // as unet_s3.hip's dma16: hipcc neither counts nor drains it; every wait in this file is a hand-counted s_waitcnt vmcnt(N).
 __device__ __forceinline__ void dma_buf16(unsigned voff, const i32x4 &rsrc, unsigned soff, unsigned lds_dst) {
-#if defined(QMRI_DMA_M0PAD)  // (experiment build, round 6's race hunt: idle cycles behind the request before anything can touch M0 again)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_nop 7\n\ts_nop 7" ::"v"(voff), "s"(rsrc),
-                 "s"(__builtin_amdgcn_readfirstlane((int)soff)), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst))
-                 : "memory");
-#else
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc),
                  "s"(__builtin_amdgcn_readfirstlane((int)soff)), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst))
                  : "memory");
-#endif
 }
 
 __device__ __forceinline__ void nt_store16(void *dst, const uint4 &v) {

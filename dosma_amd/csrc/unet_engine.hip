@@ -680,7 +680,8 @@ int qmri_unet2d_trace(void *handle, char *buf, int32_t size) {
     return (int)t.size();
 }
 
-// debugging aid (QMRI_UNET_CHECKSUMS=1 QMRI_UNET_KEEP=<layer>): the kept copy of <layer>'s output buffer of pass `pass` of the last forward
+// debugging aid (QMRI_UNET_CHECKSUMS=1 QMRI_UNET_KEEP=<layer>[,<layer>...]): the kept copy of a layer's output buffer of the last forward; `pass` = 64 * (index of
+// the layer in the list) + pass
 // -> host; returns the bytes the buffer holds (copies min(that, nbytes)), or a negative error.  Not part of include/qmri.h.
 long long qmri_debug_unet_keep(void *handle, int32_t pass, void *host, long long nbytes) {
     if (!handle) return QMRI_ERR_ARG;
@@ -727,9 +728,24 @@ static int csum(Unet *U, const char *name, const void *p, long long bytes, hipSt
                        U->csum_dev.as<unsigned long long>() + U->csum_names.size());
     U_TRY(hipGetLastError());
     U->csum_names.push_back("#" + std::to_string(U->csum_pass) + "." + name);
-    static const char *keep_name = std::getenv("QMRI_UNET_KEEP");
-    if (keep_name && std::strcmp(keep_name, name) == 0) {  // (the bisect's next step: the layer's bytes themselves, per pass)
-        const size_t ps = (size_t)U->csum_pass;
+    // QMRI_UNET_KEEP=<layer>[,<layer>...]: the bytes themselves, per (layer, pass) -- slot = 64 * index in the list + pass
+    static const std::vector<std::string> keep_names = [] {
+        std::vector<std::string> v;
+        if (const char *e = std::getenv("QMRI_UNET_KEEP")) {
+            std::string t(e);
+            size_t a = 0;
+            while (a <= t.size()) {
+                const size_t b = t.find(',', a);
+                v.push_back(t.substr(a, b == std::string::npos ? std::string::npos : b - a));
+                if (b == std::string::npos) break;
+                a = b + 1;
+            }
+        }
+        return v;
+    }();
+    for (size_t ki = 0; ki < keep_names.size(); ++ki) {
+        if (keep_names[ki] != name || U->csum_pass >= 64) continue;
+        const size_t ps = ki * 64 + (size_t)U->csum_pass;
         if (U->keep_bufs.size() <= ps) {
             U->keep_bufs.resize(ps + 1);
             U->keep_bytes.resize(ps + 1, 0);

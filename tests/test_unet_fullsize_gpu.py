@@ -176,11 +176,12 @@ def test_512_logits_at_cfg5_batch(net):
 
 
 def test_512_forward_repeats_bit_for_bit(net):
-    """Round 6's race: with conv_c4_kernel's barrier every THIRD k-step 2-4 % of the forwards of the 512 x 512 network came out with one
-    wave's rows of one work item wrong (logits off by up to 0.5), on every box tried -- found through 27 differing mask voxels in
+    """Round 6's race: with conv_c4_kernel's barrier every THIRD k-step 2-12 % of the forwards of the 512 x 512 network came out with one
+    wave's rows of one work item wrong (logits off by up to 0.5) -- step 0 of an item read its weights behind next_item's barrier, in the
+    same barrier interval as the request of step 2 that rewrites their ring slot.  Found through 27 differing mask voxels in
     bench.py's cfg5 leg, not by this suite, whose repeat tests ran a handful of forwards.  Here: 80 device-resident forwards of a
-    160-slice volume in passes of 32 (the configuration with the highest measured rate: 3.7 % per forward, i.e. a 95 % chance to see
-    the old cadence fail), every one equal to the first bit for bit.  (Every second step -- the default since -- measured 0 of 4 600.)"""
+    160-slice volume in passes of 32 (the configuration with the highest measured rate: >= 3.7 % per forward, i.e. >= 95 % to see the old
+    cadence fail), every one equal to the first bit for bit.  (Every second step -- the default since -- measured 0 of 5 600.)"""
     import torch
 
     w, tensors = net

@@ -117,6 +117,8 @@ def test_edge_cases_golden(golden, relerr):
     assert same_class.mean() > 0.99
     both = same_class & ok
     d = relerr(o["popt"][both], g["popt"][both]).max(axis=1)
+    # (how loose is 5 %?  Two builds of scipy itself -- 1.15.3 and the Fortran-MINPACK 1.7.1 -- differ beyond 1e-4 on 4.2 % of these same
+    #  columns with identical stop codes: tests/test_oracle.py::test_fixtures_hold_under_the_fortran_minpack_scipy)
     assert (d > RTOL).mean() < 0.05          # measured 3.8 % (18 of 473; scripts/edge_noise_check.py)
     assert (d > 10 * RTOL).mean() < 0.02     # measured 1.3 %
     # ... and the tail is the ill-conditioning of fitting noise, not a different algorithm: against the C restatement of lmdif run

@@ -332,3 +332,21 @@ def test_monoexponential_fit_with_more_samples_than_the_kernels_keep(golden):
     assert tc.volume[0, 0, 0] == 0 and (tc.volume > 0).sum() > 100
     np.testing.assert_allclose(popt.volume, g["popt_masked"], rtol=1e-9, equal_nan=True)
     np.testing.assert_allclose(r2m.volume, g["r2_masked"], rtol=1e-9, atol=1e-12, equal_nan=True)
+
+
+def test_bench_gpu_sampler_never_raises_without_a_gpu():
+    """bench.py's clock / power sampler (hwmon files of the device's PCI function, else rocm-smi) on a box with neither: it starts, stops
+    and summarises to "no samples" -- the bench line then carries nulls, it does not fail."""
+    import time
+
+    import torch
+
+    import bench
+
+    sp = bench.GpuSampler(torch, 0)
+    with sp:
+        time.sleep(0.02)
+    out = sp.summary()
+    assert set(out) >= {"samples", "how", "sclk_ghz_mean", "power_w_mean"}
+    assert out["sclk_ghz_mean"] is None or out["sclk_ghz_mean"] > 0
+    assert bench.effective_cores() is None or bench.effective_cores() > 0

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--input", default="bench")
     ap.add_argument("--churn", type=int, default=1, help="allocate / free device memory between forwards")
+    ap.add_argument("--precision", default="fp16x3")
     args = ap.parse_args()
     import torch
 
@@ -32,8 +33,8 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     H, S = args.hw, args.slices
-    eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), H, H, max_batch=args.batch, precision="fp16x3", device=0)
-    if args.input == "bench":
+    eng = L.Unet2dEngine(W.to_abi_order(W.random_weights(seed=0)), H, H, max_batch=args.batch, precision=args.precision, device=0)
+    if args.input == "bench" and S * H * H <= 512 * 512 * 160:
         y = bench.make_volume(torch, dev, 20260928)
         x = y[0][: S * H * H]
     else:

@@ -459,3 +459,25 @@ def test_results_do_not_depend_on_the_order_voxels_are_pulled():
         assert p.returncode == 0, p.stderr[-2000:]
         shas.append([l for l in p.stdout.splitlines() if l.startswith("SHA")][0])
     assert shas[0] == shas[1] == shas[2], shas
+
+
+def test_fit_repeats_bit_for_bit():
+    """The fit kernels hand out their work dynamically (waves pull tiles and refill idle lanes through atomic counters): which wave fits which
+    voxel changes from launch to launch, the per-voxel results must not.  40 launches of the masked, log-linear-initialised fit on 1 Mi voxels
+    (30 % background), every output array equal to the first launch's bit for bit -- the fit-side twin of
+    test_unet_fullsize_gpu.py::test_512_forward_repeats_bit_for_bit (round 6: scripts/fit_repeat_check.py ran 300 launches of the bench volume
+    and 50 calls of every other entry: one distinct result each, profiles/r06_repeat_sweep.txt)."""
+    rng = np.random.default_rng(21)
+    E, N = 8, 1 << 20
+    x = np.arange(1, E + 1) * 10.0
+    y = (rng.uniform(300, 1500, N) * np.exp(-x[:, None] / rng.uniform(15, 80, N)) + 18 * rng.standard_normal((E, N))).astype(np.float32)
+    y[:, rng.random(N) < 0.3] = 0
+    mask = rng.random(N) < 0.6
+    first = None
+    for rep in range(40):
+        o = L.monoexp_fit_host(x, y, mask=mask, init=L.INIT_LOGLIN, want_info=True)
+        got = [np.ascontiguousarray(o[k]).view(np.uint8) for k in ("popt", "r2", "info", "nfev")]
+        if first is None:
+            first = [g.copy() for g in got]
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(got, first)), f"launch {rep} differs from the first"

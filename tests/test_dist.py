@@ -286,6 +286,14 @@ def test_bench_one_rank_through_rccl():
     c5 = out["cfg5"]
     assert c5["per_rank"] == [1] and c5["weights_broadcast"]["identical_on_all_ranks"] and c5["weights_broadcast"]["bytes"] > 1.3e8
     assert out["parity"]["nfev_equal_frac"] > 0.999 and out["unet2d"]["value"] > 100
+    # round 6: shader clock / board power over the timed loops, the sustained UNet leg and the reference-clock figure are in every line
+    assert set(out["roofline"]["clock_samples"]) >= {"samples", "sclk_ghz_mean", "power_w_mean"} and "sclk_ghz_mean" in out["roofline"]
+    u = out["unet2d"]
+    assert u["sustained"]["steps"] >= 2 and u["sustained"]["slices_per_s_this_rank"] > 100 and "value_at_ref_clock" in u
+    if u["roofline"]["clock_samples"]["samples"]:   # (a box that exposes the hwmon files)
+        assert 0.5 < u["roofline"]["sclk_ghz_mean"] < 3.0 and 100 < u["roofline"]["power_w_mean"] < 1500
+        assert abs(u["value_at_ref_clock"] - u["value"] * 1.82 / u["sustained"]["sclk_ghz_mean"]) < 1e-6 * u["value"]
+    assert c5["schedule"] == "back_to_back" and c5["every_volume_once"] and c5["two_streams"]["same_results"]
 
 
 @pytest.mark.gpu

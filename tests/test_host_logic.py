@@ -350,3 +350,24 @@ def test_bench_gpu_sampler_never_raises_without_a_gpu():
     assert set(out) >= {"samples", "how", "sclk_ghz_mean", "power_w_mean"}
     assert out["sclk_ghz_mean"] is None or out["sclk_ghz_mean"] > 0
     assert bench.effective_cores() is None or bench.effective_cores() > 0
+
+
+def test_bench_cpu_baseline_reports_the_fastest_rung():
+    """bench.py's cpu_baseline on a small CPU tensor (no GPU): the reference's call pattern through a worker ladder, `value` = the faster of the
+    ladder's two best rungs timed on the whole sample, the worker count stated (Pool(256) on a 16-core quota cost the
+    baseline 25 %)."""
+    import torch
+
+    import bench
+
+    rng = np.random.default_rng(2)
+    n = 3000
+    y = (rng.uniform(300, 1500, n) * np.exp(-bench.TE[:, None] / rng.uniform(15, 80, n)) + 18 * rng.standard_normal((bench.E, n))).astype(np.float32)
+    y[:, ::4] = 0
+    out = bench.cpu_baseline(torch.from_numpy(y), cores_cap=2)
+    assert out["kind"] == "port" and out["unit"] == "voxel-fits/s" and out["value"] > 100
+    assert out["workers"] == out["cores"] and out["workers"] in (1, 2) and out["visible_cores"] == 2
+    assert set(out["worker_ladder_voxel_fits_per_s"]) == {"1", "2"}
+    assert str(out["workers"]) in out["full_sample_voxel_fits_per_s_by_workers"]
+    assert out["value"] == max(out["full_sample_voxel_fits_per_s_by_workers"].values())
+    assert f"Pool({out['workers']})" in out["sample"]

@@ -571,9 +571,10 @@ def bench_unet(L, torch, dist, device, local_rank, world, args, barrier, red_dev
                      "`slices_per_s_bf16`",
         "slices_per_s_bf16": res["bf16"],
         "value_at_ref_clock": ref_clock,
-        "value_at_ref_clock_note": f"value x {UNET_REF_SCLK_GHZ} GHz / sclk_ghz_mean of the sustained leg (rank 0's GPU): the MFMA kernels run "
-                                   "against the 1.4 kW board cap and their time follows the clock the box holds; compare rounds on this "
-                                   "field (README: comparing rounds), not on `value`",
+        "value_at_ref_clock_note": f"value x {UNET_REF_SCLK_GHZ} GHz / sclk_ghz_mean of the sustained leg (rank 0's GPU), as VERDICT r5 asked.  CAVEAT, measured "
+                                   "in round 6 on three boxes at the same 1.37 kW: reported sclk 1.806 / 1.825 / 1.959 GHz, sustained 5417 / 5430 / 5500 slices/s -- the "
+                                   "rate does NOT follow the reported clock one to one (+8.5 % clock, +1.5 % rate), so this field over-corrects; read `value` with "
+                                   "`sustained.sclk_ghz_mean` / `power_w_mean` beside it and trust only same-box alternating A/Bs below +-2 % (README: comparing rounds)",
         "sustained": sustained,
         "data": "synthetic (random He weights of the reference architecture, random-normal input)",
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

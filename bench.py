@@ -801,7 +801,7 @@ def bench_cfg5(L, lib, torch, qd, device, local_rank, rank, world, args, vol0):
         # which rank ran which volume (gathered after the clock): every index 0 .. n_vol - 1 owned by exactly one rank
         "volume_owner": [None if np.isnan(r) else int(r) for r in summ["owner_rank"]],
         "every_volume_once": bool(np.array_equal(summ["volume_index"], np.arange(n_vol)) and sum(out["per_rank"]) == n_vol
-                                  and all(int(r) == v % world for v, r in enumerate(summ["owner_rank"]))),
+                                  and all((not np.isnan(r)) and int(r) == v % world for v, r in enumerate(summ["owner_rank"]))),
         "weights_broadcast": {"bytes": wbytes, "seconds": t_bcast, "make_seconds_rank0": t_make,
                               "identical_on_all_ranks": bool(np.all(sums == sums[0]) and np.all(crcs == crcs[0])),
                               "crc32_per_rank": [int(c) for c in crcs],

@@ -181,7 +181,7 @@ def test_512_forward_repeats_bit_for_bit(net):
     same barrier interval as the request of step 2 that rewrites their ring slot.  Found through 27 differing mask voxels in
     bench.py's cfg5 leg, not by this suite, whose repeat tests ran a handful of forwards.  Here: 80 device-resident forwards of a
     160-slice volume in passes of 32 (the configuration with the highest measured rate: >= 3.7 % per forward, i.e. >= 95 % to see the old
-    cadence fail), every one equal to the first bit for bit.  (Every second step -- the default since -- measured 0 of 5 600.)"""
+    cadence fail), every one equal to the first bit for bit.  (Every second step -- the default since -- measured 0 of 15 100.)"""
     import torch
 
     w, tensors = net
